@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REFERENCE itself on CPU.
+
+Build-container only: it imports ``/root/reference`` (which never travels to the GPU box) with the
+three shims of SURVEY.md Appendix A (stub ``imageio``/``cv2``; ``Tensor.cuda`` = identity; no
+``config_parser``).  The fixtures are data — inputs and the reference's outputs — and are what pins
+``oracle/mofa_oracle.py``.  Large weights are NOT stored: they are regenerated on both sides from the
+seeded recipe in ``mofanerf_amd/synth.py``.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+for _m in ("imageio", "cv2"):
+    sys.modules[_m] = types.ModuleType(_m)
+torch.Tensor.cuda = lambda self, *a, **k: self
+_default_tensor = torch.Tensor
+
+from models import render_class  # noqa: E402  (reference)
+from models.model import NeRF, StyleModule, get_embedder  # noqa: E402
+from tools.run_nerf_helpers import get_rays, sample_pdf  # noqa: E402
+from tools.load_facescape import pose_spherical  # noqa: E402
+
+torch.autograd.set_detect_anomaly(False)
+
+from mofanerf_amd import synth  # noqa: E402
+
+torch.manual_seed(0)
+np.random.seed(0)
+torch.set_num_threads(8)
+
+
+def npd(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def save(name, d):
+    p = os.path.join(HERE, name)
+    np.savez_compressed(p, **npd(d))
+    print(f"wrote {name}: {os.path.getsize(p) / 1024:.1f} KiB, {len(d)} arrays")
+
+
+def mk_nerf(D, W, seed=0, tag="nerf"):
+    m = NeRF(D=D, W=W, input_ch_shapeCodes=50, input_ch_textureCodes=256, input_ch=63 + 30, output_ch=5,
+             skips=[4], input_ch_views=27, use_viewdirs=True)
+    m.load_state_dict(synth.nerf_state(D, W, seed, tag))
+    return m.eval()
+
+
+def mk_renderer(netchunk, seed=0, with_tex=False):
+    embed_fn, _ = get_embedder(10, 0)
+    embeddirs_fn, _ = get_embedder(4, 0)
+    r = render_class.myRenderer(embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=netchunk, uvCodesLen=256,
+                                expCodesLen=30)
+    r.idSpecificMod.load_state_dict(synth.style_state(seed))
+    if with_tex:
+        r.texEncoder.load_state_dict(synth.tex_encoder_state(seed))
+    for dst, src in zip(r.expCodes_Sigma, synth.exp_sigma(seed)):
+        dst.data[:] = src
+    return r.eval()
+
+
+def kwargs_for(r, coarse, fine, perturb=0.0, raw_noise_std=0.0, white_bkgd=False, N_samples=64, N_importance=64):
+    return dict(network_query_fn=r.run_network, perturb=perturb, N_importance=N_importance, network_fine=fine,
+                N_samples=N_samples, network_fn=coarse, use_viewdirs=True, white_bkgd=white_bkgd,
+                raw_noise_std=raw_noise_std, ndc=False, lindisp=False, near=8.0, far=26.0)
+
+
+class Recorder:
+    """Record the arguments/results of raw2outputs and sample_pdf as render_rays calls them."""
+
+    def __init__(self):
+        self.r2o, self.spdf = [], []
+        self._r2o, self._spdf = render_class.raw2outputs, render_class.sample_pdf
+
+    def __enter__(self):
+        def r2o(raw, z, d, *a, **k):
+            out = self._r2o(raw, z, d, *a, **k)
+            self.r2o.append(dict(raw=raw.detach().clone(), z=z.detach().clone(), weights=out[3].detach().clone()))
+            return out
+
+        def spdf(bins, w, n, **k):
+            out = self._spdf(bins, w, n, **k)
+            self.spdf.append(dict(samples=out.detach().clone()))
+            return out
+
+        render_class.raw2outputs, render_class.sample_pdf = r2o, spdf
+        return self
+
+    def __exit__(self, *a):
+        render_class.raw2outputs, render_class.sample_pdf = self._r2o, self._spdf
+
+
+# ------------------------------------------------------------------------------------------------
+def g1_kats():
+    out = {}
+    rng = np.random.default_rng(1)
+    # Embedder, incl. |x| up to 12 (arguments up to 6e3 rad at 2^9)
+    x = torch.from_numpy(np.concatenate([rng.uniform(-12, 12, (300, 3)), [[0.5, -1.25, 2.0]], [[0, 0, 0]],
+                                         [[11.999, -11.999, 7.25]]]).astype(np.float32))
+    out["embed_x"] = x
+    out["embed_L10"] = get_embedder(10, 0)[0](x)
+    out["embed_L4"] = get_embedder(4, 0)[0](x)
+    # raw2outputs
+    for S in (64, 128):
+        R = 48
+        raw = torch.from_numpy(rng.normal(0, 1.5, (R, S, 4)).astype(np.float32))
+        raw[0, :, 3] = -1.0                  # zero-opacity ray -> acc 0 -> NaN disp
+        raw[1, :, 3] = 50.0                  # saturated from the first sample
+        z = torch.sort(torch.from_numpy(rng.uniform(8, 26, (R, S)).astype(np.float32)), -1)[0]
+        z[2] = torch.linspace(8, 26, S)
+        d = torch.from_numpy(rng.normal(0, 1, (R, 3)).astype(np.float32))
+        for wb in (False, True):
+            o = render_class.raw2outputs(raw, z, d, 0, wb)
+            for n, v in zip(("rgb", "disp", "acc", "weights", "depth"), o):
+                out[f"r2o{S}_{int(wb)}_{n}"] = v
+        out[f"r2o{S}_raw"], out[f"r2o{S}_z"], out[f"r2o{S}_d"] = raw, z, d
+        o = render_class.raw2outputs(raw, z, d, 0.7, False, pytest=True)     # noise = seed-0 np.random.rand * std
+        for n, v in zip(("rgb", "disp", "acc", "weights", "depth"), o):
+            out[f"r2o{S}_noise_{n}"] = v
+    o = render_class.raw2outputs(torch.tensor([[[0.1, -0.2, 0.3, 0.5], [1, 0, -1, 2], [0, 0.5, 0.25, -1],
+                                                [-0.5, 0.2, 0.1, 0.7]]]), torch.tensor([[8., 14, 20, 26]]),
+                                 2 * torch.tensor([[0, 0.6, -0.8]]))
+    out["r2o_anchor_rgb"], out["r2o_anchor_disp"], out["r2o_anchor_weights"], out["r2o_anchor_depth"] = o[0], o[1], o[3], o[4]
+    # sample_pdf
+    R = 40
+    bins = torch.sort(torch.from_numpy(rng.uniform(8, 26, (R, 63)).astype(np.float32)), -1)[0]
+    w = torch.from_numpy((rng.uniform(0, 1, (R, 62)) ** 6).astype(np.float32))
+    w[0] = 0.0                                # all-zero weights: uniform pdf
+    w[1] = 0.0; w[1, 30] = 1.0                # one spike: the denom<1e-5 branch everywhere else
+    w[2, :31] = 0.0                           # leading empty bins
+    out["spdf_bins"], out["spdf_w"] = bins, w
+    out["spdf_det"] = sample_pdf(bins, w, 64, det=True)
+    out["spdf_rand"] = sample_pdf(bins, w, 64, det=False, pytest=True)   # u = seed-0 np.random.rand(R,64)
+    out["spdf_anchor"] = sample_pdf(torch.linspace(8, 26, 7)[None], torch.tensor([[0, .1, .6, .2, .05, 0]]), 8, det=True)
+    # get_rays
+    for ang in (-60.0, 0.0, 60.0):
+        K = np.array([[600., 0, 128], [0, 600., 128], [0, 0, 1]])
+        c2w = pose_spherical(ang, 0.0, 16.0)
+        ro, rd = get_rays(256, 256, K, c2w[:3, :4])
+        tag = f"rays{int(ang)}"
+        out[tag + "_c2w"], out[tag + "_o"], out[tag + "_d_sub"] = c2w, ro[0, 0], rd[::37, ::41]
+    out["pose_m17_23_16"] = pose_spherical(-17.0, 23.0, 16.0)
+    # NeRF.forward at tiny widths; StyleModule
+    for D, W in ((8, 64), (10, 64), (8, 96)):
+        net = mk_nerf(D, W)
+        n = 200
+        a = torch.from_numpy(rng.normal(0, 1, (n, 93)).astype(np.float32))
+        b = torch.from_numpy(rng.normal(0, 0.05, (1, 50)).astype(np.float32)).expand(n, -1)
+        c = torch.from_numpy(rng.normal(0, 1, (n, 27)).astype(np.float32))
+        t = torch.from_numpy(rng.normal(0.2, 0.3, (1, 256)).astype(np.float32)).expand(n, -1)
+        with torch.no_grad():
+            out[f"nerf{D}x{W}_out"] = net(a, b, c, t)
+        out[f"nerf{D}x{W}_pts"], out[f"nerf{D}x{W}_bm"], out[f"nerf{D}x{W}_views"], out[f"nerf{D}x{W}_tex"] = a, b[:1], c, t[:1]
+    sm = StyleModule()
+    sm.load_state_dict(synth.style_state(0))
+    bm = synth.codes(0)[0]
+    with torch.no_grad():
+        s, b = sm(bm)
+    out["style_bm"], out["style_scale"], out["style_bias"] = bm, s, b
+    save("kat.npz", out)
+
+
+def _render_case(name, H, K, angle, Dc, Wc, Df, Wf, chunk, netchunk, perturb=0.0, noise=0.0, white=False,
+                 pytest=False, intermediates=True, seed=0):
+    r = mk_renderer(netchunk, seed)
+    coarse, fine = mk_nerf(Dc, Wc, seed, "coarse"), mk_nerf(Df, Wf, seed, "fine")
+    kw = kwargs_for(r, coarse, fine, perturb, noise, white)
+    if pytest:
+        kw["pytest"] = True
+    bm, tex, exp = synth.codes(seed)
+    c2w = pose_spherical(angle, 0.0, 16.0)[:3, :4]
+    out = dict(c2w=c2w, K=K, bm=bm, tex=tex, exp=exp, H=H, chunk=chunk, netchunk=netchunk,
+               arch=np.array([Dc, Wc, Df, Wf]), seed=seed, perturb=perturb, noise=noise, white=int(white))
+    with torch.no_grad(), Recorder() as rec:
+        rgb, disp, acc, ex = r.render_fitting(H, H, K, chunk=chunk, c2w=c2w, shapeCodes=bm, uvCodes=tex,
+                                              expType=20, expCodes=exp, retraw=True, **kw)
+    out.update(rgb=rgb, disp=disp, acc=acc, rgb0=ex["rgb0"], disp0=ex["disp0"], acc0=ex["acc0"], z_std=ex["z_std"])
+    if intermediates:
+        nch = len(rec.spdf)
+        out["z_coarse"] = torch.cat([rec.r2o[2 * i]["z"] for i in range(nch)])
+        out["raw_coarse"] = torch.cat([rec.r2o[2 * i]["raw"] for i in range(nch)])
+        out["weights_coarse"] = torch.cat([rec.r2o[2 * i]["weights"] for i in range(nch)])
+        out["z_fine"] = torch.cat([rec.r2o[2 * i + 1]["z"] for i in range(nch)])
+        out["raw_fine"] = torch.cat([rec.r2o[2 * i + 1]["raw"] for i in range(nch)])
+        out["weights_fine"] = torch.cat([rec.r2o[2 * i + 1]["weights"] for i in range(nch)])
+        out["z_samples"] = torch.cat([s["samples"] for s in rec.spdf])
+    save(name, out)
+
+
+def g2_small():
+    K16 = np.array([[37.5, 0, 8.0], [0, 37.5, 8.0], [0, 0, 1]])       # 16x16 image, focal 1200/32
+    _render_case("e2e_small.npz", 16, K16, 0.0, 8, 64, 10, 128, chunk=96, netchunk=4096)
+    _render_case("e2e_small_stoch.npz", 16, K16, -60.0, 8, 64, 10, 64, chunk=256, netchunk=100000, perturb=1.0,
+                 noise=0.5, white=True, pytest=True)
+
+
+def g3_true():
+    K8 = np.array([[18.75, 0, 4.0], [0, 18.75, 4.0], [0, 0, 1]])       # 8x8 image = 64 rays
+    _render_case("e2e_true.npz", 8, K8, 60.0, 8, 256, 10, 1024, chunk=64, netchunk=196608, intermediates=True)
+
+
+def g4_grads():
+    """d loss / d{bm, tex, exp, rays_o, rays_d} for loss = mean|rgb - 0.5| + mean(rgb0^2), 64 rays."""
+    r = mk_renderer(4096, 0)
+    coarse, fine = mk_nerf(8, 64, 0, "coarse"), mk_nerf(10, 64, 0, "fine")
+    kw = kwargs_for(r, coarse, fine)
+    bm, tex, exp = [t.clone().requires_grad_(True) for t in synth.codes(0)]
+    K8 = np.array([[18.75, 0, 4.0], [0, 18.75, 4.0], [0, 0, 1]])
+    ro, rd = get_rays(8, 8, K8, pose_spherical(20.0, 0.0, 16.0)[:3, :4])
+    ro = ro.reshape(-1, 3).clone().requires_grad_(True)
+    rd = rd.reshape(-1, 3).clone().requires_grad_(True)
+    rgb, disp, acc, ex = r.render_fitting(8, 8, K8, chunk=64, rays=torch.stack([ro, rd], 0), shapeCodes=bm.expand(64, 50),
+                                          uvCodes=tex, expType=20, expCodes=exp, **kw)
+    loss = (rgb - 0.5).abs().mean() + (ex["rgb0"] ** 2).mean()
+    loss.backward()
+    save("grads_small.npz", dict(bm=bm, tex=tex, exp=exp, rays_o=ro, rays_d=rd, rgb=rgb, rgb0=ex["rgb0"], loss=loss,
+                                 g_bm=bm.grad, g_tex=tex.grad, g_exp=exp.grad, g_rays_o=ro.grad, g_rays_d=rd.grad,
+                                 g_w_rgb=fine.rgb_linear.weight.grad, g_b_alpha=fine.alpha_linear[0].bias.grad,
+                                 g_w_xyz0_c=coarse.xyzEncode.linears1.Linear0.weight.grad,
+                                 g_style_scale_w=r.idSpecificMod.linears_scale.weight.grad))
+
+
+def g5_render_tex():
+    """``render()``: texture encoder on a seeded UV map, then the same path (training-style entry)."""
+    r = mk_renderer(4096, 0, with_tex=True)
+    coarse, fine = mk_nerf(8, 64, 0, "coarse"), mk_nerf(10, 64, 0, "fine")
+    kw = kwargs_for(r, coarse, fine)
+    rng = np.random.default_rng(5)
+    uv = torch.from_numpy(rng.uniform(0, 1, (512, 512, 3)).astype(np.float32))
+    bm = synth.codes(0)[0]
+    K8 = np.array([[18.75, 0, 4.0], [0, 18.75, 4.0], [0, 0, 1]])
+    ro, rd = get_rays(8, 8, K8, pose_spherical(-35.0, 0.0, 16.0)[:3, :4])
+    rays = torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)], 0)
+    with torch.no_grad():
+        rgb, disp, acc, ex = r.render(8, 8, K8, chunk=64, rays=rays, shapeCodes=bm.expand(64, 50), uvMap=uv, expType=7,
+                                      retraw=True, **kw)
+        code = r.decoding_texCodes
+    # the UV map is regenerated from rng seed 5 by the test; store only a checksum of it
+    save("render_tex.npz", dict(uv_sum=uv.double().sum(), bm=bm, rays=rays, tex_code=code, rgb=rgb, disp=disp, acc=acc,
+                                rgb0=ex["rgb0"], z_std=ex["z_std"], raw=ex["raw"], losses=ex["losses"]))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    for w in which:
+        {"g1": g1_kats, "g2": g2_small, "g3": g3_true, "g4": g4_grads, "g5": g5_render_tex}[w]()

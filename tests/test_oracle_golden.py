@@ -1,0 +1,136 @@
+"""Pin oracle/mofa_oracle.py against fixtures produced by the reference itself (CPU only).
+
+The reference has no tests of its own; tests/golden/make_golden.py ran the reference
+in the build container and these tests replay its inputs through the oracle.  Same torch CPU ops in
+the same order => tolerances are at the fp32 rounding floor (mostly bit-exact).
+"""
+import numpy as np
+import torch
+
+from conftest import nan_equal_close
+from mofanerf_amd import synth
+from oracle import mofa_oracle as orc
+
+T = torch.from_numpy
+
+
+def test_embedder(golden):
+    g = golden("kat.npz")
+    x = T(g["embed_x"])
+    assert np.array_equal(orc.positional_encode(x, 10).numpy(), g["embed_L10"])
+    assert np.array_equal(orc.positional_encode(x, 4).numpy(), g["embed_L4"])
+    e = orc.positional_encode(torch.tensor([[0.5, -1.25, 2.0]]), 10)[0]
+    assert abs(float(e.sum()) - 4.0605088) < 1e-5          # SURVEY.md §8c sanity anchor
+
+
+def test_raw2outputs(golden):
+    g = golden("kat.npz")
+    for S in (64, 128):
+        raw, z, d = T(g[f"r2o{S}_raw"]), T(g[f"r2o{S}_z"]), T(g[f"r2o{S}_d"])
+        for wb in (0, 1):
+            out = orc.raw2outputs(raw, z, d, None, bool(wb))
+            for n, v in zip(("rgb", "disp", "acc", "weights", "depth"), out):
+                nan_equal_close(v.numpy(), g[f"r2o{S}_{wb}_{n}"], 0.0)
+        assert np.isnan(g[f"r2o{S}_0_disp"][0])            # the zero-opacity ray
+        np.random.seed(0)
+        noise = T(np.random.rand(*raw.shape[:2]).astype(np.float64) * 0.7).float()
+        out = orc.raw2outputs(raw, z, d, noise, False)
+        for n, v in zip(("rgb", "disp", "acc", "weights", "depth"), out):
+            nan_equal_close(v.numpy(), g[f"r2o{S}_noise_{n}"], 1e-7, 1e-6)
+    np.testing.assert_allclose(g["r2o_anchor_rgb"][0], [0.52549005, 0.45028955, 0.57368523], rtol=1e-6)
+
+
+def test_sample_pdf(golden):
+    g = golden("kat.npz")
+    bins, w = T(g["spdf_bins"]), T(g["spdf_w"])
+    assert np.array_equal(orc.sample_pdf(bins, w, torch.linspace(0, 1, 64)).numpy(), g["spdf_det"])
+    np.random.seed(0)
+    u = torch.Tensor(np.random.rand(bins.shape[0], 64))
+    assert np.array_equal(orc.sample_pdf(bins, w, u).numpy(), g["spdf_rand"])
+    np.testing.assert_allclose(g["spdf_anchor"][0], [8.0, 14.178512, 14.857115, 15.535717, 16.214321, 16.892923,
+                                                     18.714521, 26.0], rtol=1e-6)
+
+
+def test_rays_and_pose(golden):
+    g = golden("kat.npz")
+    K = np.array([[600., 0, 128], [0, 600., 128], [0, 0, 1]])
+    for ang in (-60, 0, 60):
+        c2w = orc.pose_spherical(float(ang), 0.0, 16.0)
+        assert np.array_equal(c2w.numpy(), g[f"rays{ang}_c2w"])
+        ro, rd = orc.get_rays(256, 256, K, c2w[:3, :4])
+        assert np.array_equal(ro[0, 0].numpy(), g[f"rays{ang}_o"])
+        assert np.array_equal(rd[::37, ::41].numpy(), g[f"rays{ang}_d_sub"])
+    assert np.array_equal(orc.pose_spherical(-17.0, 23.0, 16.0).numpy(), g["pose_m17_23_16"])
+
+
+def test_nerf_forward_and_style(golden):
+    g = golden("kat.npz")
+    for D, W in ((8, 64), (10, 64), (8, 96)):
+        st = synth.nerf_state(D, W)
+        n = g[f"nerf{D}x{W}_pts"].shape[0]
+        out = orc.nerf_forward(st, T(g[f"nerf{D}x{W}_pts"]), T(g[f"nerf{D}x{W}_bm"]).expand(n, -1),
+                               T(g[f"nerf{D}x{W}_views"]), T(g[f"nerf{D}x{W}_tex"]).expand(n, -1))
+        nan_equal_close(out.numpy(), g[f"nerf{D}x{W}_out"], 1e-6)
+    s, b = orc.style_module(synth.style_state(0), T(g["style_bm"]))
+    nan_equal_close(s.numpy(), g["style_scale"], 1e-7)
+    nan_equal_close(b.numpy(), g["style_bias"], 1e-7)
+
+
+def _oracle_for(g, with_tex=False):
+    Dc, Wc, Df, Wf = [int(v) for v in g["arch"]] if "arch" in g else (8, 64, 10, 64)
+    seed = int(g["seed"]) if "seed" in g else 0
+    return orc.OracleRenderer(synth.nerf_state(Dc, Wc, seed, "coarse"), synth.nerf_state(Df, Wf, seed, "fine"),
+                              synth.style_state(seed), synth.exp_sigma(seed),
+                              synth.tex_encoder_state(seed) if with_tex else None,
+                              netchunk=int(g["netchunk"]) if "netchunk" in g else 4096)
+
+
+def _check_e2e(g, kw, tol):
+    r = _oracle_for(g)
+    H = int(g["H"])
+    ro, rd = orc.get_rays(H, H, g["K"], T(g["c2w"]))
+    with torch.no_grad():
+        rgb, disp, acc, ex = r.render(ro, rd, int(g["chunk"]), T(g["bm"]), 20, 8.0, 26.0, tex_code=T(g["tex"]),
+                                      exp_codes=T(g["exp"]), N_samples=64, N_importance=64, retraw=True, **kw)
+    errs = {}
+    for n, v in (("rgb", rgb), ("disp", disp), ("acc", acc), ("rgb0", ex["rgb0"]), ("disp0", ex["disp0"]),
+                 ("acc0", ex["acc0"]), ("z_std", ex["z_std"])):
+        errs[n] = nan_equal_close(v.numpy(), g[n], tol, tol)
+    nan_equal_close(ex["raw"].reshape(-1, 128, 4).numpy(), g["raw_fine"], 10 * tol, tol)
+    assert ex["losses"] == 0
+    return errs
+
+
+def test_e2e_small(golden):
+    _check_e2e(golden("e2e_small.npz"), {}, 2e-6)
+
+
+def test_e2e_small_stochastic(golden):
+    g = golden("e2e_small_stoch.npz")
+    R = int(g["H"]) ** 2
+    np.random.seed(0); t_rand = torch.Tensor(np.random.rand(R, 64))
+    np.random.seed(0); u = torch.Tensor(np.random.rand(R, 64))
+    np.random.seed(0); n0 = torch.Tensor(np.random.rand(R, 64) * float(g["noise"]))
+    np.random.seed(0); n1 = torch.Tensor(np.random.rand(R, 128) * float(g["noise"]))
+    _check_e2e(g, dict(perturb=1.0, white_bkgd=True, t_rand=t_rand, u=u, noise0=n0, noise1=n1), 2e-6)
+
+
+def test_e2e_true_size(golden):
+    """64 rays through coarse 256x8 + fine 1024x10 (the shipped sizes), recipe weights."""
+    _check_e2e(golden("e2e_true.npz"), {}, 5e-6)
+
+
+def test_render_with_tex_encoder(golden):
+    g = golden("render_tex.npz")
+    uv = T(np.random.default_rng(5).uniform(0, 1, (512, 512, 3)).astype(np.float32))
+    assert abs(float(uv.double().sum()) - float(g["uv_sum"])) < 1e-6
+    r = _oracle_for(g, with_tex=True)
+    rays = T(g["rays"])
+    with torch.no_grad():
+        code = orc.tex_encoder(r.tex_enc, uv)
+        rgb, disp, acc, ex = r.render(rays[0], rays[1], 64, T(g["bm"]), 7, 8.0, 26.0, uv_map=uv, N_samples=64,
+                                      N_importance=64)
+    nan_equal_close(code.numpy(), g["tex_code"], 1e-6, 1e-5)
+    nan_equal_close(rgb.numpy(), g["rgb"], 2e-6)
+    nan_equal_close(acc.numpy(), g["acc"], 2e-6)
+    nan_equal_close(disp.numpy(), g["disp"], 2e-6, 2e-6)
