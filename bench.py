@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the MoFaNeRF ray-marching hot path on MI355X.
+
+One "step" = one 512x512 novel view (262,144 rays; 64 coarse + 128 fine network samples per ray) through
+the shipped network sizes (coarse 256x8, fine 1024x10; tools/config_parser.py:17-24) with
+chunk = netchunk = 196608 (configs/exp_mofanerf.txt:9-10) — BASELINE.json configs[1].  Weights are the seeded
+synthetic recipe (no checkpoint is downloadable), inputs are resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+N > 1: the frame's rows are split into N contiguous blocks (one process per GPU), each rank runs the whole
+coarse->fine pipeline on its block, and one RCCL all-gather of the [rays/N, 5] tiles reassembles the frame on
+every rank inside the timed region (strong scaling: total work fixed).
+
+Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel (the BN=128 fp32-MFMA layer kernel): algorithmic
+FLOPs of its launches / their summed duration measured with HIP events on the launch stream, against the fp32
+MFMA peak of 157.3 TFLOP/s.  `cpu_baseline` times the CPU oracle on a bounded sample of the same frame (rank 0,
+N = 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from mofanerf_amd import dist as mdist, factory, lib, schema, synth  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+H = W = 512
+ARCH = (8, 256, 10, 1024)
+N_SAMPLES, N_IMPORTANCE = 64, 64
+
+
+def pose_spherical(phi_deg, theta_deg, radius):
+    """Camera-to-world of tools/load_facescape.py:33-38 (host-side, 3 matrix products)."""
+    ph, th = np.deg2rad(phi_deg), np.deg2rad(theta_deg)
+    t = np.eye(4, dtype=np.float32); t[2, 3] = radius
+    rx = np.array([[1, 0, 0, 0], [0, np.cos(th), -np.sin(th), 0], [0, np.sin(th), np.cos(th), 0], [0, 0, 0, 1]], np.float32)
+    ry = np.array([[np.cos(ph), 0, -np.sin(ph), 0], [0, 1, 0, 0], [np.sin(ph), 0, np.cos(ph), 0], [0, 0, 0, 1]], np.float32)
+    return torch.from_numpy(ry @ (rx @ t))
+
+
+def flops_per_ray(folded=True):
+    Dc, Wc, Df, Wf = ARCH
+    return 2 * (N_SAMPLES * schema.mac_per_point(Dc, Wc, folded) +
+                (N_SAMPLES + N_IMPORTANCE) * schema.mac_per_point(Df, Wf, folded))
+
+
+def layer_kernel_flops_per_ray():
+    """Algorithmic FLOPs executed by the dominant kernel (all Linear layers except layer 0 — its own kernel variant —
+    and the two small heads), per ray."""
+    Dc, Wc, Df, Wf = ARCH
+    tot = 0
+    for (D, Wd, S) in ((Dc, Wc, N_SAMPLES), (Df, Wf, N_SAMPLES + N_IMPORTANCE)):
+        mac = schema.mac_per_point(D, Wd, True) - 63 * Wd - Wd - 3 * (Wd // 2)
+        tot += 2 * S * mac
+    return tot
+
+
+def build_product(device, seed=0):
+    Dc, Wc, Df, Wf = ARCH
+    args = factory.default_args(netdepth=Dc, netwidth=Wc, netdepth_fine=Df, netwidth_fine=Wf, no_reload=True,
+                                device=device, basedir="/nonexistent", N_samples=N_SAMPLES, N_importance=N_IMPORTANCE)
+    _, kw, _, _, _, _, render = factory.create_nerf(args)
+    kw["network_fn"].load_state_dict(synth.nerf_state(Dc, Wc, seed, "coarse"))
+    kw["network_fine"].load_state_dict(synth.nerf_state(Df, Wf, seed, "fine"))
+    render.idSpecificMod.load_state_dict(synth.style_state(seed))
+    for dst, src in zip(render.expCodes_Sigma, synth.exp_sigma(seed)):
+        dst.data[:] = src.to(dst.device)
+    kw.update(near=8.0, far=26.0)
+    return render.eval(), kw, args
+
+
+def cpu_baseline(n_rays, seed=0):
+    """Time the CPU oracle (restatement of the reference, proven equal to it by tests/test_oracle_golden.py) on the
+    first `n_rays` rays of the centre rows of the same frame."""
+    from oracle import mofa_oracle as orc
+    Dc, Wc, Df, Wf = ARCH
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    o = orc.OracleRenderer(synth.nerf_state(Dc, Wc, seed, "coarse"), synth.nerf_state(Df, Wf, seed, "fine"),
+                           synth.style_state(seed), synth.exp_sigma(seed), netchunk=196608)
+    bm, tex, exp = synth.codes(seed)
+    ro, rd = orc.get_rays(H, W, synth.intrinsics(H, W), pose_spherical(0.0, 0.0, 16.0)[:3, :4])
+    b = (H // 2) * W
+    ro, rd = ro.reshape(-1, 3)[b:b + n_rays], rd.reshape(-1, 3)[b:b + n_rays]
+    with torch.no_grad():
+        o.render(ro[:16], rd[:16], 16, bm, 20, 8.0, 26.0, tex_code=tex, exp_codes=exp, N_samples=N_SAMPLES,
+                 N_importance=N_IMPORTANCE)                                    # warm the allocator / thread pool
+        t0 = time.perf_counter()
+        o.render(ro, rd, 4096, bm, 20, 8.0, 26.0, tex_code=tex, exp_codes=exp, N_samples=N_SAMPLES,
+                 N_importance=N_IMPORTANCE)
+        dt = time.perf_counter() - t0
+    return {"value": round(n_rays / dt, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_rays} rays (centre rows of the same 512x512 frame), same networks/codes, one pass, "
+                      f"{dt:.1f} s; torch CPU fp32 oracle, no_grad, anomaly detection off"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-rays", type=int, default=768, help="rays in the CPU-baseline sample (0 = skip)")
+    a = ap.parse_args()
+
+    rank, world, local = mdist.init_from_env()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N>1)"
+    assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU fallback for the product path"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    L = lib.load()
+
+    render, kw, args = build_product(dev)
+    bm, tex, exp = (t.to(dev) for t in synth.codes(0))
+    K = synth.intrinsics(H, W)
+    n_total = H * W
+    b, e = mdist.shard_range(n_total, rank, world, align=W)           # whole image rows per rank
+    angles = [0.0, -60.0, 60.0]                                         # run_fit.py's three novel views
+
+    def frame_rays(angle):
+        c2w = pose_spherical(angle, 0.0, 16.0)[:3, :4].contiguous().to(dev)
+        n = e - b
+        o, d, v = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(3))
+        lib.check(L.mofa_get_rays(H, W, float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]), lib.ptr(c2w), b, n,
+                                  lib.ptr(o), lib.ptr(d), lib.ptr(v), lib.stream()), "mofa_get_rays")
+        return torch.stack([o, d], 0)
+
+    rays = {ang: frame_rays(ang) for ang in angles}                     # inputs resident in HBM before timing
+
+    def step(i):
+        r = rays[angles[i % len(angles)]]
+        rgb, disp, acc, _ = render.render_fitting(H, W, K, chunk=args.chunk, rays=r, shapeCodes=bm, uvCodes=tex,
+                                                  expType=20, expCodes=exp, **kw)
+        tile = torch.cat([rgb, disp[:, None], acc[:, None]], -1)        # [rays/N, 5]
+        return mdist.all_gather_tiles(tile, n_total, world, rank, align=W)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    sync()
+    lib.check(L.mofa_prof_begin(), "mofa_prof_begin")
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        frame = step(a.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    ms, launches, pflops = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+    lib.check(L.mofa_prof_end(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(pflops)), "mofa_prof_end")
+    dt = mdist.barrier_max(dt, dev)
+    assert frame.shape == (n_total, 5) and bool(torch.isfinite(frame[:, :3]).all())
+
+    if rank == 0:
+        rays_per_s = n_total * a.steps / dt
+        my_rays = (e - b) * a.steps
+        alg_flops = layer_kernel_flops_per_ray() * my_rays               # algorithmic work of this rank's k_layer launches
+        achieved = alg_flops / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")       # PMC-derived bytes/launch, if a pass was collected
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("bytes_per_launch")
+        out = {
+            "metric": "rendered rays/sec (64c+128f samples) at 512^2 novel-view", "value": round(rays_per_s, 1),
+            "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "512x512 novel view, 64 coarse + 128 fine samples/ray, coarse 256x8 + fine 1024x10, "
+                                   "chunk=netchunk=196608, seeded Xavier weights (BASELINE.json configs[1])",
+                       "rays_per_step": n_total, "parallelism": f"ray-rows x{world} + all-gather",
+                       "gflop_per_ray_folded": round(flops_per_ray(True) / 1e9, 4),
+                       "gflop_per_ray_nominal": round(flops_per_ray(False) / 1e9, 4)},
+            "whole_path_tflops": round(flops_per_ray(True) * rays_per_s / 1e12, 2),
+            "roofline": {"bound": "mfma", "kernel": "mofa::k_layer<128,false,true> (fp32 MFMA Linear+bias+ReLU)",
+                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "launches": int(launches.value),
+                         "avg_launch_ms": round(ms.value / max(1, launches.value), 4),
+                         "algorithmic_gflop_per_launch": round(alg_flops / max(1, launches.value) / 1e9, 3),
+                         "padded_over_algorithmic": round(pflops.value / alg_flops, 4) if alg_flops else None},
+        }
+        if world == 1 and a.cpu_rays > 0:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_rays)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

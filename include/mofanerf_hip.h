@@ -1,0 +1,142 @@
+/*
+ * mofanerf_hip.h — C ABI of libmofanerf_hip.so, the MI355X (gfx950) implementation of MoFaNeRF's
+ * ray-marching hot path.
+ *
+ * The reference (zhuhao-nju/mofanerf) is pure Python/PyTorch with no FFI layer; the drop-in boundary
+ * is the Python class `myRenderer` (models/render_class.py:40).  This header is what that class's
+ * methods bind instead of aten ops.  Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless stated; the caller owns every buffer
+ *     (PyTorch's caching allocator in the shipped host layer); nothing here allocates or frees.
+ *   - `stream` is a hipStream_t passed as void*; no entry point synchronises the host.
+ *   - return 0 on success, MOFA_EINVAL for a bad argument, MOFA_EHIP if a launch failed
+ *     (hipGetLastError text via mofa_last_error()).
+ *   - kernels are stateless and re-entrant per stream.
+ *
+ * Panel layout ("panels").  Activations and the per-point weight blocks are stored K-panel-major so
+ * that one MFMA operand tile is a single contiguous, already bank-swizzled LDS image:
+ *     a matrix [rows, K] (K padded to a multiple of 16) is K/16 panels, each [rows][16] floats;
+ *     element (row, k) lives at
+ *         (k/16)*rows*16 + row*16 + ((((k%16)/4) ^ ((row/4)%4)) * 4) + k%4 .
+ * `rows` is the point count padded to 256 for activations, the feature count padded to 64 for weights.
+ */
+#ifndef MOFANERF_HIP_H
+#define MOFANERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOFA_ABI_VERSION 1
+#define MOFA_OK 0
+#define MOFA_EINVAL (-1)
+#define MOFA_EHIP (-2)
+
+#define MOFA_PE_POINT_FREQS 10 /* multires       (tools/config_parser.py) -> 63 features */
+#define MOFA_PE_VIEW_FREQS 4   /* multires_views                          -> 27 features */
+#define MOFA_CH_EXP 30
+#define MOFA_CH_SHAPE 50
+#define MOFA_CH_TEX 256
+#define MOFA_ROW_TILE 256 /* activation rows are padded to this */
+
+int mofa_abi_version(void);
+const char* mofa_last_error(void);
+
+/* ---- network description -------------------------------------------------------------------
+ * NeRF(D, W, use_viewdirs=True, skips=[4]) of models/model.py:80-137.  `weights`/`biases` are the
+ * 2D+7 Linear layers in state-dict order (mofanerf_amd/schema.py::nerf_layers):
+ *   xyzEncode.linears1.Linear0..3, linear_BiM_xyz.linears1.Linear0..4, .linears2.Linear0..D-6,
+ *   linear_uv_xyzBiM.linears1.Linear0..4, .linears2.Linear0..D-6, linear_view_xyBMuv.0,
+ *   alpha_linear.0, rgb_linear — each weight row-major [out, in] exactly as PyTorch stores it. */
+typedef struct MofaNetShape {
+    int32_t D; /* netdepth  (8 coarse / 10 fine)   */
+    int32_t W; /* netwidth  (256 coarse / 1024 fine) */
+} MofaNetShape;
+
+int mofa_net_num_layers(MofaNetShape s);          /* 2D+7 */
+size_t mofa_net_packed_floats(MofaNetShape s);    /* size of the packed per-point weight blob */
+size_t mofa_net_folded_floats(MofaNetShape s);    /* size of the per-call folded-bias blob    */
+size_t mofa_net_workspace_floats(MofaNetShape s, int64_t n_points, int64_t n_rays);
+
+/* Repack the per-point-varying weight columns of every layer into panels (+ dense head rows).
+ * Replaces nothing in the reference (it multiplies the concatenated inputs, model.py:129-133); the
+ * split is exact algebra — see SURVEY.md §7 "constant folding". */
+int mofa_net_pack(MofaNetShape s, const float* const* weights, float* packed, void* stream);
+
+/* Per-call folded biases: b' = b + W[:, const cols] @ code for the five conditioned layers
+ * (expression 30 -> xyzEncode.L0; shape 50 -> BiM l1.L0 / l2.L0; texture 256 -> uv l1.L0 / l2.L0),
+ * plus plain copies of every other bias.  Replaces the torch.cat of expanded codes in
+ * render_class.py:74-85,104 and model.py:129,132.   exp_code[30] is the ALREADY modulated code
+ * (scale*sigma+bias, render_class.py:81). */
+int mofa_net_fold(MofaNetShape s, const float* const* weights, const float* const* biases,
+                  const float* exp_code, const float* shape_code, const float* tex_code, float* folded,
+                  void* stream);
+
+/* run_network + NeRF.forward for n_rays*S points (render_class.py:69-94, model.py:121-137):
+ * positional encoding of pts = o + d*z (separately rounded mul and add, render_class.py:315),
+ * 2D+5 fused Linear+bias+ReLU layers on MFMA, per-ray view-direction bias, sigma/rgb heads.
+ *   rays_o, rays_d, viewdirs [n_rays,3]; z [n_rays,S] (z_row_stride = S) or one shared row (stride 0)
+ *   pts: optional explicit [n_rays*S,3] points (then rays_o/rays_d/z may be NULL)
+ *   view_w [W/2, 27+W], view_b [W/2]: the ORIGINAL linear_view_xyBMuv.0 tensors (their 27 view
+ *   columns become a per-ray bias, computed here from viewdirs)
+ *   raw_out [n_rays,S,4] = (rgb pre-sigmoid, sigma pre-ReLU)
+ *   workspace: mofa_net_workspace_floats(s, n_rays*S, n_rays) floats. */
+int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, const float* view_w,
+                     const float* view_b, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
+                     const float* pts, const float* viewdirs, int64_t n_rays, int32_t S, float* workspace,
+                     float* raw_out, void* stream);
+
+/* ---- single-layer entry points (unit-testable pieces of mofa_net_forward) -------------------- */
+size_t mofa_panel_floats(int64_t rows, int32_t k); /* rows * roundup(k,16) */
+int mofa_pack_panels(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, float* dst,
+                     int32_t rows_padded, int32_t panel0, int32_t k_padded, void* stream);
+int mofa_to_panels(const float* x, int64_t rows, int32_t k, float* dst, int64_t rows_padded, void* stream);
+int mofa_from_panels(const float* src, int64_t rows_padded, int64_t rows, int32_t k, float* x, void* stream);
+/* y = act(x1|x2 @ Wpacked^T + bias); bias_row_div = 0: bias[Np]; else bias[(m / div), Np] (per ray). */
+int mofa_layer_forward(const float* x1, int32_t k1, const float* x2, int32_t k2, const float* w_packed,
+                       const float* bias, int32_t bias_row_div, int64_t bias_rows, float* y, int64_t m_padded,
+                       int32_t n_padded, int32_t relu, void* stream);
+/* first layer with the positional encoding generated in the prologue (model.py:44-45 + Linear0). */
+int mofa_layer0_forward(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
+                        const float* pts, int64_t n_points, int32_t S, const float* w_packed, const float* bias,
+                        float* y, int64_t m_padded, int32_t n_padded, void* stream);
+int mofa_head_forward(const float* x, int32_t k_padded, int64_t m_padded, const float* w_dense, const float* b,
+                      int32_t n_out, float* raw, int32_t raw_off, int64_t n_points, void* stream);
+int mofa_view_bias(const float* viewdirs, int64_t n_rays, const float* w, int32_t n_out, int32_t ld,
+                   const float* bias, float* out, int32_t n_padded, void* stream);
+int mofa_positional_encode(const float* x, int64_t n, int32_t n_freqs, float* out, void* stream);
+
+/* ---- measurement hook ------------------------------------------------------------------------
+ * Between mofa_prof_begin() and mofa_prof_end() every launch of the dominant kernel (the BN=128 MFMA layer kernel)
+ * is bracketed by hipEventRecord on its own stream.  mofa_prof_end() synchronises those events (host blocks) and
+ * returns the summed kernel time, the launch count and the padded FLOPs they executed.  Used by bench.py only. */
+int mofa_prof_begin(void);
+int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops);
+
+/* ---- ray-side kernels ------------------------------------------------------------------------ */
+/* get_rays (tools/run_nerf_helpers.py:153-168) + viewdir normalisation (render_class.py:399-401) for
+ * pixels [pix0, pix0+n) of an H x W image in row-major order.  c2w: 12 floats [3,4] (device). */
+int mofa_get_rays(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float* c2w, int64_t pix0,
+                  int64_t n, float* rays_o, float* rays_d, float* viewdirs, void* stream);
+
+/* raw2outputs (render_class.py:440-482): one wavefront per ray, exclusive prefix product over the
+ * samples.  noise may be NULL; disp is NaN where acc == 0 exactly like the reference. */
+int mofa_composite_forward(const float* raw, const float* z, int64_t z_row_stride, const float* rays_d,
+                           const float* noise, int64_t n_rays, int32_t S, int32_t white_bkgd, float* rgb,
+                           float* disp, float* acc, float* depth, float* weights, void* stream);
+
+/* sample_pdf on (z_mid, weights[1:-1]) + sort(cat(z, z_samples)) + std(z_samples)
+ * (render_class.py:324-328,345; tools/run_nerf_helpers.py:203-247).  u: [n_rays,Ni] (stride Ni) or a
+ * shared row (stride 0) — linspace(0,1,Ni) for det. */
+int mofa_sample_pdf_merge(const float* z, int64_t z_row_stride, const float* weights, const float* u,
+                          int64_t u_row_stride, int64_t n_rays, int32_t S, int32_t Ni, float* z_samples,
+                          float* z_fine, float* z_std, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOFANERF_HIP_H */

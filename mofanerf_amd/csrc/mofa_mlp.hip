@@ -1,0 +1,563 @@
+// Fused positional-encode -> conditioned-MLP kernels for gfx950 (MI355X).
+//
+// Replaces run_network/batchify/NeRF.forward of the reference (models/render_class.py:69-109,
+// models/model.py:121-137, :202-230): every Linear+bias+ReLU is one launch of k_layer, an
+// LDS-tiled fp32 MFMA (v_mfma_f32_32x32x2_f32 — exact fp32, bitwise an fmaf chain) GEMM whose
+// operands arrive as ready-made, bank-swizzled LDS images ("panels") by direct global->LDS DMA.
+//
+// Formulation.  For a tile of 256 points (rows m) and BN output features (rows n):
+//     D[n][m] = sum_k Wp[n][k] * X[m][k]          (weights are the MFMA "A" operand, points "B")
+// so each lane ends up with 4 CONSECUTIVE features of ONE point per accumulator quad — one 16-byte
+// store per quad straight into the next layer's panel layout (bias + ReLU fused).
+//
+// Work decomposition: workgroup = 4 waves (256 threads), tile 256 (m) x BN (n); BN = 128 -> waves
+// 2(n) x 2(m), wave tile 64 x 128 (8 accumulators of 32x32 = 128 AGPRs); BN = 64 -> waves 1 x 4,
+// wave tile 64 x 64.  K is walked in 16-wide panels, double-buffered in LDS (24 KiB / stage at
+// BN=128 => 48 KiB / workgroup, 2 workgroups per CU so one's epilogue hides under the other's MFMAs).
+// blockIdx -> tile is XCD-aware: block b runs on XCD b%8, and each XCD walks a contiguous range of
+// point tiles across all feature tiles, so an X tile is fetched into ONE L2 and the (<= 8 MiB) weight
+// slab stays resident in the 256 MiB Infinity Cache.
+#include <stdlib.h>
+
+#include <utility>
+#include <vector>
+
+#include "mofa_common.h"
+
+namespace mofa {
+namespace {
+
+struct LayerArgs {
+    const float* x1;      // panels [k1p][m_padded][16]
+    const float* x2;      // optional second source (skip concat [x | h]), panels [k2p][m_padded][16]
+    const float* w;       // packed weights, panels [(k1p+k2p)][n_padded][16]
+    const float* bias;    // [bias_rows][n_padded]
+    float* y;             // panels [n_padded/16][m_padded][16]
+    // layer-0 (positional encoding prologue) inputs
+    const float* rays_o;
+    const float* rays_d;
+    const float* z;
+    const float* pts;
+    long long z_row_stride;
+    long long n_points;
+    long long m_padded;
+    long long bias_rows;
+    int k1p, k2p;         // number of 16-wide K panels per source
+    int n_padded;
+    int bias_row_div;     // 0: one bias row; else bias row = m / bias_row_div (per-ray bias)
+    int relu;
+    int S;
+    int n_tiles;          // n_padded / BN
+    int total_tiles;
+};
+
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+    // 16 B per lane, LDS destination = wave-uniform base + lane*16 (LDS-DMA, no VGPR round trip)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// positional-encoding feature k of a 3-vector: [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...]
+// (models/model.py:24-45; frequency-major blocks of 3).  k is wave-uniform => no divergence.
+__device__ __forceinline__ float pe_feature(int k, float x0, float x1, float x2, int nfeat) {
+    if (k >= nfeat) return 0.0f;
+    if (k < 3) return k == 0 ? x0 : (k == 1 ? x1 : x2);
+    const int j = k - 3;
+    const int f = j / 6;
+    const int r = j - 6 * f;
+    const int d = r >= 3 ? r - 3 : r;
+    const float x = d == 0 ? x0 : (d == 1 ? x1 : x2);
+    const float arg = x * (float)(1 << f);  // exact (power of two), like x * freq in the reference
+    return r < 3 ? sinf(arg) : cosf(arg);
+}
+
+template <int NI, int NJ>
+__device__ __forceinline__ void mma_panel(const float* __restrict__ Xt, const float* __restrict__ Wt, int xrow0,
+                                          int wrow0, int lane, f32x16 (&acc)[NI][NJ]) {
+    const int lr = lane & 31, g = lane >> 5, sw = (lane >> 2) & 3;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int p = ((2 * h + g) ^ sw) << 2;  // swizzled 16-B chunk holding k = 8h + 4g .. +3
+        f32x4 a[NI], b[NJ];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) a[i] = *(const f32x4*)(Wt + (wrow0 + 32 * i + lr) * 16 + p);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j] = *(const f32x4*)(Xt + (xrow0 + 32 * j + lr) * 16 + p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    }
+}
+
+// BN: feature-tile height; L0: X tile is generated (positional encoding) instead of loaded;
+// GLDS: stage operands with LDS-DMA (true) or through registers (false; kept as the A/B arm).
+template <int BN, bool L0, bool GLDS>
+__global__ __launch_bounds__(256, 2) void k_layer(const LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BM = kRowTile;
+    constexpr int WAVES_N = BN / 64;
+    constexpr int WAVES_M = 4 / WAVES_N;
+    constexpr int NI = 2;
+    constexpr int NJ = (BM / WAVES_M) / 32;
+    constexpr int STAGE = (BM + BN) * 16;  // floats per pipeline stage
+    constexpr int XR = BM / 64;            // 4 KiB rounds per X stage
+    constexpr int WR = BN / 64;
+
+    // XCD-aware tile order (block b -> XCD b % 8; grid is padded to a multiple of 8)
+    const int per_xcd = gridDim.x >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= a.total_tiles) return;
+    const int mt = logical / a.n_tiles, nt = logical - mt * a.n_tiles;
+    const long long m0 = (long long)mt * BM;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WAVES_N, wm = wave / WAVES_N;
+    const int KT = a.k1p + a.k2p;
+
+    // layer 0: this thread owns point row m0+tid
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if constexpr (L0) {
+        long long m = m0 + tid;
+        if (m >= a.n_points) m = a.n_points - 1;
+        if (a.pts) {
+            px = a.pts[m * 3 + 0], py = a.pts[m * 3 + 1], pz = a.pts[m * 3 + 2];
+        } else {
+            const long long r = m / a.S;
+            const int s = (int)(m - r * a.S);
+            const float zz = a.z[r * a.z_row_stride + s];
+            // pts = o + d * z with a separately rounded multiply and add (render_class.py:315)
+            px = __fadd_rn(a.rays_o[r * 3 + 0], __fmul_rn(a.rays_d[r * 3 + 0], zz));
+            py = __fadd_rn(a.rays_o[r * 3 + 1], __fmul_rn(a.rays_d[r * 3 + 1], zz));
+            pz = __fadd_rn(a.rays_o[r * 3 + 2], __fmul_rn(a.rays_d[r * 3 + 2], zz));
+        }
+    }
+
+    auto x_src = [&](int kt) -> const float* {
+        const float* base = kt < a.k1p ? a.x1 : a.x2;
+        const int kk = kt < a.k1p ? kt : kt - a.k1p;
+        return base + ((long long)kk * a.m_padded + m0) * 16;
+    };
+    auto w_src = [&](int kt) -> const float* { return a.w + ((long long)kt * a.n_padded + n0) * 16; };
+
+    f32x4 sx[GLDS ? 1 : XR], sw_[GLDS ? 1 : WR];  // register staging (GLDS == false only)
+
+    auto stage_issue = [&](int buf, int kt) {
+        float* xs = smem + buf * STAGE;
+        float* ws = xs + BM * 16;
+        if constexpr (L0) {
+            const int swz = (tid >> 2) & 3;
+#pragma unroll 1
+            for (int kk = 0; kk < 16; ++kk) {
+                const float v = pe_feature(kt * 16 + kk, px, py, pz, 3 + 6 * MOFA_PE_POINT_FREQS);
+                xs[tid * 16 + ((((kk >> 2) & 3) ^ swz) << 2) + (kk & 3)] = v;
+            }
+        } else if constexpr (GLDS) {
+            const float* src = x_src(kt);
+#pragma unroll
+            for (int r = 0; r < XR; ++r) glds16(src + (r * 256 + tid) * 4, xs + (r * 256 + wave * 64) * 4);
+        } else {
+            const float* src = x_src(kt);
+#pragma unroll
+            for (int r = 0; r < XR; ++r) sx[r] = *(const f32x4*)(src + (r * 256 + tid) * 4);
+        }
+        const float* wsrc = w_src(kt);
+        if constexpr (GLDS) {
+#pragma unroll
+            for (int r = 0; r < WR; ++r) glds16(wsrc + (r * 256 + tid) * 4, ws + (r * 256 + wave * 64) * 4);
+        } else {
+#pragma unroll
+            for (int r = 0; r < WR; ++r) sw_[r] = *(const f32x4*)(wsrc + (r * 256 + tid) * 4);
+        }
+    };
+    auto stage_commit = [&](int buf) {  // register-staged arm: write the tile once the MFMAs are issued
+        if constexpr (!GLDS) {
+            float* xs = smem + buf * STAGE;
+            float* ws = xs + BM * 16;
+            if constexpr (!L0) {
+#pragma unroll
+                for (int r = 0; r < XR; ++r) *(f32x4*)(xs + (r * 256 + tid) * 4) = sx[r];
+            }
+#pragma unroll
+            for (int r = 0; r < WR; ++r) *(f32x4*)(ws + (r * 256 + tid) * 4) = sw_[r];
+        }
+    };
+
+    f32x16 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    stage_issue(0, 0);
+    stage_commit(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) stage_issue(cur ^ 1, kt + 1);
+        const float* xs = smem + cur * STAGE;
+        mma_panel<NI, NJ>(xs, xs + BM * 16, wm * (32 * NJ), wn * 64, lane, acc);
+        if (kt + 1 < KT) stage_commit(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: bias + ReLU, one 16-B store per accumulator quad into the next layer's panels
+    const int lr = lane & 31, g = lane >> 5;
+    f32x4 bv[NI][4];
+    if (!a.bias_row_div) {  // one bias row for every point: fetch it once
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(a.bias + n0 + wn * 64 + 32 * i + 8 * q + 4 * g);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const long long m = m0 + wm * (32 * NJ) + 32 * j + lr;
+        if (a.bias_row_div) {  // per-ray bias (view layer): row = ray of this point
+            long long brow = m / a.bias_row_div;
+            if (brow >= a.bias_rows) brow = a.bias_rows - 1;
+            const float* bias = a.bias + brow * a.n_padded + n0 + wn * 64 + 4 * g;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(bias + 32 * i + 8 * q);
+        }
+        const int msw = (int)(m >> 2) & 3;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + 32 * i + 8 * q + 4 * g;
+                f32x4 v;
+                v.x = acc[i][j][4 * q + 0] + bv[i][q].x;
+                v.y = acc[i][j][4 * q + 1] + bv[i][q].y;
+                v.z = acc[i][j][4 * q + 2] + bv[i][q].z;
+                v.w = acc[i][j][4 * q + 3] + bv[i][q].w;
+                if (a.relu) {
+                    v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                }
+                *(f32x4*)(a.y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
+            }
+        }
+    }
+}
+
+// ---- heads: sigma = sigmaCodes . w + b (model.py:130), rgb = v . W3 + b3 (model.py:134) ---------
+__global__ __launch_bounds__(256) void k_head(const float* __restrict__ x, int kp, long long m_padded,
+                                              const float* __restrict__ w, const float* __restrict__ b, int n_out,
+                                              float* __restrict__ raw, int raw_off, long long n_points) {
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= n_points) return;
+    const int sw = (int)(m >> 2) & 3;
+    const int K = kp * 16;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < kp; ++kt) {
+        const f32x4* row = (const f32x4*)(x + ((long long)kt * m_padded + m) * 16);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 v = row[c ^ sw];
+            const int k = kt * 16 + 4 * c;
+            for (int o = 0; o < n_out; ++o) {
+                const float* wo = w + (long long)o * K + k;
+                acc[o] = fmaf(v.x, wo[0], acc[o]);
+                acc[o] = fmaf(v.y, wo[1], acc[o]);
+                acc[o] = fmaf(v.z, wo[2], acc[o]);
+                acc[o] = fmaf(v.w, wo[3], acc[o]);
+            }
+        }
+    }
+    for (int o = 0; o < n_out; ++o) raw[m * 4 + raw_off + o] = acc[o] + b[o];
+}
+
+// ---- per-ray bias of the view layer: b + W[:, :27] @ PE(viewdir)  (model.py:133, render_class.py:88-90)
+__global__ __launch_bounds__(256) void k_view_bias(const float* __restrict__ viewdirs, long long n_rays,
+                                                   const float* __restrict__ w, int n_out, int ld,
+                                                   const float* __restrict__ bias, float* __restrict__ out,
+                                                   int n_padded) {
+    constexpr int RPB = 8, NF = 3 + 6 * MOFA_PE_VIEW_FREQS;
+    __shared__ float pe[RPB][NF + 1];
+    const long long r0 = (long long)blockIdx.x * RPB;
+    for (int t = threadIdx.x; t < RPB * NF; t += 256) {
+        const int rr = t / NF, k = t - rr * NF;
+        long long r = r0 + rr;
+        if (r >= n_rays) r = n_rays - 1;
+        pe[rr][k] = pe_feature(k, viewdirs[r * 3], viewdirs[r * 3 + 1], viewdirs[r * 3 + 2], NF);
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < n_padded; n += 256) {
+        float acc[RPB];
+        const float b = n < n_out ? bias[n] : 0.f;
+#pragma unroll
+        for (int rr = 0; rr < RPB; ++rr) acc[rr] = 0.f;
+        if (n < n_out) {
+            for (int k = 0; k < NF; ++k) {
+                const float wk = w[(long long)n * ld + k];
+#pragma unroll
+                for (int rr = 0; rr < RPB; ++rr) acc[rr] = fmaf(wk, pe[rr][k], acc[rr]);
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RPB; ++rr)
+            if (r0 + rr < n_rays) out[(r0 + rr) * n_padded + n] = acc[rr] + b;
+    }
+}
+
+// ---- folded per-call bias: out[n] = bias[n] + sum_c W[n, col0 + c] * code[c] -----------------------
+__global__ __launch_bounds__(256) void k_fold_bias(const float* __restrict__ w, int n_out, int ld, int col0,
+                                                   int ncols, const float* __restrict__ code,
+                                                   const float* __restrict__ bias, float* __restrict__ out,
+                                                   int n_padded) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_padded) return;
+    float acc = 0.f;
+    if (n < n_out) {
+        for (int c = 0; c < ncols; ++c) acc = fmaf(w[(long long)n * ld + col0 + c], code[c], acc);
+        acc += bias[n];
+    }
+    out[n] = acc;
+}
+
+// ---- weight / activation repacking -------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_panels(const float* __restrict__ w, int n_out, int ld, int col0,
+                                                     int ncols, float* __restrict__ dst, int rows_padded,
+                                                     int panel0, int k_padded) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)rows_padded * k_padded;
+    if (idx >= total) return;
+    const int e = idx & 3, p = (idx >> 2) & 3;
+    const long long rowpanel = idx >> 4;
+    const int row = (int)(rowpanel % rows_padded), panel = (int)(rowpanel / rows_padded);
+    const int k = panel * 16 + ((p ^ ((row >> 2) & 3)) << 2) + e;
+    const float v = (row < n_out && k < ncols) ? w[(long long)row * ld + col0 + k] : 0.f;
+    dst[(long long)panel0 * rows_padded * 16 + idx] = v;
+}
+
+__global__ __launch_bounds__(256) void k_to_panels(const float* __restrict__ x, long long rows, int k_in,
+                                                   float* __restrict__ dst, long long rows_padded, int k_padded) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows_padded * k_padded) return;
+    const int e = idx & 3, p = (idx >> 2) & 3;
+    const long long rowpanel = idx >> 4;
+    const long long row = rowpanel % rows_padded;
+    const int panel = (int)(rowpanel / rows_padded);
+    const int k = panel * 16 + ((p ^ ((int)(row >> 2) & 3)) << 2) + e;
+    dst[idx] = (row < rows && k < k_in) ? x[row * k_in + k] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_from_panels(const float* __restrict__ src, long long rows_padded,
+                                                     long long rows, int k_out, float* __restrict__ x) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * k_out) return;
+    const long long row = idx / k_out;
+    const int k = (int)(idx - row * k_out);
+    x[idx] = src[panel_index(rows_padded, row, k)];
+}
+
+__global__ __launch_bounds__(256) void k_dense_rows(const float* __restrict__ w, int n_out, int ld, int col0,
+                                                    int ncols, float* __restrict__ dst, int k_padded) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_out * k_padded) return;
+    const int o = idx / k_padded, k = idx - o * k_padded;
+    dst[idx] = k < ncols ? w[(long long)o * ld + col0 + k] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_positional_encode(const float* __restrict__ x, long long n, int n_freqs,
+                                                           float* __restrict__ out) {
+    const int nf = 3 + 6 * n_freqs;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * nf) return;
+    const long long r = idx / nf;
+    const int k = (int)(idx - r * nf);
+    out[idx] = pe_feature(k, x[r * 3], x[r * 3 + 1], x[r * 3 + 2], nf);
+}
+
+inline int stage_mode() {  // MOFA_STAGE=reg selects the register-staged A/B arm; default is LDS-DMA
+    const char* e = getenv("MOFA_STAGE");
+    return (e && e[0] == 'r') ? 0 : 1;
+}
+
+// Optional per-launch timing of the dominant kernel (k_layer<128, false, *>) with HIP events recorded on the launch
+// stream; used by bench.py for the live roofline figure.  Off by default (no events, no overhead).
+struct ProfState {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+    double flops = 0.0;
+};
+ProfState g_prof;
+
+template <int BN, bool L0>
+int launch_layer(LayerArgs a, hipStream_t st) {
+    a.n_tiles = a.n_padded / BN;
+    const long long mt = a.m_padded / kRowTile;
+    const long long total = mt * a.n_tiles;
+    MOFA_REQUIRE(total > 0 && total < (1ll << 30), "layer: tile count %lld out of range", total);
+    a.total_tiles = (int)total;
+    const unsigned grid = (unsigned)round_up(total, 8);
+    const size_t lds = 2 * (size_t)(kRowTile + BN) * 16 * sizeof(float);
+    const bool prof = g_prof.on && BN == 128 && !L0;
+    if (prof) {
+        if (g_prof.used == g_prof.ev.size()) {
+            hipEvent_t e0, e1;
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return check_launch("hipEventCreate");
+            g_prof.ev.emplace_back(e0, e1);
+        }
+        (void)hipEventRecord(g_prof.ev[g_prof.used].first, st);
+    }
+    if (stage_mode())
+        hipLaunchKernelGGL((k_layer<BN, L0, true>), dim3(grid), dim3(256), lds, st, a);
+    else
+        hipLaunchKernelGGL((k_layer<BN, L0, false>), dim3(grid), dim3(256), lds, st, a);
+    if (prof) {
+        (void)hipEventRecord(g_prof.ev[g_prof.used].second, st);
+        g_prof.used++;
+        g_prof.flops += 2.0 * (double)a.m_padded * (double)a.n_padded * 16.0 * (double)(a.k1p + a.k2p);
+    }
+    return check_launch(L0 ? "k_layer<L0>" : "k_layer");
+}
+
+int dispatch_layer(LayerArgs a, bool l0, hipStream_t st) {
+    MOFA_REQUIRE(a.m_padded > 0 && a.m_padded % kRowTile == 0, "m_padded=%lld must be a positive multiple of %d",
+                 a.m_padded, kRowTile);
+    MOFA_REQUIRE(a.n_padded > 0 && a.n_padded % 64 == 0, "n_padded=%d must be a positive multiple of 64", a.n_padded);
+    if (a.n_padded % 128 == 0) return l0 ? launch_layer<128, true>(a, st) : launch_layer<128, false>(a, st);
+    return l0 ? launch_layer<64, true>(a, st) : launch_layer<64, false>(a, st);
+}
+
+inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+}  // namespace mofa
+
+using namespace mofa;
+
+extern "C" {
+
+size_t mofa_panel_floats(int64_t rows, int32_t k) { return (size_t)rows * (size_t)round_up(k, 16); }
+
+int mofa_pack_panels(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, float* dst,
+                     int32_t rows_padded, int32_t panel0, int32_t k_padded, void* stream) {
+    MOFA_REQUIRE(w && dst, "pack_panels: null pointer");
+    MOFA_REQUIRE(rows_padded >= n_out && k_padded % 16 == 0 && k_padded >= ncols && col0 >= 0 && col0 + ncols <= ld,
+                 "pack_panels: bad shape n_out=%d ld=%d col0=%d ncols=%d rows_padded=%d k_padded=%d", n_out, ld, col0,
+                 ncols, rows_padded, k_padded);
+    const long long total = (long long)rows_padded * k_padded;
+    hipLaunchKernelGGL(k_pack_panels, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, w, n_out, ld, col0,
+                       ncols, dst, rows_padded, panel0, k_padded);
+    return check_launch("k_pack_panels");
+}
+
+int mofa_to_panels(const float* x, int64_t rows, int32_t k, float* dst, int64_t rows_padded, void* stream) {
+    MOFA_REQUIRE(x && dst && rows > 0 && rows_padded >= rows && k > 0, "to_panels: bad arguments");
+    const int kp = (int)round_up(k, 16);
+    hipLaunchKernelGGL(k_to_panels, dim3(blocks_for(rows_padded * kp)), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)rows, k, dst, (long long)rows_padded, kp);
+    return check_launch("k_to_panels");
+}
+
+int mofa_from_panels(const float* src, int64_t rows_padded, int64_t rows, int32_t k, float* x, void* stream) {
+    MOFA_REQUIRE(x && src && rows > 0 && rows_padded >= rows && k > 0, "from_panels: bad arguments");
+    hipLaunchKernelGGL(k_from_panels, dim3(blocks_for(rows * k)), dim3(256), 0, (hipStream_t)stream, src,
+                       (long long)rows_padded, (long long)rows, k, x);
+    return check_launch("k_from_panels");
+}
+
+int mofa_layer_forward(const float* x1, int32_t k1, const float* x2, int32_t k2, const float* w_packed,
+                       const float* bias, int32_t bias_row_div, int64_t bias_rows, float* y, int64_t m_padded,
+                       int32_t n_padded, int32_t relu, void* stream) {
+    MOFA_REQUIRE(x1 && w_packed && bias && y, "layer_forward: null pointer");
+    MOFA_REQUIRE(k1 > 0 && k1 % 16 == 0 && k2 >= 0 && k2 % 16 == 0 && (k2 == 0 || x2),
+                 "layer_forward: k1=%d k2=%d must be multiples of 16 (x2 required when k2>0)", k1, k2);
+    MOFA_REQUIRE(bias_row_div >= 0 && (bias_row_div == 0 || bias_rows > 0), "layer_forward: bad bias rows");
+    LayerArgs a{};
+    a.x1 = x1, a.x2 = x2, a.w = w_packed, a.bias = bias, a.y = y;
+    a.k1p = k1 / 16, a.k2p = k2 / 16, a.n_padded = n_padded, a.m_padded = m_padded;
+    a.bias_row_div = bias_row_div, a.bias_rows = bias_rows, a.relu = relu;
+    return dispatch_layer(a, false, (hipStream_t)stream);
+}
+
+int mofa_layer0_forward(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
+                        const float* pts, int64_t n_points, int32_t S, const float* w_packed, const float* bias,
+                        float* y, int64_t m_padded, int32_t n_padded, void* stream) {
+    MOFA_REQUIRE(w_packed && bias && y, "layer0_forward: null pointer");
+    MOFA_REQUIRE(pts || (rays_o && rays_d && z && S > 0), "layer0_forward: need pts or (rays_o, rays_d, z, S)");
+    MOFA_REQUIRE(n_points > 0 && n_points <= m_padded, "layer0_forward: n_points=%lld m_padded=%lld",
+                 (long long)n_points, (long long)m_padded);
+    LayerArgs a{};
+    a.w = w_packed, a.bias = bias, a.y = y, a.rays_o = rays_o, a.rays_d = rays_d, a.z = z, a.pts = pts;
+    a.z_row_stride = z_row_stride, a.n_points = n_points, a.S = S > 0 ? S : 1;
+    a.k1p = 4, a.k2p = 0, a.n_padded = n_padded, a.m_padded = m_padded, a.relu = 1;
+    return dispatch_layer(a, true, (hipStream_t)stream);
+}
+
+int mofa_head_forward(const float* x, int32_t k_padded, int64_t m_padded, const float* w_dense, const float* b,
+                      int32_t n_out, float* raw, int32_t raw_off, int64_t n_points, void* stream) {
+    MOFA_REQUIRE(x && w_dense && b && raw, "head_forward: null pointer");
+    MOFA_REQUIRE(k_padded % 16 == 0 && n_out >= 1 && n_out <= 4 && raw_off >= 0 && raw_off + n_out <= 4 &&
+                     n_points <= m_padded,
+                 "head_forward: bad shape");
+    hipLaunchKernelGGL(k_head, dim3(blocks_for(n_points)), dim3(256), 0, (hipStream_t)stream, x, k_padded / 16,
+                       (long long)m_padded, w_dense, b, n_out, raw, raw_off, (long long)n_points);
+    return check_launch("k_head");
+}
+
+int mofa_view_bias(const float* viewdirs, int64_t n_rays, const float* w, int32_t n_out, int32_t ld,
+                   const float* bias, float* out, int32_t n_padded, void* stream) {
+    MOFA_REQUIRE(viewdirs && w && bias && out && n_rays > 0 && n_padded >= n_out, "view_bias: bad arguments");
+    hipLaunchKernelGGL(k_view_bias, dim3((unsigned)((n_rays + 7) / 8)), dim3(256), 0, (hipStream_t)stream, viewdirs,
+                       (long long)n_rays, w, n_out, ld, bias, out, n_padded);
+    return check_launch("k_view_bias");
+}
+
+int mofa_positional_encode(const float* x, int64_t n, int32_t n_freqs, float* out, void* stream) {
+    MOFA_REQUIRE(x && out && n > 0 && n_freqs >= 0 && n_freqs <= 16, "positional_encode: bad arguments");
+    hipLaunchKernelGGL(k_positional_encode, dim3(blocks_for(n * (3 + 6 * n_freqs))), dim3(256), 0,
+                       (hipStream_t)stream, x, (long long)n, n_freqs, out);
+    return check_launch("k_positional_encode");
+}
+
+int mofa_prof_begin(void) {
+    g_prof.on = true, g_prof.used = 0, g_prof.flops = 0.0;
+    return MOFA_OK;
+}
+
+int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops) {
+    MOFA_REQUIRE(total_ms && launches && padded_flops, "prof_end: null pointer");
+    g_prof.on = false;
+    double ms = 0.0;
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        if (hipEventSynchronize(g_prof.ev[i].second) != hipSuccess) return check_launch("hipEventSynchronize");
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof.ev[i].first, g_prof.ev[i].second) != hipSuccess)
+            return check_launch("hipEventElapsedTime");
+        ms += (double)t;
+    }
+    *total_ms = ms, *launches = (int64_t)g_prof.used, *padded_flops = g_prof.flops;
+    g_prof.used = 0;
+    return MOFA_OK;
+}
+
+// internal (used by mofa_net.hip)
+int mofa_internal_fold_bias(const float* w, int n_out, int ld, int col0, int ncols, const float* code,
+                            const float* bias, float* out, int n_padded, void* stream) {
+    hipLaunchKernelGGL(k_fold_bias, dim3(blocks_for(n_padded)), dim3(256), 0, (hipStream_t)stream, w, n_out, ld, col0,
+                       ncols, code, bias, out, n_padded);
+    return check_launch("k_fold_bias");
+}
+
+int mofa_internal_dense_rows(const float* w, int n_out, int ld, int col0, int ncols, float* dst, int k_padded,
+                             void* stream) {
+    hipLaunchKernelGGL(k_dense_rows, dim3(blocks_for((long long)n_out * k_padded)), dim3(256), 0, (hipStream_t)stream,
+                       w, n_out, ld, col0, ncols, dst, k_padded);
+    return check_launch("k_dense_rows");
+}
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+// Ray-side kernels of the MoFaNeRF hot path for gfx950: ray generation, per-ray alpha compositing
+// (wavefront prefix product) and importance resampling + merge.  All HBM-bound; one 64-lane wavefront
+// owns one ray so the sample buffer is read with fully coalesced 16-byte loads.
+// Built with -ffp-contract=off: the reference evaluates these formulas as separate aten ops, so no
+// multiply-add may be fused here (SURVEY.md §7 hard part 2).
+#include "mofa_common.h"
+
+namespace mofa {
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- get_rays (tools/run_nerf_helpers.py:153-168) + viewdirs (render_class.py:399-401) -------------
+__global__ __launch_bounds__(256) void k_get_rays(int H, int W, float fx, float fy, float cx, float cy,
+                                                  const float* __restrict__ c2w, long long pix0, long long n,
+                                                  float* __restrict__ rays_o, float* __restrict__ rays_d,
+                                                  float* __restrict__ viewdirs) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const long long pix = pix0 + t;
+    const int j = (int)(pix / W), i = (int)(pix - (long long)j * W);
+    const float d0 = __fdiv_rn((float)i - cx, fx);
+    const float d1 = -__fdiv_rn((float)j - cy, fy);
+    const float d2 = -1.0f;
+    float rd[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)  // sum(dirs[..., None, :] * c2w[:3, :3], -1): ((d0*c0 + d1*c1) + d2*c2)
+        rd[a] = __fadd_rn(__fadd_rn(__fmul_rn(d0, c2w[a * 4 + 0]), __fmul_rn(d1, c2w[a * 4 + 1])),
+                          __fmul_rn(d2, c2w[a * 4 + 2]));
+    const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(rd[0], rd[0]), __fmul_rn(rd[1], rd[1])),
+                                           __fmul_rn(rd[2], rd[2])));
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        rays_o[t * 3 + a] = c2w[a * 4 + 3];
+        rays_d[t * 3 + a] = rd[a];
+        if (viewdirs) viewdirs[t * 3 + a] = __fdiv_rn(rd[a], nrm);
+    }
+}
+
+// ---- raw2outputs (models/render_class.py:440-482) --------------------------------------------------
+// One wavefront per ray; lane l owns samples [l*SPL, l*SPL+SPL).  T_i = prod_{j<i} (1 - alpha_j + 1e-10)
+// is an in-lane running product combined with a 6-step wavefront exclusive prefix product.
+template <int SPL>
+__global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw, const float* __restrict__ z,
+                                                   long long z_row_stride, const float* __restrict__ rays_d,
+                                                   const float* __restrict__ noise, long long n_rays, int S,
+                                                   int white_bkgd, float* __restrict__ rgb_out,
+                                                   float* __restrict__ disp_out, float* __restrict__ acc_out,
+                                                   float* __restrict__ depth_out, float* __restrict__ weights_out) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+    const float dnorm = __fsqrt_rn(dx * dx + dy * dy + dz * dz);
+    const float* zr = z + ray * z_row_stride;
+    const f32x4* rr = (const f32x4*)(raw + ray * (long long)S * 4);
+
+    float zv[SPL + 1], alpha[SPL], cr[SPL], cg[SPL], cb[SPL];
+    const int s0 = lane * SPL;
+#pragma unroll
+    for (int t = 0; t <= SPL; ++t) zv[t] = (s0 + t < S) ? zr[s0 + t] : 0.f;
+    float run = 1.0f;  // product of this lane's (1 - alpha + 1e-10)
+#pragma unroll
+    for (int t = 0; t < SPL; ++t) {
+        const int s = s0 + t;
+        if (s < S) {
+            const f32x4 v = rr[s];
+            float dist = (s + 1 < S) ? (zv[t + 1] - zv[t]) : 1e10f;
+            dist = dist * dnorm;
+            float sig = v.w;
+            if (noise) sig = sig + noise[ray * (long long)S + s];
+            sig = fmaxf(sig, 0.f);
+            alpha[t] = 1.0f - expf(-sig * dist);
+            cr[t] = 1.0f / (1.0f + expf(-v.x));
+            cg[t] = 1.0f / (1.0f + expf(-v.y));
+            cb[t] = 1.0f / (1.0f + expf(-v.z));
+            run = run * ((1.0f - alpha[t]) + 1e-10f);
+        } else {
+            alpha[t] = 0.f, cr[t] = cg[t] = cb[t] = 0.f;
+        }
+    }
+    // exclusive prefix product across lanes
+    float incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl = incl * up;
+    }
+    float T = __shfl_up(incl, 1, 64);
+    if (lane == 0) T = 1.0f;
+
+    float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+#pragma unroll
+    for (int t = 0; t < SPL; ++t) {
+        const int s = s0 + t;
+        if (s < S) {
+            const float w = alpha[t] * T;
+            weights_out[ray * (long long)S + s] = w;
+            sr += w * cr[t], sg += w * cg[t], sb += w * cb[t];
+            sd += w * zv[t];
+            sa += w;
+            T = T * ((1.0f - alpha[t]) + 1e-10f);
+        }
+    }
+    sr = wave_sum(sr), sg = wave_sum(sg), sb = wave_sum(sb), sd = wave_sum(sd), sa = wave_sum(sa);
+    if (lane == 0) {
+        if (white_bkgd) {
+            const float bg = 1.0f - sa;
+            sr += bg, sg += bg, sb += bg;
+        }
+        rgb_out[ray * 3] = sr, rgb_out[ray * 3 + 1] = sg, rgb_out[ray * 3 + 2] = sb;
+        const float q = __fdiv_rn(sd, sa);  // 0/0 -> NaN, and torch.max propagates it (render_class.py:476)
+        disp_out[ray] = (q != q) ? q : __fdiv_rn(1.0f, fmaxf(1e-10f, q));
+        acc_out[ray] = sa;
+        depth_out[ray] = sd;
+    }
+}
+
+// ---- sample_pdf + sort(cat) + std (tools/run_nerf_helpers.py:203-247; render_class.py:324-328,345) ----
+// One wavefront per ray.  B = S-1 bin edges z_mid, B-1 = S-2 interior weights.
+// cdf follows the CPU reference: cumsum accumulates in double and rounds every prefix to float.
+constexpr int kMaxS = 256, kMaxNi = 256;
+
+__global__ __launch_bounds__(256) void k_sample_pdf_merge(const float* __restrict__ z, long long z_row_stride,
+                                                          const float* __restrict__ weights,
+                                                          const float* __restrict__ u, long long u_row_stride,
+                                                          long long n_rays, int S, int Ni,
+                                                          float* __restrict__ z_samples, float* __restrict__ z_fine,
+                                                          float* __restrict__ z_std) {
+    __shared__ float s_all[kWavesPerBlock][kMaxS + kMaxNi];  // [0,S): coarse z, [S,S+Ni): new samples
+    __shared__ float s_bins[kWavesPerBlock][kMaxS];
+    __shared__ float s_cdf[kWavesPerBlock][kMaxS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long ray = (long long)blockIdx.x * kWavesPerBlock + wv;
+    if (ray >= n_rays) return;  // wave-uniform; no block-level barrier is used below
+    float* all = s_all[wv];
+    float* bins = s_bins[wv];
+    float* cdf = s_cdf[wv];
+    const float* zr = z + ray * z_row_stride;
+    const float* wr = weights + ray * (long long)S;
+    const int B = S - 1;   // len(bins) == len(cdf)
+    const int NW = S - 2;  // interior weights
+
+    for (int s = lane; s < S; s += 64) all[s] = zr[s];
+    __builtin_amdgcn_wave_barrier();
+    for (int b = lane; b < B; b += 64) bins[b] = 0.5f * (all[b + 1] + all[b]);
+
+    // pdf = (w + 1e-5) / sum(w + 1e-5); cdf = [0, cumsum(pdf)]
+    double part = 0.0;
+    for (int i = lane; i < NW; i += 64) part += (double)(wr[i + 1] + 1e-5f);
+    const float wsum = (float)wave_sum_d(part);
+    double carry = 0.0;
+    if (lane == 0) cdf[0] = 0.f;
+    for (int base = 0; base < NW; base += 64) {
+        const int i = base + lane;
+        double v = (i < NW) ? (double)__fdiv_rn(wr[i + 1] + 1e-5f, wsum) : 0.0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double up = __shfl_up(v, o, 64);
+            if (lane >= o) v += up;
+        }
+        v += carry;
+        if (i < NW) cdf[i + 1] = (float)v;
+        carry = __shfl(v, 63, 64);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // invert the cdf at each u
+    double m1 = 0.0;
+    for (int j = lane; j < Ni; j += 64) {
+        const float uu = u[ray * u_row_stride + j];
+        int lo = 0, hi = B;  // first index with cdf[idx] > uu  (searchsorted right=True)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] > uu) hi = mid; else lo = mid + 1;
+        }
+        const int below = max(lo - 1, 0), above = min(lo, B - 1);
+        const float c0 = cdf[below], c1 = cdf[above], b0 = bins[below], b1 = bins[above];
+        float denom = c1 - c0;
+        if (denom < 1e-5f) denom = 1.0f;
+        const float t = __fdiv_rn(uu - c0, denom);
+        const float smp = b0 + t * (b1 - b0);
+        all[S + j] = smp;
+        z_samples[ray * (long long)Ni + j] = smp;
+        m1 += (double)smp;
+    }
+    // population std of the new samples (torch.std(unbiased=False))
+    const double mean = wave_sum_d(m1) / (double)Ni;
+    __builtin_amdgcn_wave_barrier();
+    double m2 = 0.0;
+    for (int j = lane; j < Ni; j += 64) {
+        const double dlt = (double)all[S + j] - mean;
+        m2 += dlt * dlt;
+    }
+    m2 = wave_sum_d(m2);
+    if (lane == 0) z_std[ray] = (float)sqrt(m2 / (double)Ni);
+
+    // merge by rank: position = #(smaller) + #(equal with a lower index)
+    const int N = S + Ni;
+    for (int e = lane; e < N; e += 64) {
+        const float v = all[e];
+        int rank = 0;
+        for (int k = 0; k < N; ++k) {
+            const float o = all[k];
+            rank += (o < v || (o == v && k < e)) ? 1 : 0;
+        }
+        z_fine[ray * (long long)N + rank] = v;
+    }
+}
+
+inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+}  // namespace mofa
+
+using namespace mofa;
+
+extern "C" {
+
+int mofa_get_rays(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float* c2w, int64_t pix0,
+                  int64_t n, float* rays_o, float* rays_d, float* viewdirs, void* stream) {
+    MOFA_REQUIRE(c2w && rays_o && rays_d, "get_rays: null pointer");
+    MOFA_REQUIRE(H > 0 && W > 0 && n > 0 && pix0 >= 0 && pix0 + n <= (int64_t)H * W, "get_rays: pixel range");
+    hipLaunchKernelGGL(k_get_rays, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, H, W, fx, fy, cx, cy,
+                       c2w, (long long)pix0, (long long)n, rays_o, rays_d, viewdirs);
+    return check_launch("k_get_rays");
+}
+
+int mofa_composite_forward(const float* raw, const float* z, int64_t z_row_stride, const float* rays_d,
+                           const float* noise, int64_t n_rays, int32_t S, int32_t white_bkgd, float* rgb,
+                           float* disp, float* acc, float* depth, float* weights, void* stream) {
+    MOFA_REQUIRE(raw && z && rays_d && rgb && disp && acc && depth && weights, "composite_forward: null pointer");
+    MOFA_REQUIRE(n_rays > 0 && S >= 2 && S <= 256, "composite_forward: need 2 <= S <= 256 (got %d)", S);
+    const dim3 grid(blocks_for(n_rays, kWavesPerBlock)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define MOFA_COMPOSITE(SPL)                                                                                     \
+    hipLaunchKernelGGL((k_composite<SPL>), grid, block, 0, st, raw, z, (long long)z_row_stride, rays_d, noise, \
+                       (long long)n_rays, S, white_bkgd, rgb, disp, acc, depth, weights)
+    if (S <= 64) MOFA_COMPOSITE(1);
+    else if (S <= 128) MOFA_COMPOSITE(2);
+    else MOFA_COMPOSITE(4);
+#undef MOFA_COMPOSITE
+    return check_launch("k_composite");
+}
+
+int mofa_sample_pdf_merge(const float* z, int64_t z_row_stride, const float* weights, const float* u,
+                          int64_t u_row_stride, int64_t n_rays, int32_t S, int32_t Ni, float* z_samples,
+                          float* z_fine, float* z_std, void* stream) {
+    MOFA_REQUIRE(z && weights && u && z_samples && z_fine && z_std, "sample_pdf_merge: null pointer");
+    MOFA_REQUIRE(n_rays > 0 && S >= 4 && S <= kMaxS && Ni >= 1 && Ni <= kMaxNi,
+                 "sample_pdf_merge: need 4 <= S <= %d, 1 <= Ni <= %d", kMaxS, kMaxNi);
+    hipLaunchKernelGGL(k_sample_pdf_merge, dim3(blocks_for(n_rays, kWavesPerBlock)), dim3(256), 0,
+                       (hipStream_t)stream, z, (long long)z_row_stride, weights, u, (long long)u_row_stride,
+                       (long long)n_rays, S, Ni, z_samples, z_fine, z_std);
+    return check_launch("k_sample_pdf_merge");
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+"""Device-side state of one ``NeRF`` for the HIP path: packed weights, folded biases, workspace.
+
+``HipNet`` never computes anything itself — it owns the buffers the C ABI needs (allocated through
+PyTorch's caching allocator on the current HIP device) and issues the ``mofa_net_*`` calls on the
+current stream.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import lib
+from .model import NeRF
+
+
+def unwrap(net):
+    """Callers may hand the nets wrapped in ``nn.DataParallel`` (run_fit.py:166-167)."""
+    return net.module if isinstance(net, torch.nn.DataParallel) else net
+
+
+class HipNet:
+    def __init__(self, net: NeRF):
+        if not isinstance(net, NeRF):
+            raise lib.MofaError(f"expected mofanerf_amd.model.NeRF, got {type(net).__name__}")
+        self.net = net
+        self.shape = lib.NetShape(net.D, net.W)
+        self._L = lib.load()
+        self._linears = net.ordered_linears()
+        if self._L.mofa_net_num_layers(self.shape) != len(self._linears):
+            raise lib.MofaError("layer count mismatch between the module and the C ABI plan")
+        self._packed: Optional[torch.Tensor] = None
+        self._packed_key = None
+        self._folded: Optional[torch.Tensor] = None
+        self._ws: Optional[torch.Tensor] = None
+
+    # -- weights -----------------------------------------------------------------------------------
+    def _weights(self):
+        ws = [l.weight.detach() for l in self._linears]
+        bs = [l.bias.detach() for l in self._linears]
+        for t in ws + bs:
+            if not t.is_cuda:
+                raise lib.MofaError("network parameters must live on the GPU (net.cuda()); there is no CPU path")
+        return [w.contiguous() for w in ws], [b.contiguous() for b in bs]
+
+    def _key(self):
+        return tuple((l.weight.data_ptr(), l.weight._version) for l in self._linears)
+
+    def packed(self) -> torch.Tensor:
+        """Panel-packed weights; re-packed only when a parameter changed (optimizer step / load_state_dict)."""
+        key = self._key()
+        if self._packed is None or key != self._packed_key:
+            ws, _ = self._weights()
+            n = self._L.mofa_net_packed_floats(self.shape)
+            if self._packed is None or self._packed.numel() != n or self._packed.device != ws[0].device:
+                self._packed = torch.empty(n, dtype=torch.float32, device=ws[0].device)
+            lib.check(self._L.mofa_net_pack(self.shape, lib.ptr_array(ws), lib.ptr(self._packed), lib.stream()),
+                      "mofa_net_pack")
+            self._packed_key = key
+        return self._packed
+
+    def fold(self, exp_code: torch.Tensor, shape_code: torch.Tensor, tex_code: torch.Tensor) -> torch.Tensor:
+        """Per-call folded biases from the (already modulated) expression code [30], shape code [50] and
+        texture code [256]."""
+        ws, bs = self._weights()
+        n = self._L.mofa_net_folded_floats(self.shape)
+        if self._folded is None or self._folded.device != ws[0].device:
+            self._folded = torch.empty(n, dtype=torch.float32, device=ws[0].device)
+        e = exp_code.detach().reshape(-1).float().contiguous()
+        s = shape_code.detach().reshape(-1).float().contiguous()
+        t = tex_code.detach().reshape(-1).float().contiguous()
+        if e.numel() != 30 or s.numel() != 50 or t.numel() != 256:
+            raise lib.MofaError(f"code sizes must be 30/50/256, got {e.numel()}/{s.numel()}/{t.numel()}")
+        lib.check(self._L.mofa_net_fold(self.shape, lib.ptr_array(ws), lib.ptr_array(bs), lib.ptr(e), lib.ptr(s),
+                                        lib.ptr(t), lib.ptr(self._folded), lib.stream()), "mofa_net_fold")
+        return self._folded
+
+    def workspace(self, n_points: int, n_rays: int, device) -> torch.Tensor:
+        n = self._L.mofa_net_workspace_floats(self.shape, n_points, n_rays)
+        if self._ws is None or self._ws.numel() < n or self._ws.device != device:
+            self._ws = torch.empty(n, dtype=torch.float32, device=device)
+        return self._ws
+
+    # -- forward -----------------------------------------------------------------------------------
+    def forward_rays(self, rays_o, rays_d, z, z_row_stride: int, viewdirs, S: int, raw_out: torch.Tensor,
+                     folded: Optional[torch.Tensor] = None):
+        """raw_out[R,S,4] = NeRF(PE(o + d z), codes, PE(viewdirs)) for R rays x S samples."""
+        R = viewdirs.shape[0]
+        view = self._linears[-3]
+        ws = self.workspace(R * S, R, viewdirs.device)
+        lib.check(self._L.mofa_net_forward(self.shape, lib.ptr(self.packed()),
+                                           lib.ptr(folded if folded is not None else self._folded),
+                                           lib.ptr(view.weight.detach().contiguous()),
+                                           lib.ptr(view.bias.detach().contiguous()), lib.ptr(rays_o), lib.ptr(rays_d),
+                                           lib.ptr(z), z_row_stride, None, lib.ptr(viewdirs), R, S, lib.ptr(ws),
+                                           lib.ptr(raw_out), lib.stream()), "mofa_net_forward")
+        return raw_out
+
+    def forward_points(self, pts, viewdirs, S: int, raw_out: torch.Tensor, folded: Optional[torch.Tensor] = None):
+        """Same with explicit points [R*S,3] (``run_network(inputs, viewdirs, fn)`` entry)."""
+        R = viewdirs.shape[0]
+        view = self._linears[-3]
+        ws = self.workspace(R * S, R, viewdirs.device)
+        lib.check(self._L.mofa_net_forward(self.shape, lib.ptr(self.packed()),
+                                           lib.ptr(folded if folded is not None else self._folded),
+                                           lib.ptr(view.weight.detach().contiguous()),
+                                           lib.ptr(view.bias.detach().contiguous()), None, None, None, 0, lib.ptr(pts),
+                                           lib.ptr(viewdirs), R, S, lib.ptr(ws), lib.ptr(raw_out), lib.stream()),
+                  "mofa_net_forward")
+        return raw_out

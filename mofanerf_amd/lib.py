@@ -1,0 +1,103 @@
+"""ctypes binding of ``libmofanerf_hip.so`` (the C ABI in ``include/mofanerf_hip.h``).
+
+The library is built in-tree by ``mofanerf_amd/build.py`` (``__graft_entry__.build()``).  There is no
+fallback of any kind: if the shared object is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmofanerf_hip.so")
+
+_f = C.POINTER(C.c_float)
+_fp = C.c_void_p      # device pointers travel as integers
+_i32, _i64, _sz = C.c_int32, C.c_int64, C.c_size_t
+
+
+class NetShape(C.Structure):
+    _fields_ = [("D", C.c_int32), ("W", C.c_int32)]
+
+
+# name -> (restype, argtypes); mirrors include/mofanerf_hip.h one to one
+SIGNATURES = {
+    "mofa_abi_version": (C.c_int, []),
+    "mofa_last_error": (C.c_char_p, []),
+    "mofa_net_num_layers": (C.c_int, [NetShape]),
+    "mofa_net_packed_floats": (_sz, [NetShape]),
+    "mofa_net_folded_floats": (_sz, [NetShape]),
+    "mofa_net_workspace_floats": (_sz, [NetShape, _i64, _i64]),
+    "mofa_net_pack": (C.c_int, [NetShape, C.POINTER(_fp), _fp, _fp]),
+    "mofa_net_fold": (C.c_int, [NetShape, C.POINTER(_fp), C.POINTER(_fp), _fp, _fp, _fp, _fp, _fp]),
+    "mofa_net_forward": (C.c_int, [NetShape, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _fp, _fp, _i64, _i32, _fp, _fp,
+                                   _fp]),
+    "mofa_panel_floats": (_sz, [_i64, _i32]),
+    "mofa_pack_panels": (C.c_int, [_fp, _i32, _i32, _i32, _i32, _fp, _i32, _i32, _i32, _fp]),
+    "mofa_to_panels": (C.c_int, [_fp, _i64, _i32, _fp, _i64, _fp]),
+    "mofa_from_panels": (C.c_int, [_fp, _i64, _i64, _i32, _fp, _fp]),
+    "mofa_layer_forward": (C.c_int, [_fp, _i32, _fp, _i32, _fp, _fp, _i32, _i64, _fp, _i64, _i32, _i32, _fp]),
+    "mofa_layer0_forward": (C.c_int, [_fp, _fp, _fp, _i64, _fp, _i64, _i32, _fp, _fp, _fp, _i64, _i32, _fp]),
+    "mofa_head_forward": (C.c_int, [_fp, _i32, _i64, _fp, _fp, _i32, _fp, _i32, _i64, _fp]),
+    "mofa_view_bias": (C.c_int, [_fp, _i64, _fp, _i32, _i32, _fp, _fp, _i32, _fp]),
+    "mofa_positional_encode": (C.c_int, [_fp, _i64, _i32, _fp, _fp]),
+    "mofa_prof_begin": (C.c_int, []),
+    "mofa_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "mofa_get_rays": (C.c_int, [_i32, _i32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _i64, _i64, _fp, _fp, _fp,
+                                _fp]),
+    "mofa_composite_forward": (C.c_int, [_fp, _fp, _i64, _fp, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "mofa_sample_pdf_merge": (C.c_int, [_fp, _i64, _fp, _fp, _i64, _i64, _i32, _i32, _fp, _fp, _fp, _fp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class MofaError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Raises if it has not been built — never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MofaError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950).  There is no CPU or eager fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if lib.mofa_abi_version() != 1:
+            raise MofaError(f"ABI version mismatch: library {lib.mofa_abi_version()} != binding 1")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise MofaError(f"{what} failed (rc={rc}): {load().mofa_last_error().decode()}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a contiguous fp32 CUDA(HIP) tensor; ``None`` passes NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MofaError("the HIP path needs tensors on the GPU (got a CPU tensor); there is no CPU fallback")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise MofaError(f"expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def ptr_array(ts: Sequence[torch.Tensor]):
+    arr = (_fp * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = ptr(t)
+    return arr
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream

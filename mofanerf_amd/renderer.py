@@ -1,0 +1,367 @@
+"""``myRenderer``-compatible volumetric renderer whose hot path runs on hand-written HIP kernels.
+
+Drop-in for ``models/render_class.py:40-437`` of zhuhao-nju/mofanerf: same constructor, same
+``render`` / ``render_fitting`` / ``render_path`` / ``run_network`` / ``batchify_rays`` /
+``grad_parameter`` surface, same kwargs dict (``create_nerf``'s ``render_kwargs_*``), same return
+convention ``[rgb, disp, acc, extras]`` and the same per-call state stored on ``self``.
+
+What runs where
+  * HIP (``libmofanerf_hip.so``): ray generation, positional encoding, all 2D+7 layers of both
+    networks, sigma/rgb heads, alpha compositing, importance resampling + merge, z_std.
+  * PyTorch-ROCm (once per call): ``StyleModule`` on one 50-d row and the texture
+    encoder CNN on one 512² map; the handful of elementwise ops that build stochastic sample positions.
+There is no eager/CPU fallback: CPU tensors or a missing library raise ``MofaError``.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import lib
+from .hipnet import HipNet, unwrap
+from .model import EnDeUVmap, StyleModule
+
+_OUT_KEYS = ("rgb_map", "disp_map", "acc_map")
+
+
+class lossesLog:
+    """Accumulator for the texture encoder's auxiliary losses (models/render_class.py:13-37).  The shipped
+    encoder returns ``{}``, so :meth:`out` is the int ``0`` — callers add it to the loss (run_train.py:346)."""
+
+    def __init__(self, lossesList, Weight):
+        self.lossesNameList = list(lossesList)
+        self.lossesWeight = dict(zip(lossesList, Weight))
+        self.lossesDict = {n: 0 for n in lossesList}
+        self.chunkDict = {n: 0 for n in lossesList}
+
+    def update(self, lossesList, chunk):
+        for name, value in lossesList.items():
+            self.lossesDict[name] = self.lossesDict[name] + torch.sum(value)
+            self.chunkDict[name] += chunk
+
+    def out(self):
+        loss = 0
+        for name in self.lossesNameList:
+            if not (isinstance(self.lossesDict[name], int) and self.lossesDict[name] == 0):
+                loss = loss + self.lossesDict[name] / self.chunkDict[name] * self.lossesWeight[name]
+            self.lossesDict[name], self.chunkDict[name] = 0, 0
+        return loss
+
+
+def _scalar(v) -> float:
+    return float(v.item() if torch.is_tensor(v) else v)
+
+
+class Renderer(torch.nn.Module):
+    def __init__(self, embed_fn=None, embeddirs_fn=None, netchunk=1024 * 64, uvCodesLen=256, expCodesLen=4,
+                 input_ch=3, shapeCodes=50):
+        super().__init__()
+        # embed_fn / embeddirs_fn are accepted for signature compatibility; the encoding is fused into the
+        # first-layer kernel (L=10 for points, L=4 for view directions: tools/config_parser.py defaults).
+        self.embed_fn, self.embeddirs_fn = embed_fn, embeddirs_fn
+        self.netchunk = netchunk
+        self.texEncoder = EnDeUVmap(uvCodesLen)
+        self.lossList = ["loss_deformReg", "loss_kldiv", "loss_offsets"]
+        self.lossWeight = [0.05, 1, 0.01]
+        self.lossLog = lossesLog(self.lossList, self.lossWeight)
+        self.idSpecificMod = StyleModule()
+        self.is_run_fineNet = True
+        self.expCodes_Sigma = [torch.rand([1, expCodesLen]) for _ in range(20)]   # 20 kinds of expression
+        for latent in self.expCodes_Sigma:
+            latent.requires_grad = True
+        self._hipnets: Dict[int, HipNet] = {}
+        self._L = None
+        self._cache: Dict[tuple, torch.Tensor] = {}
+
+    # expCodes_Sigma is a plain list (not registered parameters, render_class.py:53-58): move it with the module
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        moved = []
+        for t in self.expCodes_Sigma:
+            with torch.no_grad():
+                n = fn(t.detach())
+            n.requires_grad_(t.requires_grad)
+            moved.append(n)
+        self.expCodes_Sigma = moved
+        self._cache.clear()
+        return self
+
+    def grad_parameter(self):
+        grad_vars = list(self.expCodes_Sigma)
+        if self.texEncoder is not None:
+            grad_vars += list(self.texEncoder.parameters())
+        if self.idSpecificMod is not None:
+            grad_vars += list(self.idSpecificMod.parameters())
+        return grad_vars
+
+    # ------------------------------------------------------------------------------------------------
+    def _lib(self):
+        if self._L is None:
+            self._L = lib.load()
+        return self._L
+
+    def _hip(self, net) -> HipNet:
+        net = unwrap(net)
+        h = self._hipnets.get(id(net))
+        if h is None or h.net is not net:
+            h = self._hipnets[id(net)] = HipNet(net)
+        return h
+
+    def _device(self):
+        return next(self.idSpecificMod.parameters()).device
+
+    def _const_row(self, key, builder, device):
+        """Small per-call constant rows (sample positions, u) are built once on the host with the same torch CPU
+        ops as the reference and cached on the device."""
+        k = (key, str(device))
+        if k not in self._cache:
+            self._cache[k] = builder().float().contiguous().to(device)
+        return self._cache[k]
+
+    def _fold_codes(self, net, tex_code):
+        """Per-call conditioning: e = scale*sigma[expType] + bias (render_class.py:75-82) and the folded biases."""
+        style = unwrap(self.idSpecificMod)
+        with torch.no_grad():
+            row = self.shapeCodes[0, :].reshape(1, -1).float().to(self._device())
+            scale, bias = style(row)
+            e = scale * self.expCodes_Sigma[self.expType].to(row.device) + bias
+        return self._hip(net).fold(e, row, tex_code.to(row.device))
+
+    # ------------------------------------------------------------------------------------------------
+    def run_network(self, inputs, viewdirs, fn=None):
+        """``inputs [R,S,3]`` points, ``viewdirs [R,3]`` -> raw ``[R,S,4]`` (render_class.py:69-94)."""
+        if viewdirs is None:
+            raise NotImplementedError("use_viewdirs=False is not part of the shipped configuration")
+        R, S = int(inputs.shape[0]), int(inputs.shape[1])
+        h = self._hip(fn)
+        folded = self._fold_codes(fn, self.decoding_texCodes)
+        raw = torch.empty(R, S, 4, dtype=torch.float32, device=inputs.device)
+        rays_per = max(1, int(self.netchunk) // S)
+        pts = inputs.detach().reshape(-1, 3).float().contiguous()
+        vd = viewdirs.detach().float().contiguous()
+        for i in range(0, R, rays_per):
+            j = min(R, i + rays_per)
+            h.forward_points(pts[i * S:j * S], vd[i:j], S, raw[i:j], folded)
+        return raw
+
+    def batchify(self, fn, chunk):
+        raise RuntimeError("batchify(fn, netchunk) is internal to the reference's eager path; the HIP path "
+                           "sub-batches points inside run_network / render_rays")
+
+    def batchify_rays(self, chunk=1024 * 32, **kwargs):
+        """Render ``self.rays`` in chunks of ``chunk`` rays (render_class.py:111-123)."""
+        all_ret: Dict[str, list] = {}
+        for i in range(0, self.rays.shape[0], chunk):
+            ret = self.render_rays([i, i + chunk], **kwargs)
+            for k, v in ret.items():
+                all_ret.setdefault(k, []).append(v)
+        return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in all_ret.items()}
+
+    # ------------------------------------------------------------------------------------------------
+    def render_rays(self, ray_batch, network_fn, N_samples, retraw=False, lindisp=False, perturb=0., N_importance=0,
+                    network_fine=None, white_bkgd=False, raw_noise_std=0., network_query_fn=None, verbose=False,
+                    pytest=False):
+        """Coarse + fine volumetric rendering of rays ``self.rays[b0:b1]`` (render_class.py:239-352)."""
+        L = self._lib()
+        rays = self.rays[ray_batch[0]:ray_batch[1]]
+        R, dev = int(rays.shape[0]), rays.device
+        if rays.shape[-1] <= 8:
+            raise NotImplementedError("use_viewdirs=False is not part of the shipped configuration")
+        rays_o, rays_d, vd = (rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous(), rays[:, 8:11].contiguous())
+        near, far = self._near, self._far
+        S = int(N_samples)
+        st = lib.stream()
+
+        def z_row():
+            t = torch.linspace(0., 1., steps=S)
+            n, f = torch.tensor([[near]]), torch.tensor([[far]])
+            z = n * (1. - t) + f * t if not lindisp else 1. / (1. / n * (1. - t) + 1. / f * t)
+            return z.reshape(-1)
+
+        z = self._const_row(("z", near, far, S, bool(lindisp)), z_row, dev)
+        z_stride = 0
+        if perturb > 0.:
+            zz = z[None, :].expand(R, S)
+            mids = .5 * (zz[..., 1:] + zz[..., :-1])
+            upper, lower = torch.cat([mids, zz[..., -1:]], -1), torch.cat([zz[..., :1], mids], -1)
+            if pytest:
+                np.random.seed(0)
+                t_rand = torch.Tensor(np.random.rand(R, S)).to(dev)
+            else:
+                t_rand = torch.rand(R, S, device=dev)
+            z = (lower + (upper - lower) * t_rand).contiguous()
+            z_stride = S
+
+        def noise_for(n_s):
+            if not raw_noise_std > 0.:
+                return None
+            if pytest:
+                np.random.seed(0)
+                return torch.Tensor(np.random.rand(R, n_s) * raw_noise_std).to(dev).contiguous()
+            return (torch.randn(R, n_s, device=dev) * raw_noise_std).contiguous()
+
+        def composite(raw, zv, zs, n_s, noise):
+            o = {k: torch.empty(R, *sh, dtype=torch.float32, device=dev)
+                 for k, sh in (("rgb", (3,)), ("disp", ()), ("acc", ()), ("depth", ()), ("weights", (n_s,)))}
+            lib.check(L.mofa_composite_forward(lib.ptr(raw), lib.ptr(zv), zs, lib.ptr(rays_d), lib.ptr(noise), R, n_s,
+                                               int(bool(white_bkgd)), lib.ptr(o["rgb"]), lib.ptr(o["disp"]),
+                                               lib.ptr(o["acc"]), lib.ptr(o["depth"]), lib.ptr(o["weights"]), st),
+                      "mofa_composite_forward")
+            return o
+
+        def network(net, folded, zv, zs, n_s):
+            h = self._hip(net)
+            raw = torch.empty(R, n_s, 4, dtype=torch.float32, device=dev)
+            rays_per = max(1, int(self.netchunk) // n_s)
+            for i in range(0, R, rays_per):
+                j = min(R, i + rays_per)
+                h.forward_rays(rays_o[i:j], rays_d[i:j], zv[i:j] if zs else zv, zs, vd[i:j], n_s, raw[i:j], folded)
+            return raw
+
+        raw = network(network_fn, self._folded_coarse, z, z_stride, S)
+        c = composite(raw, z, z_stride, S, noise_for(S))
+        ret = {"rgb_map": c["rgb"], "disp_map": c["disp"], "acc_map": c["acc"]}
+
+        if N_importance > 0 and self.is_run_fineNet:
+            Ni = int(N_importance)
+            if perturb == 0.:            # det=(perturb == 0.), render_class.py:325
+                u, u_stride = self._const_row(("u", Ni), lambda: torch.linspace(0., 1., steps=Ni), dev), 0
+            elif pytest:
+                np.random.seed(0)
+                u, u_stride = torch.Tensor(np.random.rand(R, Ni)).to(dev).contiguous(), Ni
+            else:
+                u, u_stride = torch.rand(R, Ni, device=dev), Ni
+            z_samples = torch.empty(R, Ni, dtype=torch.float32, device=dev)
+            z_fine = torch.empty(R, S + Ni, dtype=torch.float32, device=dev)
+            z_std = torch.empty(R, dtype=torch.float32, device=dev)
+            lib.check(L.mofa_sample_pdf_merge(lib.ptr(z), z_stride, lib.ptr(c["weights"]), lib.ptr(u), u_stride, R, S,
+                                              Ni, lib.ptr(z_samples), lib.ptr(z_fine), lib.ptr(z_std), st),
+                      "mofa_sample_pdf_merge")
+            fine = network_fn if network_fine is None else network_fine
+            folded = self._folded_coarse if network_fine is None else self._folded_fine
+            raw = network(fine, folded, z_fine, S + Ni, S + Ni)
+            f = composite(raw, z_fine, S + Ni, S + Ni, noise_for(S + Ni))
+            ret = {"rgb_map": f["rgb"], "disp_map": f["disp"], "acc_map": f["acc"], "rgb0": c["rgb"],
+                   "disp0": c["disp"], "acc0": c["acc"], "z_std": z_std}
+            if verbose:
+                ret["_z_samples"], ret["_z_fine"], ret["_weights0"] = z_samples, z_fine, c["weights"]
+        if retraw:
+            ret["raw"] = raw
+        return ret
+
+    # ------------------------------------------------------------------------------------------------
+    def _make_rays(self, H, W, K, c2w, rays, use_viewdirs, c2w_staticcam, ndc):
+        if ndc:
+            raise NotImplementedError("ndc=True (LLFF forward-facing scenes) is never used by MoFaNeRF: "
+                                      "create_nerf sets ndc=False for dataset_type=blender "
+                                      "(tools/create_model_condition.py:108-111)")
+        if not use_viewdirs:
+            raise NotImplementedError("use_viewdirs=False is not part of the shipped configuration")
+        L, dev = self._lib(), self._device()
+        if dev.type != "cuda":
+            raise lib.MofaError("the renderer must be on the GPU (render.cuda()); there is no CPU path")
+
+        def gen(pose):
+            n = int(H) * int(W)
+            o, d, v = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(3))
+            pose_t = torch.as_tensor(np.asarray(pose.detach().cpu() if torch.is_tensor(pose) else pose),
+                                     dtype=torch.float32)[:3, :4].contiguous().to(dev)
+            lib.check(L.mofa_get_rays(int(H), int(W), _scalar(K[0][0]), _scalar(K[1][1]), _scalar(K[0][2]),
+                                      _scalar(K[1][2]), lib.ptr(pose_t), 0, n, lib.ptr(o), lib.ptr(d), lib.ptr(v),
+                                      lib.stream()), "mofa_get_rays")
+            return o, d, v
+
+        if c2w is not None:
+            rays_o, rays_d, viewdirs = gen(c2w)
+            sh = (int(H), int(W), 3)
+        else:
+            rays_o, rays_d = rays[0], rays[1]
+            sh = tuple(rays_d.shape)
+            rays_o = rays_o.detach().reshape(-1, 3).float().to(dev)
+            rays_d = rays_d.detach().reshape(-1, 3).float().to(dev)
+            viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+        if c2w_staticcam is not None:      # visualise the effect of viewdirs only (render_class.py:161-163)
+            rays_o, rays_d, _ = gen(c2w_staticcam)
+        return rays_o, rays_d, viewdirs, sh
+
+    def _render_common(self, H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, tex_code, kwargs):
+        kwargs = dict(kwargs)
+        kwargs.pop("network_query_fn", None)
+        rays_o, rays_d, viewdirs, sh = self._make_rays(H, W, K, c2w, rays, use_viewdirs, c2w_staticcam, ndc)
+        near, far = _scalar(near), _scalar(far)
+        self._near, self._far = near, far
+        ones = torch.ones_like(rays_d[..., :1])
+        self.rays = torch.cat([rays_o, rays_d, near * ones, far * ones, viewdirs], -1)
+        self.decoding_texCodes = tex_code
+        with torch.no_grad():
+            self._folded_coarse = self._fold_codes(kwargs["network_fn"], tex_code).clone()
+            fine = kwargs.get("network_fine")
+            self._folded_fine = self._fold_codes(fine, tex_code).clone() if fine is not None else None
+            all_ret = self.batchify_rays(chunk, **kwargs)
+        for k in all_ret:
+            all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
+        ret_list = [all_ret[k] for k in _OUT_KEYS]
+        ret_dict = {k: all_ret[k] for k in all_ret if k not in _OUT_KEYS}
+        if self.lossList is not None:
+            ret_dict["losses"] = self.lossLog.out()
+        return ret_list + [ret_dict]
+
+    def render(self, H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, shapeCodes=None, uvMap=None,
+               expType=None, near=0., far=1., use_viewdirs=False, c2w_staticcam=None, **kwargs):
+        """Training / bulk-render entry: the texture code comes from the encoder CNN on ``uvMap [512,512,3]``
+        (render_class.py:125-197)."""
+        self.shapeCodes, self.uvMap = shapeCodes, uvMap
+        self.expType = int(expType)
+        code, enlosses = unwrap(self.texEncoder)(uvMap.permute([2, 0, 1]).unsqueeze(0), self.lossList)
+        self.lossLog.update(enlosses, 1)
+        return self._render_common(H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, code, kwargs)
+
+    def render_fitting(self, H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, shapeCodes=None, uvCodes=None,
+                       expType=20, expCodes=None, near=0., far=1., use_viewdirs=False, c2w_staticcam=None,
+                       network_query_fn=None, **kwargs):
+        """Fitting / novel-view entry: texture code given directly, expression code stored at slot 20
+        (render_class.py:354-437)."""
+        unwrap(kwargs["network_fine"]).eval()
+        unwrap(kwargs["network_fn"]).eval()
+        self.shapeCodes = shapeCodes
+        self.expType = int(expType)
+        if len(self.expCodes_Sigma) == 20:
+            self.expCodes_Sigma.append(expCodes)
+        else:
+            self.expCodes_Sigma[20] = expCodes
+        return self._render_common(H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, uvCodes,
+                                   kwargs)
+
+    def render_path(self, render_poses, hwf, K, chunk, render_kwargs, uvMap=None, expType=None, gt_imgs=None,
+                    savedir=None, render_factor=0, shapeCodes=None, name=None):
+        """Render one image per pose (render_class.py:199-237).  Existing outputs are skipped so a bulk render can
+        resume.  Images are written as PNG when ``savedir`` is given and an encoder is importable."""
+        H, W, focal = hwf
+        if render_factor != 0:
+            H, W, focal = H // render_factor, W // render_factor, focal / render_factor
+        if savedir is not None:
+            filename = os.path.join(savedir, "{}.png".format(name))
+            if os.path.exists(filename):
+                print("exists")
+                return 0, 0
+        rgbs, disps = [], []
+        t = time.time()
+        for i, c2w in enumerate(render_poses):
+            print(i, time.time() - t)
+            t = time.time()
+            rgb, disp, acc, _ = self.render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], shapeCodes=shapeCodes[i, :].reshape(1, -1),
+                                            uvMap=uvMap[i, :], expType=expType[i], **render_kwargs)
+            rgbs.append(rgb.cpu().numpy())
+            disps.append(disp.cpu().numpy())
+            if savedir is not None:
+                from .io import write_png
+                fn = os.path.join(savedir, "{}.png".format(name) if name is not None else "{:03d}.png".format(i))
+                write_png(fn, (255 * np.clip(rgbs[-1], 0, 1)).astype(np.uint8))
+        return np.stack(rgbs, 0), np.stack(disps, 0)
+
+
+myRenderer = Renderer   # the reference's class name

@@ -1,0 +1,54 @@
+"""CPU-side checks of the C ABI: the library loads without a GPU and exports every symbol the header declares;
+argument validation returns MOFA_EINVAL with a message (no compute is launched)."""
+import ctypes
+import os
+import re
+
+from mofanerf_amd import build, lib, schema
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "mofanerf_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mofa_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    so = build.build()
+    L = ctypes.CDLL(so)
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/mofanerf_hip.h but not exported"
+    assert sorted(lib.SIGNATURES) == syms, "python binding and header disagree"
+
+
+def test_plan_sizes_and_argument_validation():
+    L = lib.load()
+    assert L.mofa_abi_version() == 1
+    for D, W in ((8, 256), (10, 1024), (8, 64)):
+        s = lib.NetShape(D, W)
+        assert L.mofa_net_num_layers(s) == 2 * D + 7 == len(schema.nerf_layers(D, W))
+        Wp, Hp = (W + 63) // 64 * 64, (W // 2 + 63) // 64 * 64
+        n_plain = 3 + 4 + 4 + 2 * (D - 6)
+        want = Wp * 64 + n_plain * Wp * Wp + 2 * Wp * Wp + 2 * Wp * 2 * Wp + Hp * Wp + Wp + 3 * Hp
+        assert want <= L.mofa_net_packed_floats(s) <= want + 64 * (2 * D + 7)
+        assert L.mofa_net_folded_floats(s) == (2 * D + 4) * Wp + 8
+        assert L.mofa_net_workspace_floats(s, 1000, 10) == 4 * 1024 * Wp + 10 * Hp + 64
+    assert L.mofa_net_num_layers(lib.NetShape(3, 256)) == -1
+    assert L.mofa_layer_forward(None, 16, None, 0, None, None, 0, 1, None, 256, 64, 1, None) == -1
+    assert b"null pointer" in L.mofa_last_error()
+    assert L.mofa_composite_forward(1, 1, 0, 1, None, 4, 1, 0, 1, 1, 1, 1, 1, None) == -1
+    assert b"S" in L.mofa_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    """The product package must not reach into oracle/ (nor any CPU fallback): grep the sources."""
+    pkg = os.path.join(ROOT, "mofanerf_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "mofa_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f

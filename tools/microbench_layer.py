@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the MFMA layer kernel through the C ABI: TFLOP/s of mofa_layer_forward at the shipped
+shapes, for both operand-staging arms (MOFA_STAGE=glds|reg).  Prints one line per case."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mofanerf_amd import lib  # noqa: E402
+
+L = lib.load()
+dev = "cuda"
+
+
+def run(M, K, N, k2=0, iters=10):
+    x = torch.randn(M * K, device=dev)
+    x2 = torch.randn(M * k2, device=dev) if k2 else None
+    w = torch.randn(N * (K + k2), device=dev) * 0.03
+    b = torch.randn(N, device=dev)
+    y = torch.empty(M * N, device=dev)
+    st = lib.stream()
+    args = (lib.ptr(x), K, lib.ptr(x2), k2, lib.ptr(w), lib.ptr(b), 0, 1, lib.ptr(y), M, N, 1, st)
+    for _ in range(3):
+        lib.check(L.mofa_layer_forward(*args), "layer")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        lib.check(L.mofa_layer_forward(*args), "layer")
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms, 2.0 * M * (K + k2) * N / (ms * 1e-3) / 1e12
+
+
+if __name__ == "__main__":
+    cases = [(196608, 1024, 1024, 0), (196608, 1024, 1024, 1024), (196608, 1024, 512, 0), (196608, 256, 256, 0),
+             (196608, 256, 256, 256), (32768, 1024, 1024, 0), (65536, 64, 64, 0)]
+    for stage in ("glds", "reg"):
+        os.environ["MOFA_STAGE"] = stage
+        for (M, K, N, k2) in cases:
+            ms, tf = run(M, K, N, k2)
+            print(f"stage={stage:4s} M={M:7d} K={K + k2:5d} N={N:5d}: {ms:8.3f} ms  {tf:7.2f} TFLOP/s  "
+                  f"({tf / 157.3 * 100:5.1f}% of fp32 MFMA peak)", flush=True)
