@@ -272,15 +272,19 @@ class OracleRenderer:
         o, d = rays_o.reshape(-1, 3).float(), rays_d.reshape(-1, 3).float()
         rays = torch.cat([o, d, near * torch.ones_like(d[:, :1]), far * torch.ones_like(d[:, :1]), vd], -1)
         parts: Dict[str, list] = {}
+        dbg: Dict[str, list] = {}
         per_ray = ("t_rand", "u", "noise0", "noise1")
         for i in range(0, rays.shape[0], chunk):
             kwi = {k: (v[i:i + chunk] if k in per_ray and v is not None and v.dim() > 1 else v) for k, v in kw.items()}
             r = self.render_rays(rays[i:i + chunk], shape_codes, tex_code, exp_type, **kwi)
-            r.pop("_dbg", None)
+            for k, v in (r.pop("_dbg", None) or {}).items():
+                dbg.setdefault(k, []).append(v)
             for k, v in r.items():
                 parts.setdefault(k, []).append(v)
         allr = {k: torch.cat(v, 0) for k, v in parts.items()}
         allr = {k: v.reshape(list(sh[:-1]) + list(v.shape[1:])) for k, v in allr.items()}
         extras = {k: v for k, v in allr.items() if k not in ("rgb_map", "disp_map", "acc_map")}
         extras["losses"] = 0    # lossesLog.out() is always the int 0 (render_class.py:30-37, encoder returns {})
+        if dbg:                 # keep=True: per-ray intermediates, flat over rays
+            extras["_dbg"] = {k: torch.cat(v, 0) for k, v in dbg.items()}
         return [allr["rgb_map"], allr["disp_map"], allr["acc_map"], extras]

@@ -153,8 +153,12 @@ def test_layer0_positional_encoding_fused():
     lib.check(L().mofa_layer0_forward(None, None, None, 0, lib.ptr(dev(pts)), M, S, lib.ptr(wp), lib.ptr(b), lib.ptr(yp),
                                       Mp, N, st), "layer0/pts")
     lib.check(L().mofa_from_panels(lib.ptr(yp), Mp, M, N, lib.ptr(y2), st), "from_panels")
-    ref = torch.relu(orc.positional_encode(pts, 10).double() @ w.double().cpu().T + b.double().cpu()).float().numpy()
-    nan_equal_close(y2.cpu().numpy(), ref, 5e-6)
+    pe = orc.positional_encode(pts, 10).double()
+    ref = torch.relu(pe @ w.double().cpu().T + b.double().cpu()).float().numpy()
+    # fp32 fmaf-chain: sqrt(K)*2^-24*|partial sums| ~ 1e-6 * sum_k |a_k b_k| (raw x features reach |x| ~ 50 here)
+    bound = (1e-6 * (pe.abs() @ w.double().cpu().abs().T + b.double().cpu().abs()) + 1e-6).numpy()
+    err = np.abs(y2.cpu().numpy() - ref)
+    assert (err <= bound).all(), float((err - bound).max())
     assert torch.equal(y, y2)      # in-kernel o + d*z is bit-identical to the separately rounded torch ops
 
 
@@ -295,13 +299,10 @@ def test_sample_pdf_merge_vs_oracle():
         zs, zf, sd = _sample(dev(z), dev(w), dev(u), ustride)
         zmid = .5 * (z[:, 1:] + z[:, :-1])
         ref = orc.sample_pdf(zmid, w[:, 1:-1], u)
-        pdf = (w[:, 1:-1] + 1e-5) / (w[:, 1:-1] + 1e-5).sum(-1, keepdim=True)
-        err = (zs - ref).abs()
-        # conditioning: |dz| <= binwidth * 2^-23 / pdf_bin  (cdf rounding of ~1 ulp of 1.0)
-        worst_pdf = pdf.min(-1, keepdim=True)[0].clamp_min(1e-5)
-        lim = 4e-6 + 0.6 * 6e-8 / worst_pdf * 3.0
-        assert (err <= lim).all(), float((err - lim).max())
-        assert float(err.median()) <= 2e-6
+        from harness import classify_samples
+        agree, expl = classify_samples(z, w, u, zs, ref)
+        assert (agree | expl).all(), int((~(agree | expl)).sum())
+        assert float(agree.float().mean()) > 0.9 and float((zs - ref).abs().median()) <= 2e-6
         zref, _ = torch.sort(torch.cat([z, zs], -1), -1)
         assert torch.equal(zf, zref)                                   # merge is an exact sort of what we sampled
         nan_equal_close(sd.numpy(), torch.std(zs, dim=-1, unbiased=False).numpy(), 2e-6, 2e-6)
@@ -316,7 +317,7 @@ def test_sample_pdf_golden(golden):
     ww = torch.cat([torch.zeros(bins.shape[0], 1), w, torch.zeros(bins.shape[0], 1)], -1)
     zs, zf, sd = _sample(dev(z), dev(ww), dev(torch.linspace(0., 1., 64)), 0)
     ref = orc.sample_pdf(.5 * (z[:, 1:] + z[:, :-1]), w, torch.linspace(0., 1., 64))
-    good = (w + 1e-5) / (w + 1e-5).sum(-1, keepdim=True)
-    rows = good.min(-1)[0] > 1e-4
-    nan_equal_close(zs[rows].numpy(), ref[rows].numpy(), 1e-5)
+    from harness import classify_samples
+    agree, expl = classify_samples(z, ww, torch.linspace(0., 1., 64), zs, ref)
+    assert (agree | expl).all()
     nan_equal_close(zs[0].numpy(), ref[0].numpy(), 1e-5)               # all-zero weights -> uniform pdf

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import nan_equal_close
-from harness import make_oracle, make_product, render_pair, to_np
+from harness import compare_render, make_oracle, make_product, render_pair, to_np
 from mofanerf_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -27,37 +27,23 @@ def _fit(g, **over):
     return out
 
 
-def _check(g, out, tol=1e-4):
+def _check(g, out, u=None, tol=1e-4):
     rgb, disp, acc, ex = out
     H = int(g["H"])
     assert rgb.shape == (H, H, 3) and disp.shape == (H, H) and ex["rgb0"].shape == (H, H, 3)
-    errs = {}
-    errs["rgb"] = nan_equal_close(rgb.cpu().numpy(), g["rgb"], tol)
-    errs["acc"] = nan_equal_close(acc.cpu().numpy(), g["acc"], tol)
-    errs["rgb0"] = nan_equal_close(ex["rgb0"].cpu().numpy(), g["rgb0"], tol)
-    errs["acc0"] = nan_equal_close(ex["acc0"].cpu().numpy(), g["acc0"], tol)
-    errs["disp"] = nan_equal_close(disp.cpu().numpy(), g["disp"], 1e-6, 1e-4)
-    errs["disp0"] = nan_equal_close(ex["disp0"].cpu().numpy(), g["disp0"], 1e-6, 1e-4)
-    errs["z_std"] = nan_equal_close(ex["z_std"].cpu().numpy(), g["z_std"], 1e-3)
     assert ex["losses"] == 0
-    print({k: f"{v:.2e}" for k, v in errs.items()})
+    hip = to_np(dict(rgb=rgb, disp=disp, acc=acc, rgb0=ex["rgb0"], disp0=ex["disp0"], acc0=ex["acc0"], z_std=ex["z_std"],
+                     z_samples=ex["_z_samples"], z_fine=ex["_z_fine"], weights_coarse=ex["_weights0"]))
+    errs = compare_render(hip, g, u=u, tol=tol)
+    zf = hip["z_fine"].reshape(H * H, -1)
+    assert (np.diff(zf, axis=-1) >= 0).all()                   # merged sample positions are sorted
     return errs
 
 
 def test_render_fitting_small_golden(golden):
     """256 rays, coarse 8x64 + fine 10x128, chunk 96 (3 ragged chunks), rays generated on the device."""
     g = golden("e2e_small.npz")
-    out = _fit(g)
-    _check(g, out)
-    ex = out[3]
-    R = int(g["H"]) ** 2
-    # intermediates: coarse weights, new samples (conditioning-aware), merged z
-    nan_equal_close(ex["_weights0"].reshape(R, 64).cpu().numpy(), g["weights_coarse"], 1e-5)
-    zs, zs_ref = ex["_z_samples"].reshape(R, 64).cpu().numpy(), g["z_samples"]
-    assert np.median(np.abs(zs - zs_ref)) <= 4e-6
-    assert (np.abs(zs - zs_ref) <= 5e-2).all()
-    zf = ex["_z_fine"].reshape(R, 128).cpu().numpy()
-    assert (np.diff(zf, axis=-1) >= 0).all()
+    _check(g, _fit(g))
 
 
 def test_render_fitting_true_size_golden(golden):
@@ -69,22 +55,80 @@ def test_render_fitting_true_size_golden(golden):
 def test_render_fitting_stochastic_golden(golden):
     """perturb=1, raw_noise_std=0.5, white_bkgd, pytest=True (seed-0 numpy randoms, as the reference's hook)."""
     g = golden("e2e_small_stoch.npz")
-    _check(g, _fit(g, perturb=1.0, raw_noise_std=float(g["noise"]), white_bkgd=True, pytest=True))
+    np.random.seed(0)
+    u = torch.Tensor(np.random.rand(int(g["H"]) ** 2, 64))
+    _check(g, _fit(g, perturb=1.0, raw_noise_std=float(g["noise"]), white_bkgd=True, pytest=True), u=u)
 
 
 def test_render_with_texture_encoder_golden(golden):
     g = golden("render_tex.npz")
     render, kw, _ = make_product((8, 64, 10, 64), 0, 4096, DEV, with_tex=True)
-    uv = T(np.random.default_rng(5).uniform(0, 1, (512, 512, 3)).astype(np.float32)).to(DEV)
-    rays = T(g["rays"]).to(DEV)
+    uv_cpu = T(np.random.default_rng(5).uniform(0, 1, (512, 512, 3)).astype(np.float32))
+    rays = T(g["rays"])
     with torch.no_grad():
-        rgb, disp, acc, ex = render.render(8, 8, None, chunk=64, rays=rays, shapeCodes=T(g["bm"]).expand(64, 50).to(DEV),
-                                           uvMap=uv, expType=7, retraw=True, **kw)
+        rgb, disp, acc, ex = render.render(8, 8, None, chunk=64, rays=rays.to(DEV), uvMap=uv_cpu.to(DEV), expType=7,
+                                           shapeCodes=T(g["bm"]).expand(64, 50).to(DEV), retraw=True, verbose=True, **kw)
     nan_equal_close(render.decoding_texCodes.cpu().numpy(), g["tex_code"], 2e-5, 1e-4)
-    nan_equal_close(rgb.cpu().numpy(), g["rgb"], 1e-4)
-    nan_equal_close(acc.cpu().numpy(), g["acc"], 1e-4)
-    nan_equal_close(ex["raw"].cpu().numpy(), g["raw"], 2e-3, 1e-3)
     assert ex["losses"] == 0 and rgb.shape == (64, 3)
+    o = make_oracle((8, 64, 10, 64), 0, 4096, with_tex=True)       # oracle intermediates (fixture holds outputs only)
+    with torch.no_grad():
+        r_rgb, r_disp, r_acc, r_ex = o.render(rays[0], rays[1], 64, T(g["bm"]), 7, 8.0, 26.0, uv_map=uv_cpu, N_samples=64,
+                                              N_importance=64, keep=True)
+    # (that the oracle reproduces the reference's fixture is asserted on the build host by test_oracle_golden.py; on
+    #  another CPU its BLAS rounding differs and the same 2^9 amplification applies, so it is not re-asserted here)
+    d = r_ex["_dbg"]
+    ref = to_np(dict(rgb=r_rgb, disp=r_disp, acc=r_acc, rgb0=r_ex["rgb0"], disp0=r_ex["disp0"], acc0=r_ex["acc0"],
+                     z_std=r_ex["z_std"], z_samples=d["z_samples"], z_coarse=d["z_coarse"], weights_coarse=d["weights_coarse"]))
+    hip = to_np(dict(rgb=rgb, disp=disp, acc=acc, rgb0=ex["rgb0"], disp0=ex["disp0"], acc0=ex["acc0"], z_std=ex["z_std"],
+                     z_samples=ex["_z_samples"], weights_coarse=ex["_weights0"]))
+    compare_render(hip, ref)
+
+
+def _teacher_forced(g, tol=1e-4):
+    """Fine pass with the REFERENCE's sample positions: HIP fine network on the fixture's z_fine, HIP compositing, against
+    the fixture's raw/rgb/acc for EVERY ray (no tiering: inputs are identical, only fp32 rounding differs)."""
+    from mofanerf_amd import lib
+    from oracle import mofa_oracle as orc
+    arch = tuple(int(v) for v in g["arch"])
+    render, kw, _ = make_product(arch, int(g["seed"]), int(g["netchunk"]), DEV)
+    H = int(g["H"])
+    ro, rd = orc.get_rays(H, H, g["K"], T(g["c2w"]))
+    ro, rd = ro.reshape(-1, 3).contiguous().to(DEV), rd.reshape(-1, 3).contiguous().to(DEV)
+    vd = (rd / torch.norm(rd, dim=-1, keepdim=True)).contiguous()
+    render.shapeCodes, render.expType = T(g["bm"]).to(DEV), 20
+    if len(render.expCodes_Sigma) == 20:
+        render.expCodes_Sigma.append(T(g["exp"]).to(DEV))
+    R = H * H
+    outs = {}
+    for tag, net, S in (("coarse", kw["network_fn"], 64), ("fine", kw["network_fine"], 128)):
+        folded = render._fold_codes(net, T(g["tex"]).to(DEV))
+        z = T(g[f"z_{tag}"]).contiguous().to(DEV)
+        raw = torch.empty(R, S, 4, device=DEV)
+        render._hip(net).forward_rays(ro, rd, z, S, vd, S, raw, folded)
+        o = {k: torch.empty(R, *sh, device=DEV) for k, sh in (("rgb", (3,)), ("disp", ()), ("acc", ()), ("depth", ()),
+                                                              ("weights", (S,)))}
+        lib.check(lib.load().mofa_composite_forward(lib.ptr(raw), lib.ptr(z), S, lib.ptr(rd), None, R, S, 0,
+                                                    lib.ptr(o["rgb"]), lib.ptr(o["disp"]), lib.ptr(o["acc"]),
+                                                    lib.ptr(o["depth"]), lib.ptr(o["weights"]), lib.stream()), "composite")
+        torch.cuda.synchronize()
+        sfx = "0" if tag == "coarse" else ""
+        outs[tag] = dict(
+            raw=nan_equal_close(raw.cpu().numpy(), g[f"raw_{tag}"], 1e-4, 1e-4),
+            weights=nan_equal_close(o["weights"].cpu().numpy(), g[f"weights_{tag}"], 2e-5),
+            rgb=nan_equal_close(o["rgb"].cpu().numpy(), g["rgb" + sfx].reshape(R, 3), tol),
+            acc=nan_equal_close(o["acc"].cpu().numpy(), g["acc" + sfx].reshape(R), tol),
+            disp=nan_equal_close(o["disp"].cpu().numpy(), g["disp" + sfx].reshape(R), 1e-6, 1e-4))
+    print({t: {k: f"{v:.2e}" for k, v in d.items()} for t, d in outs.items()})
+    return outs
+
+
+def test_fine_pass_teacher_forced_small(golden):
+    _teacher_forced(golden("e2e_small.npz"))
+
+
+def test_fine_pass_teacher_forced_true_size(golden):
+    """The shipped sizes (coarse 256x8, fine 1024x10): raw within 1e-4, RGB/acc within 1e-4 on every ray."""
+    _teacher_forced(golden("e2e_true.npz"))
 
 
 def test_run_network_api():
@@ -127,9 +171,7 @@ def test_chunk_and_netchunk_invariance_shipped_sizes():
 def test_device_pair_vs_oracle_medium():
     """1024 rays (32x32 view), coarse 8x128 + fine 10x256: HIP vs oracle on identical rays."""
     hip, ref = render_pair(32, synth.intrinsics(32, 32), 60.0, (8, 128, 10, 256), chunk=400, netchunk=20000, device=DEV)
-    for k, tol in (("rgb", 1e-4), ("acc", 1e-4), ("rgb0", 1e-4), ("acc0", 1e-4)):
-        print(k, nan_equal_close(hip[k], ref[k], tol))
-    nan_equal_close(hip["disp"], ref["disp"], 1e-6, 1e-4)
+    compare_render(hip, ref)
 
 
 def test_cpu_tensors_fail_loudly():
