@@ -152,8 +152,9 @@ def main():
 
     def step(i):
         r = rays[angles[i % len(angles)]]
-        rgb, disp, acc, _ = render.render_fitting(H, W, K, chunk=args.chunk, rays=r, shapeCodes=bm, uvCodes=tex,
-                                                  expType=20, expCodes=exp, **kw)
+        with torch.no_grad():                                           # render-only, as run_fit.py's novel-view loop
+            rgb, disp, acc, _ = render.render_fitting(H, W, K, chunk=args.chunk, rays=r, shapeCodes=bm, uvCodes=tex,
+                                                      expType=20, expCodes=exp, **kw)
         tile = torch.cat([rgb, disp[:, None], acc[:, None]], -1)        # [rays/N, 5]
         return mdist.all_gather_tiles(tile, n_total, world, rank, align=W)
 
@@ -181,10 +182,13 @@ def main():
         my_rays = (e - b) * a.steps
         alg_flops = layer_kernel_flops_per_ray() * my_rays               # algorithmic work of this rank's k_layer launches
         achieved = alg_flops / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")       # PMC-derived bytes/launch, if a pass was collected
+        traffic, tinfo = None, {}
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")       # PMC-derived bytes/launch (separate --pmc passes)
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("bytes_per_launch")
+            tinfo = {"traffic_shape": tj.get("shape"), "traffic_algorithmic_bytes_same_shape": tj.get("algorithmic_bytes_per_launch"),
+                     "mfma_busy_fraction_pmc": tj.get("mfma_busy_fraction")}
         out = {
             "metric": "rendered rays/sec (64c+128f samples) at 512^2 novel-view", "value": round(rays_per_s, 1),
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -202,7 +206,7 @@ def main():
                          "launches": int(launches.value),
                          "avg_launch_ms": round(ms.value / max(1, launches.value), 4),
                          "algorithmic_gflop_per_launch": round(alg_flops / max(1, launches.value) / 1e9, 3),
-                         "padded_over_algorithmic": round(pflops.value / alg_flops, 4) if alg_flops else None},
+                         "padded_over_algorithmic": round(pflops.value / alg_flops, 4) if alg_flops else None, **tinfo},
         }
         if world == 1 and a.cpu_rays > 0:
             out["cpu_baseline"] = cpu_baseline(a.cpu_rays)

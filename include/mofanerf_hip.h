@@ -84,11 +84,50 @@ int mofa_net_fold(MofaNetShape s, const float* const* weights, const float* cons
  *   view_w [W/2, 27+W], view_b [W/2]: the ORIGINAL linear_view_xyBMuv.0 tensors (their 27 view
  *   columns become a per-ray bias, computed here from viewdirs)
  *   raw_out [n_rays,S,4] = (rgb pre-sigmoid, sigma pre-ReLU)
- *   workspace: mofa_net_workspace_floats(s, n_rays*S, n_rays) floats. */
+ *   workspace: mofa_net_workspace_floats(s, n_rays*S, n_rays) floats.
+ *   tape: NULL for inference (4 activation buffers are recycled), or mofa_net_tape_floats() floats that receive EVERY
+ *         layer's output for mofa_net_backward (fitting / training; sized for 288 GB of HBM: no recomputation)
+ *   view_bias_rows: NULL (computed here from viewdirs), or caller-provided per-ray bias rows [n_rays, roundup(W/2,64)]
+ *         (the autograd path computes them on the host so that gradients reach viewdirs and the 27 view columns) */
 int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, const float* view_w,
                      const float* view_b, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
                      const float* pts, const float* viewdirs, int64_t n_rays, int32_t S, float* workspace,
-                     float* raw_out, void* stream);
+                     float* raw_out, float* tape, const float* view_bias_rows, void* stream);
+
+/* ---- backward (run_fit.py:305-313 photometric fitting, run_train.py:333-357 training) -----------------------
+ * Backward of mofa_net_forward given d_raw [n_rays,S,4] and the tape of that forward:
+ *   d_folded  [mofa_net_folded_floats]: gradient w.r.t. every folded bias (sum over points of the ReLU-masked
+ *             pre-activation gradient) — host autograd carries it on to the codes / raw biases / constant columns;
+ *   d_view_bias_rows [n_rays, roundup(W/2,64)]: gradient w.r.t. the per-ray view bias rows;
+ *   d_rays_o, d_rays_d [n_rays,3]: through the positional encoding and pts = o + d*z (z carries no gradient: the
+ *             coarse z is constant and the fine z is detached, render_class.py:326).
+ * packed_t: transposed weight panels from mofa_net_pack_t; workspace: mofa_net_backward_workspace_floats(). */
+size_t mofa_net_packed_t_floats(MofaNetShape s);
+size_t mofa_net_tape_floats(MofaNetShape s, int64_t n_points);
+size_t mofa_net_backward_workspace_floats(MofaNetShape s, int64_t n_points);
+int mofa_net_pack_t(MofaNetShape s, const float* const* weights, float* packed_t, void* stream);
+int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t, const float* tape,
+                      const float* d_raw, const float* rays_o, const float* rays_d, const float* z,
+                      int64_t z_row_stride, int64_t n_rays, int32_t S, float* workspace, float* d_folded,
+                      float* d_view_bias_rows, float* d_rays_o, float* d_rays_d, void* stream);
+/* pieces of mofa_net_backward (unit-testable) */
+int mofa_pack_panels_t(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, float* dst,
+                       int32_t rows_padded, int32_t k_padded, void* stream);
+int mofa_layer_backward_data(const float* g, int32_t g_k, const float* wt_packed, const float* mask, int32_t accumulate,
+                             float* dx, int64_t m_padded, int32_t k_out_padded, void* stream);
+int mofa_head_backward(const float* d_raw, int32_t raw_off, int32_t n_out, const float* w_dense, int32_t k_padded,
+                       const float* mask, int32_t accumulate, float* dx, int64_t m_padded, int64_t n_points, void* stream);
+int mofa_bias_grad(const float* g, int64_t m_padded, int64_t n_points, int32_t n_padded, float* out, void* stream);
+int mofa_bias_grad_rays(const float* g, int64_t m_padded, int64_t n_rays, int32_t S, int32_t n_padded, float* out,
+                        void* stream);
+int mofa_pe_backward(const float* dpe, int64_t m_padded, const float* rays_o, const float* rays_d, const float* z,
+                     int64_t z_row_stride, int64_t n_rays, int32_t S, float* d_rays_o, float* d_rays_d, void* stream);
+/* raw2outputs backward: upstream gradients g_* (g_disp/g_acc/g_depth/g_weights may be NULL = zero) ->
+ * d_raw [n_rays,S,4] and the |rays_d| contribution d_rays_d [n_rays,3] (may be NULL). */
+int mofa_composite_backward(const float* raw, const float* z, int64_t z_row_stride, const float* rays_d,
+                            const float* noise, int64_t n_rays, int32_t S, int32_t white_bkgd, const float* g_rgb,
+                            const float* g_disp, const float* g_acc, const float* g_depth, const float* g_weights,
+                            float* d_raw, float* d_rays_d, void* stream);
 
 /* ---- single-layer entry points (unit-testable pieces of mofa_net_forward) -------------------- */
 size_t mofa_panel_floats(int64_t rows, int32_t k); /* rows * roundup(k,16) */

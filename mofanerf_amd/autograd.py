@@ -1,0 +1,138 @@
+"""Autograd glue for the fitting / training entry points (run_fit.py:305-313, run_train.py:333-357).
+
+The per-point work — forward with a tape of every layer's output, backward-data GEMMs, ReLU masks, bias-gradient
+column sums, positional-encoding and compositing backward — runs in HIP (``mofa_net_forward`` with a tape,
+``mofa_net_backward``, ``mofa_composite_backward``).  What PyTorch's autograd carries is only the per-CALL /
+per-RAY algebra whose inputs are the things the scripts optimise:
+
+* the folded bias blob ``b' = b + W[:, const cols] @ code`` (five matvecs per network) — so gradients reach the shape /
+  texture / expression codes (and, in training, the constant weight columns and every bias);
+* the per-ray view-bias rows ``b + PE(viewdir) @ W[:, :27]^T`` — so gradients reach the camera pose through viewdirs;
+* ``viewdirs = rays_d / |rays_d|`` and the ray tensors themselves.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import lib, schema
+from .hipnet import HipNet
+
+
+def _pad_to(v: torch.Tensor, n: int) -> torch.Tensor:
+    return v if v.shape[-1] == n else F.pad(v, (0, n - v.shape[-1]))
+
+
+def _ru(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def fold_torch(h: HipNet, exp_code: torch.Tensor, shape_code: torch.Tensor, tex_code: torch.Tensor) -> torch.Tensor:
+    """Differentiable twin of ``mofa_net_fold``: same blob layout (one ``n_padded`` slice per layer in state-dict order,
+    the view layer skipped, heads padded to 4)."""
+    D = h.net.D
+    lin = h._linears
+    bim0, bim_skip, uv0, uv_skip, view = 4, 9, 4 + D, 9 + D, 4 + 2 * D
+    e, s, t = exp_code.reshape(-1), shape_code.reshape(-1), tex_code.reshape(-1)
+    parts: List[torch.Tensor] = []
+    for li, l in enumerate(lin):
+        if li == view:
+            continue
+        b = l.bias
+        if li == 0:
+            b = b + l.weight[:, schema.PE_POINTS:schema.PE_POINTS + schema.CH_EXP] @ e
+        elif li in (bim0, bim_skip):
+            b = b + l.weight[:, :schema.CH_SHAPE] @ s
+        elif li in (uv0, uv_skip):
+            b = b + l.weight[:, :schema.CH_TEX] @ t
+        parts.append(_pad_to(b, 4 if li > view else _ru(l.out_features, 64)))
+    return torch.cat(parts)
+
+
+def view_bias_torch(h: HipNet, viewdirs: torch.Tensor) -> torch.Tensor:
+    """Differentiable twin of ``mofa_view_bias``: ``[R, roundup(W/2, 64)]``."""
+    l = h._linears[-3]
+    feats = [viewdirs]
+    for i in range(4):                                  # multires_views = 4
+        f = float(2 ** i)
+        feats += [torch.sin(viewdirs * f), torch.cos(viewdirs * f)]
+    pe = torch.cat(feats, -1)
+    return _pad_to(pe @ l.weight[:, :schema.PE_VIEWS].t() + l.bias, _ru(l.out_features, 64))
+
+
+class NetFn(torch.autograd.Function):
+    """raw[R,S,4] = NeRF(PE(o + d z), folded biases, per-ray view bias) with a HIP backward."""
+
+    @staticmethod
+    def forward(ctx, h: HipNet, rays_o, rays_d, z, z_row_stride: int, S: int, folded, vbias):
+        L = h._L
+        R = rays_o.shape[0]
+        dev = rays_o.device
+        ro, rd = rays_o.detach().contiguous(), rays_d.detach().contiguous()
+        zc = z.detach().contiguous()
+        fo, vb = folded.detach().contiguous(), vbias.detach().contiguous()
+        raw = torch.empty(R, S, 4, dtype=torch.float32, device=dev)
+        tape = torch.empty(L.mofa_net_tape_floats(h.shape, R * S), dtype=torch.float32, device=dev)
+        ws = h.workspace(R * S, R, dev)
+        lib.check(L.mofa_net_forward(h.shape, lib.ptr(h.packed()), lib.ptr(fo), None, None, lib.ptr(ro), lib.ptr(rd),
+                                     lib.ptr(zc), z_row_stride, None, None, R, S, lib.ptr(ws), lib.ptr(raw), lib.ptr(tape),
+                                     lib.ptr(vb), lib.stream()), "mofa_net_forward(tape)")
+        ctx.h, ctx.S, ctx.z_row_stride = h, S, z_row_stride
+        ctx.save_for_backward(ro, rd, zc, tape)
+        ctx.n_folded, ctx.vb_shape = fo.numel(), tuple(vb.shape)
+        return raw
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        h, S = ctx.h, ctx.S
+        L = h._L
+        ro, rd, zc, tape = ctx.saved_tensors
+        R, dev = ro.shape[0], ro.device
+        d_raw = d_raw.contiguous()
+        d_folded = torch.empty(ctx.n_folded, dtype=torch.float32, device=dev)
+        d_vb = torch.empty(ctx.vb_shape, dtype=torch.float32, device=dev)
+        d_o, d_d = torch.empty_like(ro), torch.empty_like(rd)
+        ws = h.backward_workspace(R * S, dev)
+        lib.check(L.mofa_net_backward(h.shape, lib.ptr(h.packed()), lib.ptr(h.packed_t()), lib.ptr(tape), lib.ptr(d_raw),
+                                      lib.ptr(ro), lib.ptr(rd), lib.ptr(zc), ctx.z_row_stride, R, S, lib.ptr(ws),
+                                      lib.ptr(d_folded), lib.ptr(d_vb), lib.ptr(d_o), lib.ptr(d_d), lib.stream()),
+                  "mofa_net_backward")
+        return None, d_o, d_d, None, None, None, d_folded, d_vb
+
+
+class CompositeFn(torch.autograd.Function):
+    """raw2outputs with a HIP backward.  Returns (rgb, disp, acc, depth, weights)."""
+
+    @staticmethod
+    def forward(ctx, raw, z, z_row_stride: int, rays_d, noise, white_bkgd: bool):
+        L = lib.load()
+        R, S = raw.shape[0], raw.shape[1]
+        dev = raw.device
+        rawc, zc, rd = raw.detach().contiguous(), z.detach().contiguous(), rays_d.detach().contiguous()
+        o = [torch.empty(R, *sh, dtype=torch.float32, device=dev) for sh in ((3,), (), (), (), (S,))]
+        lib.check(L.mofa_composite_forward(lib.ptr(rawc), lib.ptr(zc), z_row_stride, lib.ptr(rd), lib.ptr(noise), R, S,
+                                           int(bool(white_bkgd)), *[lib.ptr(t) for t in o], lib.stream()),
+                  "mofa_composite_forward")
+        ctx.save_for_backward(rawc, zc, rd, noise if noise is not None else torch.empty(0, device=dev))
+        ctx.meta = (z_row_stride, bool(white_bkgd), noise is not None)
+        return tuple(o)
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_depth, g_weights):
+        L = lib.load()
+        rawc, zc, rd, noise = ctx.saved_tensors
+        z_row_stride, white, has_noise = ctx.meta
+        R, S = rawc.shape[0], rawc.shape[1]
+        d_raw = torch.empty_like(rawc)
+        d_rd = torch.empty_like(rd)
+        c = lambda g: None if g is None else g.contiguous()
+        if g_rgb is None:
+            g_rgb = torch.zeros(R, 3, dtype=torch.float32, device=rawc.device)
+        lib.check(L.mofa_composite_backward(lib.ptr(rawc), lib.ptr(zc), z_row_stride, lib.ptr(rd),
+                                            lib.ptr(noise) if has_noise else None, R, S, int(white), lib.ptr(c(g_rgb)),
+                                            lib.ptr(c(g_disp)), lib.ptr(c(g_acc)), lib.ptr(c(g_depth)),
+                                            lib.ptr(c(g_weights)), lib.ptr(d_raw), lib.ptr(d_rd), lib.stream()),
+                  "mofa_composite_backward")
+        return d_raw, None, None, d_rd, None, None

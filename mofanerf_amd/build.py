@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmofanerf_hip.so")
-SOURCES = ["mofa_mlp.hip", "mofa_rays.hip", "mofa_net.hip"]
+SOURCES = ["mofa_mlp.hip", "mofa_rays.hip", "mofa_bwd.hip", "mofa_net.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function"]
 

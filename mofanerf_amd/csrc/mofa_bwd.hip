@@ -1,0 +1,349 @@
+// Backward kernels of the hot path (fitting / training: run_fit.py:305-313, run_train.py:333-357).
+// The backward-data GEMMs reuse k_layer (mofa_mlp.hip, BWD epilogue); this file holds the HBM-bound pieces:
+// head backward, bias-gradient column sums, positional-encoding backward and raw2outputs backward.
+// Built with -ffp-contract=off like the forward.
+#include "mofa_common.h"
+
+namespace mofa {
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- head backward: dX[m][k] (+)= sum_o d_raw[m][off+o] * w[o][k], optionally * (saved > 0) -------------------
+// one thread per (point, 16-byte chunk of features); dx in panels [kp][m_padded][16].
+__global__ __launch_bounds__(256) void k_head_backward(const float* __restrict__ d_raw, int raw_off, int n_out,
+                                                       const float* __restrict__ w, int k_padded,
+                                                       const float* __restrict__ mask, int accumulate,
+                                                       float* __restrict__ dx, long long m_padded, long long n_points) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over m_padded * (k_padded/4)
+    const int chunks = k_padded >> 2;
+    if (idx >= m_padded * chunks) return;
+    // consecutive threads walk one panel row-major: (panel, m, physical chunk p)
+    const int p = (int)(idx & 3);
+    const long long rowpanel = idx >> 2;
+    const long long m = rowpanel % m_padded;
+    const int panel = (int)(rowpanel / m_padded);
+    const int k = panel * 16 + ((p ^ ((int)(m >> 2) & 3)) << 2);
+    const long long off = ((long long)panel * m_padded + m) * 16 + (p << 2);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (m < n_points) {
+        for (int o = 0; o < n_out; ++o) {
+            const float g = d_raw[m * 4 + raw_off + o];
+            const float* wo = w + (long long)o * k_padded + k;
+            v.x = fmaf(g, wo[0], v.x), v.y = fmaf(g, wo[1], v.y), v.z = fmaf(g, wo[2], v.z), v.w = fmaf(g, wo[3], v.w);
+        }
+    }
+    if (accumulate) {
+        const f32x4 o = *(const f32x4*)(dx + off);
+        v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+    }
+    if (mask) {
+        const f32x4 s = *(const f32x4*)(mask + off);
+        v.x = s.x > 0.f ? v.x : 0.f, v.y = s.y > 0.f ? v.y : 0.f, v.z = s.z > 0.f ? v.z : 0.f, v.w = s.w > 0.f ? v.w : 0.f;
+    }
+    *(f32x4*)(dx + off) = v;
+}
+
+// ---- bias gradient: out[n] = sum_{m < n_points} G[m][n]; one block per 16-feature panel ----------------------
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, long long m_padded, long long n_points,
+                                                float* __restrict__ out) {
+    __shared__ float red[256][17];
+    const int panel = blockIdx.x;
+    const float* base = g + (long long)panel * m_padded * 16;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    for (long long m = threadIdx.x; m < n_points; m += 256) {
+        const int sw = (int)(m >> 2) & 3;
+        const f32x4* row = (const f32x4*)(base + m * 16);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 v = row[c ^ sw];
+            acc[4 * c + 0] += v.x, acc[4 * c + 1] += v.y, acc[4 * c + 2] += v.z, acc[4 * c + 3] += v.w;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) red[threadIdx.x][c] = acc[c];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) red[threadIdx.x][c] += red[threadIdx.x + s][c];
+        __syncthreads();
+    }
+    if (threadIdx.x < 16) out[panel * 16 + threadIdx.x] = red[0][threadIdx.x];
+}
+
+// ---- per-ray bias gradient (view layer): out[r][n] = sum_{s<S} G[r*S+s][n]; thread per (ray, 4 features) ------
+__global__ __launch_bounds__(256) void k_colsum_rays(const float* __restrict__ g, long long m_padded, long long n_rays,
+                                                     int S, int n_padded, float* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int chunks = n_padded >> 2;
+    if (idx >= n_rays * chunks) return;
+    const long long r = idx / chunks;
+    const int ch = (int)(idx - r * chunks);
+    const int panel = ch >> 2, c = ch & 3;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+        const long long m = r * S + s;
+        const f32x4 v = *(const f32x4*)(g + ((long long)panel * m_padded + m) * 16 + ((c ^ ((int)(m >> 2) & 3)) << 2));
+        acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+    }
+    *(f32x4*)(out + r * n_padded + ch * 4) = acc;
+}
+
+// ---- positional-encoding backward + pts = o + d*z backward --------------------------------------------------
+// dpe: panels [4][m_padded][16] (gradient w.r.t. the 63 encoding features, k = 63 is padding).  One wavefront per ray.
+__global__ __launch_bounds__(256) void k_pe_backward(const float* __restrict__ dpe, long long m_padded,
+                                                     const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                     const float* __restrict__ z, long long z_row_stride,
+                                                     long long n_rays, int S, float* __restrict__ d_rays_o,
+                                                     float* __restrict__ d_rays_d) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const float ox = rays_o[ray * 3], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
+    const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+    float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+    for (int s = lane; s < S; s += 64) {
+        const long long m = ray * S + s;
+        const float zz = z[ray * z_row_stride + s];
+        const float x[3] = {__fadd_rn(ox, __fmul_rn(dx, zz)), __fadd_rn(oy, __fmul_rn(dy, zz)),
+                            __fadd_rn(oz, __fmul_rn(dz, zz))};
+        const int sw = (int)(m >> 2) & 3;
+        auto at = [&](int k) -> float {   // gradient w.r.t. encoding feature k of point m (panel layout)
+            return dpe[(long long)(k >> 4) * m_padded * 16 + m * 16 + ((((k >> 2) & 3) ^ sw) << 2) + (k & 3)];
+        };
+        float gx[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gx[d] = at(d);                     // identity features
+#pragma unroll 1
+        for (int f = 0; f < MOFA_PE_POINT_FREQS; ++f) {
+            const float fr = (float)(1 << f);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float gs = at(3 + 6 * f + d), gc = at(6 + 6 * f + d);
+                float sn, cs;
+                sincosf(x[d] * fr, &sn, &cs);
+                // d/dx sin(f x) = f cos(f x);  d/dx cos(f x) = -f sin(f x)
+                gx[d] += fr * (gs * cs - gc * sn);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) go[c] += gx[c], gd[c] += gx[c] * zz;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float a = wave_sum(go[c]), b = wave_sum(gd[c]);
+        if (lane == 0) d_rays_o[ray * 3 + c] = a, d_rays_d[ray * 3 + c] = b;
+    }
+}
+
+// ---- raw2outputs backward (models/render_class.py:440-482) ---------------------------------------------------
+// w_i = alpha_i T_i, T_i = prod_{j<i}(1 - alpha_j + 1e-10).  With G_i = dL/dw_i (collected from rgb, depth, acc, disp and
+// the explicit weights gradient):  dL/dalpha_j = G_j T_j - (sum_{i>j} G_i w_i) / (1 - alpha_j + 1e-10).
+template <int SPL>
+__global__ __launch_bounds__(256) void k_composite_backward(
+    const float* __restrict__ raw, const float* __restrict__ z, long long z_row_stride, const float* __restrict__ rays_d,
+    const float* __restrict__ noise, long long n_rays, int S, int white_bkgd, const float* __restrict__ g_rgb,
+    const float* __restrict__ g_disp, const float* __restrict__ g_acc, const float* __restrict__ g_depth,
+    const float* __restrict__ g_weights, float* __restrict__ d_raw, float* __restrict__ d_rays_d) {
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+    const float dnorm = __fsqrt_rn(dx * dx + dy * dy + dz * dz);
+    const float* zr = z + ray * z_row_stride;
+    const f32x4* rr = (const f32x4*)(raw + ray * (long long)S * 4);
+
+    float zv[SPL + 1], alpha[SPL], sig[SPL], dlt[SPL], cr[SPL], cg[SPL], cb[SPL];
+    const int s0 = lane * SPL;
+#pragma unroll
+    for (int t = 0; t <= SPL; ++t) zv[t] = (s0 + t < S) ? zr[s0 + t] : 0.f;
+    float run = 1.0f;
+#pragma unroll
+    for (int t = 0; t < SPL; ++t) {
+        const int s = s0 + t;
+        if (s < S) {
+            const f32x4 v = rr[s];
+            dlt[t] = (s + 1 < S) ? (zv[t + 1] - zv[t]) : 1e10f;
+            float sg = v.w;
+            if (noise) sg = sg + noise[ray * (long long)S + s];
+            sig[t] = sg;                                   // pre-ReLU (sign decides the gate)
+            alpha[t] = 1.0f - expf(-fmaxf(sg, 0.f) * (dlt[t] * dnorm));
+            cr[t] = 1.0f / (1.0f + expf(-v.x)), cg[t] = 1.0f / (1.0f + expf(-v.y)), cb[t] = 1.0f / (1.0f + expf(-v.z));
+            run = run * ((1.0f - alpha[t]) + 1e-10f);
+        } else {
+            alpha[t] = 0.f, sig[t] = 0.f, dlt[t] = 0.f, cr[t] = cg[t] = cb[t] = 0.f;
+        }
+    }
+    float incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl = incl * up;
+    }
+    float T0 = __shfl_up(incl, 1, 64);
+    if (lane == 0) T0 = 1.0f;
+
+    // forward sums needed by the disp gradient
+    float T = T0, sd = 0.f, sa = 0.f;
+    float w[SPL], Tt[SPL];
+#pragma unroll
+    for (int t = 0; t < SPL; ++t) {
+        Tt[t] = T;
+        w[t] = alpha[t] * T;
+        if (s0 + t < S) sd += w[t] * zv[t], sa += w[t];
+        T = T * ((1.0f - alpha[t]) + 1e-10f);
+    }
+    sd = wave_sum(sd), sa = wave_sum(sa);
+    const float gr = g_rgb[ray * 3], gg = g_rgb[ray * 3 + 1], gb = g_rgb[ray * 3 + 2];
+    float gdepth = g_depth ? g_depth[ray] : 0.f, gacc = g_acc ? g_acc[ray] : 0.f;
+    const float gdisp = g_disp ? g_disp[ray] : 0.f;
+    if (gdisp != 0.f) {                                     // disp = acc/depth where depth/acc > 1e-10
+        const float q = __fdiv_rn(sd, sa);
+        if (q > 1e-10f) gdepth += gdisp * (-sa / (sd * sd)), gacc += gdisp * (1.0f / sd);
+        else if (q != q) gdepth += q, gacc += q;             // NaN propagates like autograd through 0/0
+    }
+    if (white_bkgd) gacc -= gr + gg + gb;                    // rgb += 1 - acc
+
+    // G_i and the suffix sums of G_i w_i
+    float G[SPL], local = 0.f;
+#pragma unroll
+    for (int t = 0; t < SPL; ++t) {
+        const int s = s0 + t;
+        G[t] = (s < S) ? ((g_weights ? g_weights[ray * (long long)S + s] : 0.f) + gr * cr[t] + gg * cg[t] + gb * cb[t] +
+                          gdepth * zv[t] + gacc)
+                       : 0.f;
+        local += G[t] * w[t];
+    }
+    float suf = local;                                      // inclusive suffix sum over lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float dn = __shfl_down(suf, o, 64);
+        if (lane + o < 64) suf += dn;
+    }
+    float after = __shfl_down(suf, 1, 64);                  // sum over lanes > this one
+    if (lane == 63) after = 0.f;
+
+    float dn_acc = 0.f;                                     // d L / d |rays_d|
+#pragma unroll
+    for (int t = SPL - 1; t >= 0; --t) {
+        const int s = s0 + t;
+        if (s < S) {
+            const float one_m = (1.0f - alpha[t]) + 1e-10f;
+            const float dalpha = G[t] * Tt[t] - after / one_m;
+            const float dist = dlt[t] * dnorm;
+            const float keep = 1.0f - alpha[t];             // exp(-sigma dist)
+            const float dsig = sig[t] > 0.f ? dalpha * dist * keep : 0.f;
+            const float ddist = dalpha * fmaxf(sig[t], 0.f) * keep;
+            dn_acc += ddist * dlt[t];
+            f32x4 o;
+            o.x = w[t] * gr * cr[t] * (1.0f - cr[t]);
+            o.y = w[t] * gg * cg[t] * (1.0f - cg[t]);
+            o.z = w[t] * gb * cb[t] * (1.0f - cb[t]);
+            o.w = dsig;
+            *(f32x4*)(d_raw + (ray * (long long)S + s) * 4) = o;
+            after += G[t] * w[t];
+        }
+    }
+    dn_acc = wave_sum(dn_acc);
+    if (lane == 0 && d_rays_d) {
+        const float inv = dnorm > 0.f ? 1.0f / dnorm : 0.f;
+        d_rays_d[ray * 3] = dn_acc * dx * inv, d_rays_d[ray * 3 + 1] = dn_acc * dy * inv, d_rays_d[ray * 3 + 2] = dn_acc * dz * inv;
+    }
+}
+
+// ---- head bias gradient: out[c] = sum_m d_raw[m][off + c]  (single block; 4 floats per point) ------------------
+__global__ __launch_bounds__(256) void k_raw_colsum(const float* __restrict__ d_raw, long long n_points, int off, int n,
+                                                    float* __restrict__ out) {
+    __shared__ float red[256][4];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long long m = threadIdx.x; m < n_points; m += 256)
+        for (int c = 0; c < n; ++c) acc[c] += d_raw[m * 4 + off + c];
+    for (int c = 0; c < 4; ++c) red[threadIdx.x][c] = acc[c];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s)
+            for (int c = 0; c < 4; ++c) red[threadIdx.x][c] += red[threadIdx.x + s][c];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) out[threadIdx.x] = threadIdx.x < n ? red[0][threadIdx.x] : 0.f;
+}
+
+inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+}  // namespace mofa
+
+using namespace mofa;
+
+extern "C" {
+
+int mofa_head_backward(const float* d_raw, int32_t raw_off, int32_t n_out, const float* w_dense, int32_t k_padded,
+                       const float* mask, int32_t accumulate, float* dx, int64_t m_padded, int64_t n_points,
+                       void* stream) {
+    MOFA_REQUIRE(d_raw && w_dense && dx, "head_backward: null pointer");
+    MOFA_REQUIRE(k_padded % 16 == 0 && n_out >= 1 && raw_off >= 0 && raw_off + n_out <= 4 && n_points <= m_padded,
+                 "head_backward: bad shape");
+    hipLaunchKernelGGL(k_head_backward, dim3(blocks_for(m_padded * (k_padded / 4), 256)), dim3(256), 0,
+                       (hipStream_t)stream, d_raw, raw_off, n_out, w_dense, k_padded, mask, accumulate, dx,
+                       (long long)m_padded, (long long)n_points);
+    return check_launch("k_head_backward");
+}
+
+int mofa_internal_raw_colsum(const float* d_raw, long long n_points, int off, int n, float* out, void* stream) {
+    hipLaunchKernelGGL(k_raw_colsum, dim3(1), dim3(256), 0, (hipStream_t)stream, d_raw, n_points, off, n, out);
+    return check_launch("k_raw_colsum");
+}
+
+int mofa_bias_grad(const float* g, int64_t m_padded, int64_t n_points, int32_t n_padded, float* out, void* stream) {
+    MOFA_REQUIRE(g && out && n_padded % 16 == 0 && n_points <= m_padded, "bias_grad: bad arguments");
+    hipLaunchKernelGGL(k_colsum, dim3(n_padded / 16), dim3(256), 0, (hipStream_t)stream, g, (long long)m_padded,
+                       (long long)n_points, out);
+    return check_launch("k_colsum");
+}
+
+int mofa_bias_grad_rays(const float* g, int64_t m_padded, int64_t n_rays, int32_t S, int32_t n_padded, float* out,
+                        void* stream) {
+    MOFA_REQUIRE(g && out && n_padded % 16 == 0 && n_rays * S <= m_padded, "bias_grad_rays: bad arguments");
+    hipLaunchKernelGGL(k_colsum_rays, dim3(blocks_for(n_rays * (n_padded / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                       g, (long long)m_padded, (long long)n_rays, S, n_padded, out);
+    return check_launch("k_colsum_rays");
+}
+
+int mofa_pe_backward(const float* dpe, int64_t m_padded, const float* rays_o, const float* rays_d, const float* z,
+                     int64_t z_row_stride, int64_t n_rays, int32_t S, float* d_rays_o, float* d_rays_d, void* stream) {
+    MOFA_REQUIRE(dpe && rays_o && rays_d && z && d_rays_o && d_rays_d && n_rays * S <= m_padded,
+                 "pe_backward: bad arguments");
+    hipLaunchKernelGGL(k_pe_backward, dim3(blocks_for(n_rays, kWavesPerBlock)), dim3(256), 0, (hipStream_t)stream, dpe,
+                       (long long)m_padded, rays_o, rays_d, z, (long long)z_row_stride, (long long)n_rays, S, d_rays_o,
+                       d_rays_d);
+    return check_launch("k_pe_backward");
+}
+
+int mofa_composite_backward(const float* raw, const float* z, int64_t z_row_stride, const float* rays_d,
+                            const float* noise, int64_t n_rays, int32_t S, int32_t white_bkgd, const float* g_rgb,
+                            const float* g_disp, const float* g_acc, const float* g_depth, const float* g_weights,
+                            float* d_raw, float* d_rays_d, void* stream) {
+    MOFA_REQUIRE(raw && z && rays_d && g_rgb && d_raw, "composite_backward: null pointer");
+    MOFA_REQUIRE(n_rays > 0 && S >= 2 && S <= 256, "composite_backward: need 2 <= S <= 256 (got %d)", S);
+    const dim3 grid(blocks_for(n_rays, kWavesPerBlock)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define MOFA_CB(SPL)                                                                                                \
+    hipLaunchKernelGGL((k_composite_backward<SPL>), grid, block, 0, st, raw, z, (long long)z_row_stride, rays_d, noise, \
+                       (long long)n_rays, S, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_weights, d_raw, d_rays_d)
+    if (S <= 64) MOFA_CB(1);
+    else if (S <= 128) MOFA_CB(2);
+    else MOFA_CB(4);
+#undef MOFA_CB
+    return check_launch("k_composite_backward");
+}
+
+}  // extern "C"

@@ -33,6 +33,8 @@ struct LayerArgs {
     const float* w;       // packed weights, panels [(k1p+k2p)][n_padded][16]
     const float* bias;    // [bias_rows][n_padded]
     float* y;             // panels [n_padded/16][m_padded][16]
+    const float* mask;    // backward epilogue: saved forward activation with y's geometry; y *= (mask > 0)
+    int accumulate;       // backward epilogue: y = (y_old + acc) [* mask]
     // layer-0 (positional encoding prologue) inputs
     const float* rays_o;
     const float* rays_d;
@@ -95,7 +97,9 @@ __device__ __forceinline__ void mma_panel(const float* __restrict__ Xt, const fl
 
 // BN: feature-tile height; L0: X tile is generated (positional encoding) instead of loaded;
 // GLDS: stage operands with LDS-DMA (true) or through registers (false; kept as the A/B arm).
-template <int BN, bool L0, bool GLDS>
+// BWD: backward-data epilogue (no bias/ReLU; optional accumulate into y and ReLU mask from the saved activation):
+//      dX[m][k] = sum_n G[m][n] * W[n][k]  is the same GEMM with the transposed weight pack as "Wp".
+template <int BN, bool L0, bool GLDS, bool BWD = false>
 __global__ __launch_bounds__(256, 2) void k_layer(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BM = kRowTile;
@@ -209,8 +213,38 @@ __global__ __launch_bounds__(256, 2) void k_layer(const LayerArgs a) {
         __syncthreads();
     }
 
-    // epilogue: bias + ReLU, one 16-B store per accumulator quad into the next layer's panels
     const int lr = lane & 31, g = lane >> 5;
+    if constexpr (BWD) {
+        // backward-data epilogue: (acc [+ y_old]) [* (saved activation > 0)]
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const long long m = m0 + wm * (32 * NJ) + 32 * j + lr;
+            const int msw = (int)(m >> 2) & 3;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + 32 * i + 8 * q + 4 * g;
+                    const long long off = (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2);
+                    f32x4 v;
+                    v.x = acc[i][j][4 * q + 0], v.y = acc[i][j][4 * q + 1], v.z = acc[i][j][4 * q + 2],
+                    v.w = acc[i][j][4 * q + 3];
+                    if (a.accumulate) {
+                        const f32x4 o = *(const f32x4*)(a.y + off);
+                        v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+                    }
+                    if (a.mask) {
+                        const f32x4 k = *(const f32x4*)(a.mask + off);
+                        v.x = k.x > 0.f ? v.x : 0.f, v.y = k.y > 0.f ? v.y : 0.f, v.z = k.z > 0.f ? v.z : 0.f,
+                        v.w = k.w > 0.f ? v.w : 0.f;
+                    }
+                    *(f32x4*)(a.y + off) = v;
+                }
+            }
+        }
+        return;
+    }
+    // epilogue: bias + ReLU, one 16-B store per accumulator quad into the next layer's panels
     f32x4 bv[NI][4];
     if (!a.bias_row_div) {  // one bias row for every point: fetch it once
 #pragma unroll
@@ -340,6 +374,21 @@ __global__ __launch_bounds__(256) void k_pack_panels(const float* __restrict__ w
     dst[(long long)panel0 * rows_padded * 16 + idx] = v;
 }
 
+// transposed pack for the backward-data GEMM: dst rows = forward INPUT features (k), contraction = forward outputs (n):
+//   dst(row = k, kk = n) = w[n, col0 + k]
+__global__ __launch_bounds__(256) void k_pack_panels_t(const float* __restrict__ w, int n_out, int ld, int col0,
+                                                       int ncols, float* __restrict__ dst, int rows_padded,
+                                                       int k_padded) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)rows_padded * k_padded;
+    if (idx >= total) return;
+    const int e = idx & 3, p = (idx >> 2) & 3;
+    const long long rowpanel = idx >> 4;
+    const int row = (int)(rowpanel % rows_padded), panel = (int)(rowpanel / rows_padded);
+    const int n = panel * 16 + ((p ^ ((row >> 2) & 3)) << 2) + e;
+    dst[idx] = (row < ncols && n < n_out) ? w[(long long)n * ld + col0 + row] : 0.f;
+}
+
 __global__ __launch_bounds__(256) void k_to_panels(const float* __restrict__ x, long long rows, int k_in,
                                                    float* __restrict__ dst, long long rows_padded, int k_padded) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -394,7 +443,7 @@ struct ProfState {
 };
 ProfState g_prof;
 
-template <int BN, bool L0>
+template <int BN, bool L0, bool BWD = false>
 int launch_layer(LayerArgs a, hipStream_t st) {
     a.n_tiles = a.n_padded / BN;
     const long long mt = a.m_padded / kRowTile;
@@ -403,7 +452,7 @@ int launch_layer(LayerArgs a, hipStream_t st) {
     a.total_tiles = (int)total;
     const unsigned grid = (unsigned)round_up(total, 8);
     const size_t lds = 2 * (size_t)(kRowTile + BN) * 16 * sizeof(float);
-    const bool prof = g_prof.on && BN == 128 && !L0;
+    const bool prof = g_prof.on && BN == 128 && !L0 && !BWD;
     if (prof) {
         if (g_prof.used == g_prof.ev.size()) {
             hipEvent_t e0, e1;
@@ -412,7 +461,9 @@ int launch_layer(LayerArgs a, hipStream_t st) {
         }
         (void)hipEventRecord(g_prof.ev[g_prof.used].first, st);
     }
-    if (stage_mode())
+    if constexpr (BWD)
+        hipLaunchKernelGGL((k_layer<BN, false, true, true>), dim3(grid), dim3(256), lds, st, a);
+    else if (stage_mode())
         hipLaunchKernelGGL((k_layer<BN, L0, true>), dim3(grid), dim3(256), lds, st, a);
     else
         hipLaunchKernelGGL((k_layer<BN, L0, false>), dim3(grid), dim3(256), lds, st, a);
@@ -421,7 +472,15 @@ int launch_layer(LayerArgs a, hipStream_t st) {
         g_prof.used++;
         g_prof.flops += 2.0 * (double)a.m_padded * (double)a.n_padded * 16.0 * (double)(a.k1p + a.k2p);
     }
-    return check_launch(L0 ? "k_layer<L0>" : "k_layer");
+    return check_launch(BWD ? "k_layer<BWD>" : (L0 ? "k_layer<L0>" : "k_layer"));
+}
+
+int dispatch_layer_bwd(LayerArgs a, hipStream_t st) {
+    MOFA_REQUIRE(a.m_padded > 0 && a.m_padded % kRowTile == 0, "m_padded=%lld must be a positive multiple of %d",
+                 a.m_padded, kRowTile);
+    MOFA_REQUIRE(a.n_padded > 0 && a.n_padded % 64 == 0, "n_padded=%d must be a positive multiple of 64", a.n_padded);
+    if (a.n_padded % 128 == 0) return launch_layer<128, false, true>(a, st);
+    return launch_layer<64, false, true>(a, st);
 }
 
 int dispatch_layer(LayerArgs a, bool l0, hipStream_t st) {
@@ -482,6 +541,30 @@ int mofa_layer_forward(const float* x1, int32_t k1, const float* x2, int32_t k2,
     a.k1p = k1 / 16, a.k2p = k2 / 16, a.n_padded = n_padded, a.m_padded = m_padded;
     a.bias_row_div = bias_row_div, a.bias_rows = bias_rows, a.relu = relu;
     return dispatch_layer(a, false, (hipStream_t)stream);
+}
+
+/* dX = G @ W (optionally += and * ReLU mask): g panels [n_padded_fwd/16][Mp][16], wt_packed = transposed pack
+ * (rows = forward input features padded to k_out_padded, contraction = g_k), dx panels [k_out_padded/16][Mp][16]. */
+int mofa_layer_backward_data(const float* g, int32_t g_k, const float* wt_packed, const float* mask, int32_t accumulate,
+                             float* dx, int64_t m_padded, int32_t k_out_padded, void* stream) {
+    MOFA_REQUIRE(g && wt_packed && dx, "layer_backward_data: null pointer");
+    MOFA_REQUIRE(g_k > 0 && g_k % 16 == 0, "layer_backward_data: g_k=%d must be a positive multiple of 16", g_k);
+    LayerArgs a{};
+    a.x1 = g, a.w = wt_packed, a.y = dx, a.mask = mask, a.accumulate = accumulate;
+    a.k1p = g_k / 16, a.k2p = 0, a.n_padded = k_out_padded, a.m_padded = m_padded;
+    return dispatch_layer_bwd(a, (hipStream_t)stream);
+}
+
+int mofa_pack_panels_t(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, float* dst,
+                       int32_t rows_padded, int32_t k_padded, void* stream) {
+    MOFA_REQUIRE(w && dst, "pack_panels_t: null pointer");
+    MOFA_REQUIRE(rows_padded >= ncols && k_padded % 16 == 0 && k_padded >= n_out && col0 >= 0 && col0 + ncols <= ld,
+                 "pack_panels_t: bad shape n_out=%d ld=%d col0=%d ncols=%d rows_padded=%d k_padded=%d", n_out, ld, col0,
+                 ncols, rows_padded, k_padded);
+    const long long total = (long long)rows_padded * k_padded;
+    hipLaunchKernelGGL(k_pack_panels_t, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, w, n_out, ld, col0,
+                       ncols, dst, rows_padded, k_padded);
+    return check_launch("k_pack_panels_t");
 }
 
 int mofa_layer0_forward(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <utility>
 #include <vector>
 
 #include "mofa_common.h"
@@ -13,6 +14,18 @@ int mofa_internal_fold_bias(const float* w, int n_out, int ld, int col0, int nco
                             const float* bias, float* out, int n_padded, void* stream);
 int mofa_internal_dense_rows(const float* w, int n_out, int ld, int col0, int ncols, float* dst, int k_padded,
                              void* stream);
+int mofa_internal_raw_colsum(const float* d_raw, long long n_points, int off, int n, float* out, void* stream);
+int mofa_layer_backward_data(const float* g, int32_t g_k, const float* wt_packed, const float* mask, int32_t accumulate,
+                             float* dx, int64_t m_padded, int32_t k_out_padded, void* stream);
+int mofa_pack_panels_t(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, float* dst,
+                       int32_t rows_padded, int32_t k_padded, void* stream);
+int mofa_head_backward(const float* d_raw, int32_t raw_off, int32_t n_out, const float* w_dense, int32_t k_padded,
+                       const float* mask, int32_t accumulate, float* dx, int64_t m_padded, int64_t n_points, void* stream);
+int mofa_bias_grad(const float* g, int64_t m_padded, int64_t n_points, int32_t n_padded, float* out, void* stream);
+int mofa_bias_grad_rays(const float* g, int64_t m_padded, int64_t n_rays, int32_t S, int32_t n_padded, float* out,
+                        void* stream);
+int mofa_pe_backward(const float* dpe, int64_t m_padded, const float* rays_o, const float* rays_d, const float* z,
+                     int64_t z_row_stride, int64_t n_rays, int32_t S, float* d_rays_o, float* d_rays_d, void* stream);
 }
 
 namespace mofa {
@@ -48,12 +61,14 @@ struct Layer {
     int n_padded, k_padded[2];
     bool head;            // dense head (alpha / rgb) instead of an MFMA layer
     size_t packed_off, folded_off;
+    size_t packed_t_off[2];   // transposed packs for the backward-data GEMMs (one per source part)
+    size_t tape_cols;         // sum of n_padded of the MFMA layers before this one (tape slot = Mp * tape_cols)
 };
 
 struct Plan {
     int D, W, Wp, Hp;
     std::vector<Layer> L;
-    size_t packed_floats = 0, folded_floats = 0;
+    size_t packed_floats = 0, folded_floats = 0, packed_t_floats = 0, tape_cols = 0;
     // indices into L
     int xyz0, bim0, bim_skip, uv0, uv_skip, view, alpha, rgb;
 };
@@ -115,6 +130,15 @@ Plan make_plan(MofaNetShape s) {
         p.packed_floats += l.head ? (size_t)l.n_out * kp : (size_t)l.n_padded * kp;
         p.packed_floats = (size_t)round_up((int64_t)p.packed_floats, 64);
         p.folded_floats += (l.fold == kView) ? 0 : (size_t)l.n_padded;
+        l.tape_cols = p.tape_cols;
+        l.packed_t_off[0] = l.packed_t_off[1] = 0;
+        if (!l.head) {
+            p.tape_cols += (size_t)l.n_padded;
+            for (int part = 0; part < l.nsrc; ++part) {
+                l.packed_t_off[part] = p.packed_t_floats;
+                p.packed_t_floats += (size_t)l.k_padded[part] * (size_t)l.n_padded;
+            }
+        }
     }
     return p;
 }
@@ -183,76 +207,213 @@ int mofa_net_fold(MofaNetShape s, const float* const* weights, const float* cons
     return MOFA_OK;
 }
 
+size_t mofa_net_packed_t_floats(MofaNetShape s) { return shape_ok(s) ? make_plan(s).packed_t_floats : 0; }
+
+size_t mofa_net_tape_floats(MofaNetShape s, int64_t n_points) {
+    if (!shape_ok(s) || n_points <= 0) return 0;
+    return (size_t)round_up(n_points, kRowTile) * make_plan(s).tape_cols;
+}
+
+size_t mofa_net_backward_workspace_floats(MofaNetShape s, int64_t n_points) {
+    if (!shape_ok(s) || n_points <= 0) return 0;
+    const Plan p = make_plan(s);
+    return (size_t)round_up(n_points, kRowTile) * (4 * (size_t)p.Wp + 64) + 64;
+}
+
+int mofa_net_pack_t(MofaNetShape s, const float* const* weights, float* packed_t, void* stream) {
+    MOFA_REQUIRE(shape_ok(s), "net_pack_t: unsupported shape D=%d W=%d", s.D, s.W);
+    MOFA_REQUIRE(weights && packed_t, "net_pack_t: null pointer");
+    const Plan p = make_plan(s);
+    for (size_t li = 0; li < p.L.size(); ++li) {
+        const Layer& l = p.L[li];
+        if (l.head) continue;
+        MOFA_REQUIRE(weights[li], "net_pack_t: weights[%zu] is null", li);
+        for (int part = 0; part < l.nsrc; ++part) {
+            const int rc = mofa_pack_panels_t(weights[li], l.n_out, l.ld, l.col0[part], l.ncols[part],
+                                              packed_t + l.packed_t_off[part], l.k_padded[part], l.n_padded, stream);
+            if (rc != MOFA_OK) return rc;
+        }
+    }
+    return MOFA_OK;
+}
+
+#define MOFA_TRY(expr) \
+    if ((rc = (expr)) != MOFA_OK) return rc
+
 int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, const float* view_w,
                      const float* view_b, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
                      const float* pts, const float* viewdirs, int64_t n_rays, int32_t S, float* workspace,
-                     float* raw_out, void* stream) {
+                     float* raw_out, float* tape, const float* view_bias_rows, void* stream) {
     MOFA_REQUIRE(shape_ok(s), "net_forward: unsupported shape D=%d W=%d", s.D, s.W);
-    MOFA_REQUIRE(packed && folded && view_w && view_b && viewdirs && workspace && raw_out, "net_forward: null pointer");
+    MOFA_REQUIRE(packed && folded && workspace && raw_out, "net_forward: null pointer");
+    MOFA_REQUIRE(view_bias_rows || (view_w && view_b && viewdirs),
+                 "net_forward: need view_bias_rows or (view_w, view_b, viewdirs)");
     MOFA_REQUIRE(n_rays > 0 && S > 0, "net_forward: n_rays=%lld S=%d", (long long)n_rays, S);
     MOFA_REQUIRE(pts || (rays_o && rays_d && z), "net_forward: need pts or (rays_o, rays_d, z)");
     const Plan p = make_plan(s);
     const int64_t M = n_rays * S, Mp = round_up(M, kRowTile);
     const size_t act = (size_t)Mp * p.Wp;
-    float* bufA = workspace;            // xyz_code, later reused
-    float* bufB = workspace + act;      // sigmaCodes
+    float* bufA = workspace;             // xyz_code, later rgbCodes
+    float* bufB = workspace + act;       // sigmaCodes
     float* t0 = workspace + 2 * act;
     float* t1 = workspace + 3 * act;
     float* vbias = workspace + 4 * act;  // [n_rays, Hp]
-
+    // with a tape every layer output is kept (fitting / training); otherwise 4 buffers are recycled
+    auto slot = [&](int li, float* fallback) -> float* {
+        return tape ? tape + (size_t)Mp * p.L[li].tape_cols : fallback;
+    };
     auto run = [&](int li, const float* x1, const float* x2, float* y) -> int {
         const Layer& l = p.L[li];
         return mofa_layer_forward(x1, l.k_padded[0], x2, x2 ? l.k_padded[1] : 0, packed + l.packed_off,
                                   folded + l.folded_off, 0, 1, y, Mp, l.n_padded, 1, stream);
     };
     int rc;
-#define MOFA_TRY(expr) \
-    if ((rc = (expr)) != MOFA_OK) return rc
     // xyzEncode
+    float* xyz;
     {
         const Layer& l = p.L[p.xyz0];
+        float* y0 = slot(p.xyz0, t0);
         MOFA_TRY(mofa_layer0_forward(rays_o, rays_d, z, z_row_stride, pts, M, S, packed + l.packed_off,
-                                     folded + l.folded_off, t0, Mp, l.n_padded, stream));
-        MOFA_TRY(run(p.xyz0 + 1, t0, nullptr, t1));
-        MOFA_TRY(run(p.xyz0 + 2, t1, nullptr, t0));
-        MOFA_TRY(run(p.xyz0 + 3, t0, nullptr, bufA));
+                                     folded + l.folded_off, y0, Mp, l.n_padded, stream));
+        float* y1 = slot(p.xyz0 + 1, t1);
+        MOFA_TRY(run(p.xyz0 + 1, y0, nullptr, y1));
+        float* y2 = slot(p.xyz0 + 2, t0);
+        MOFA_TRY(run(p.xyz0 + 2, y1, nullptr, y2));
+        xyz = slot(p.xyz0 + 3, bufA);
+        MOFA_TRY(run(p.xyz0 + 3, y2, nullptr, xyz));
     }
     // one conditioned skipMLP: x -> linears1 (5 layers) -> [x | h] -> linears2 (D-5 layers) -> out
-    auto cond = [&](int first, int skip, const float* x, float* out, float* pa, float* pb) -> int {
+    auto cond = [&](int first, int skip, const float* x, float* out_fb, float* pa, float* pb, float** out) -> int {
         const float* cur = x;
         float* pp[2] = {pa, pb};
         int w = 0;
         for (int li = first; li < skip; ++li) {
-            MOFA_TRY(run(li, cur, nullptr, pp[w]));
-            cur = pp[w], w ^= 1;
+            float* y = slot(li, pp[w]);
+            MOFA_TRY(run(li, cur, nullptr, y));
+            cur = y, w ^= 1;
         }
         const int last = skip + (s.D - 5) - 1;
         for (int li = skip; li <= last; ++li) {
-            float* y = (li == last) ? out : pp[w];
+            float* y = slot(li, (li == last) ? out_fb : pp[w]);
             MOFA_TRY(run(li, li == skip ? x : cur, li == skip ? cur : nullptr, y));
             cur = y, w ^= 1;
         }
+        *out = const_cast<float*>(cur);
         return MOFA_OK;
     };
-    MOFA_TRY(cond(p.bim0, p.bim_skip, bufA, bufB, t0, t1));
+    float *sigma = nullptr, *rgbc = nullptr;
+    MOFA_TRY(cond(p.bim0, p.bim_skip, xyz, bufB, t0, t1, &sigma));
     {
         const Layer& l = p.L[p.alpha];
-        MOFA_TRY(mofa_head_forward(bufB, l.k_padded[0], Mp, packed + l.packed_off, folded + l.folded_off, 1, raw_out,
+        MOFA_TRY(mofa_head_forward(sigma, l.k_padded[0], Mp, packed + l.packed_off, folded + l.folded_off, 1, raw_out,
                                    3, M, stream));
     }
-    MOFA_TRY(cond(p.uv0, p.uv_skip, bufB, bufA, t0, t1));  // rgbCodes -> bufA (xyz_code is dead by now)
+    MOFA_TRY(cond(p.uv0, p.uv_skip, sigma, bufA, t0, t1, &rgbc));  // without a tape rgbCodes reuses xyz_code's buffer
     {
         const Layer& l = p.L[p.view];
-        // per-ray bias b + W[:, :27] @ PE(viewdir) from the ORIGINAL (unpacked) view-layer tensors
-        MOFA_TRY(mofa_view_bias(viewdirs, n_rays, view_w, l.n_out, l.ld, view_b, vbias, l.n_padded, stream));
-        MOFA_TRY(mofa_layer_forward(bufA, l.k_padded[0], nullptr, 0, packed + l.packed_off, vbias, S, n_rays, t0, Mp,
-                                    l.n_padded, 1, stream));
+        if (!view_bias_rows) {
+            // per-ray bias b + W[:, :27] @ PE(viewdir) from the ORIGINAL (unpacked) view-layer tensors
+            MOFA_TRY(mofa_view_bias(viewdirs, n_rays, view_w, l.n_out, l.ld, view_b, vbias, l.n_padded, stream));
+            view_bias_rows = vbias;
+        }
+        float* v = slot(p.view, t0);
+        MOFA_TRY(mofa_layer_forward(rgbc, l.k_padded[0], nullptr, 0, packed + l.packed_off, view_bias_rows, S, n_rays, v,
+                                    Mp, l.n_padded, 1, stream));
         const Layer& r = p.L[p.rgb];
-        MOFA_TRY(mofa_head_forward(t0, r.k_padded[0], Mp, packed + r.packed_off, folded + r.folded_off, 3, raw_out, 0,
+        MOFA_TRY(mofa_head_forward(v, r.k_padded[0], Mp, packed + r.packed_off, folded + r.folded_off, 3, raw_out, 0,
                                    M, stream));
     }
-#undef MOFA_TRY
     return MOFA_OK;
 }
+
+int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t, const float* tape,
+                      const float* d_raw, const float* rays_o, const float* rays_d, const float* z,
+                      int64_t z_row_stride, int64_t n_rays, int32_t S, float* workspace, float* d_folded,
+                      float* d_view_bias_rows, float* d_rays_o, float* d_rays_d, void* stream) {
+    MOFA_REQUIRE(shape_ok(s), "net_backward: unsupported shape D=%d W=%d", s.D, s.W);
+    MOFA_REQUIRE(packed && packed_t && tape && d_raw && rays_o && rays_d && z && workspace && d_folded &&
+                     d_view_bias_rows && d_rays_o && d_rays_d,
+                 "net_backward: null pointer");
+    MOFA_REQUIRE(n_rays > 0 && S > 0, "net_backward: n_rays=%lld S=%d", (long long)n_rays, S);
+    const Plan p = make_plan(s);
+    const int64_t M = n_rays * S, Mp = round_up(M, kRowTile);
+    const size_t act = (size_t)Mp * p.Wp;
+    float* g0 = workspace;
+    float* g1 = workspace + act;
+    float* gS = workspace + 2 * act;   // accumulates d sigmaCodes
+    float* gX = workspace + 3 * act;   // accumulates d xyz_code
+    float* dpe = workspace + 4 * act;  // [Mp, 64]
+    auto T = [&](int li) -> const float* { return tape + (size_t)Mp * p.L[li].tape_cols; };
+    int rc;
+    // bias gradient of layer li from its masked output gradient g
+    auto bgrad = [&](int li, const float* g) -> int {
+        return mofa_bias_grad(g, Mp, M, p.L[li].n_padded, d_folded + p.L[li].folded_off, stream);
+    };
+    // dX = G @ W[:, part]
+    auto bdata = [&](int li, int part, const float* g, const float* mask, int accumulate, float* dx) -> int {
+        const Layer& l = p.L[li];
+        return mofa_layer_backward_data(g, l.n_padded, packed_t + l.packed_t_off[part], mask, accumulate, dx, Mp,
+                                        l.k_padded[part], stream);
+    };
+    const int n2 = s.D - 5;
+    // heads' bias gradients
+    MOFA_TRY(mofa_internal_raw_colsum(d_raw, M, 3, 1, d_folded + p.L[p.alpha].folded_off, stream));
+    MOFA_TRY(mofa_internal_raw_colsum(d_raw, M, 0, 3, d_folded + p.L[p.rgb].folded_off, stream));
+    // rgb head -> gradient at the view layer's output (masked by its ReLU); its per-ray sums are d(view bias rows)
+    {
+        const Layer& r = p.L[p.rgb];
+        MOFA_TRY(mofa_head_backward(d_raw, 0, 3, packed + r.packed_off, r.k_padded[0], T(p.view), 0, g0, Mp, M, stream));
+        MOFA_TRY(mofa_bias_grad_rays(g0, Mp, n_rays, S, p.L[p.view].n_padded, d_view_bias_rows, stream));
+    }
+    // view layer -> d rgbCodes, masked by the last uv layer's ReLU
+    MOFA_TRY(bdata(p.view, 0, g0, T(p.uv_skip + n2 - 1), 0, g1));
+    float *cur = g1, *spare = g0;
+    // One conditioned stack, walked backwards.  `cur` = masked gradient at its output.  The gradient w.r.t. the stack's
+    // input x has two contributions (the skip concat and linears1.Linear0): the first overwrites gx, the second
+    // accumulates and applies `final_mask` (the ReLU of the layer that produced x) if given.
+    auto stack_bwd = [&](int first, int skip, float* gx, const float* final_mask) -> int {
+        const int last = skip + n2 - 1;
+        for (int li = last; li > skip; --li) {
+            MOFA_TRY(bgrad(li, cur));
+            MOFA_TRY(bdata(li, 0, cur, T(li - 1), 0, spare));
+            std::swap(cur, spare);
+        }
+        MOFA_TRY(bgrad(skip, cur));
+        MOFA_TRY(bdata(skip, 0, cur, nullptr, 0, gx));               // x part of [x | h]
+        MOFA_TRY(bdata(skip, 1, cur, T(skip - 1), 0, spare));        // h part, masked by linears1's last ReLU
+        std::swap(cur, spare);
+        for (int li = skip - 1; li > first; --li) {
+            MOFA_TRY(bgrad(li, cur));
+            MOFA_TRY(bdata(li, 0, cur, T(li - 1), 0, spare));
+            std::swap(cur, spare);
+        }
+        MOFA_TRY(bgrad(first, cur));
+        MOFA_TRY(bdata(first, 0, cur, final_mask, 1, gx));
+        return MOFA_OK;
+    };
+    // uv stack (input sigmaCodes); the sigma head adds the third contribution and applies the bim stack's last ReLU
+    MOFA_TRY(stack_bwd(p.uv0, p.uv_skip, gS, nullptr));
+    {
+        const Layer& a = p.L[p.alpha];
+        MOFA_TRY(mofa_head_backward(d_raw, 3, 1, packed + a.packed_off, a.k_padded[0], T(p.bim_skip + n2 - 1), 1, gS, Mp,
+                                    M, stream));
+    }
+    // bim stack (input xyz_code)
+    cur = gS, spare = g0;
+    MOFA_TRY(stack_bwd(p.bim0, p.bim_skip, gX, T(p.xyz0 + 3)));
+    // xyzEncode Linear3..1, then Linear0 -> gradient w.r.t. the encoding features -> rays
+    cur = gX, spare = g0;
+    for (int li = p.xyz0 + 3; li > p.xyz0; --li) {
+        MOFA_TRY(bgrad(li, cur));
+        MOFA_TRY(bdata(li, 0, cur, T(li - 1), 0, spare));
+        std::swap(cur, spare);
+        if (spare == gX) spare = g1;
+    }
+    MOFA_TRY(bgrad(p.xyz0, cur));
+    MOFA_TRY(bdata(p.xyz0, 0, cur, nullptr, 0, dpe));
+    MOFA_TRY(mofa_pe_backward(dpe, Mp, rays_o, rays_d, z, z_row_stride, n_rays, S, d_rays_o, d_rays_d, stream));
+    return MOFA_OK;
+}
+#undef MOFA_TRY
 
 }  // extern "C"

@@ -33,6 +33,9 @@ class HipNet:
         self._packed_key = None
         self._folded: Optional[torch.Tensor] = None
         self._ws: Optional[torch.Tensor] = None
+        self._packed_t: Optional[torch.Tensor] = None
+        self._packed_t_key = None
+        self._bws: Optional[torch.Tensor] = None
 
     # -- weights -----------------------------------------------------------------------------------
     def _weights(self):
@@ -58,6 +61,25 @@ class HipNet:
                       "mofa_net_pack")
             self._packed_key = key
         return self._packed
+
+    def packed_t(self) -> torch.Tensor:
+        """Transposed weight panels for the backward-data GEMMs (re-packed when a parameter changed)."""
+        key = self._key()
+        if self._packed_t is None or key != self._packed_t_key:
+            ws, _ = self._weights()
+            n = self._L.mofa_net_packed_t_floats(self.shape)
+            if self._packed_t is None or self._packed_t.numel() != n or self._packed_t.device != ws[0].device:
+                self._packed_t = torch.empty(n, dtype=torch.float32, device=ws[0].device)
+            lib.check(self._L.mofa_net_pack_t(self.shape, lib.ptr_array(ws), lib.ptr(self._packed_t), lib.stream()),
+                      "mofa_net_pack_t")
+            self._packed_t_key = key
+        return self._packed_t
+
+    def backward_workspace(self, n_points: int, device) -> torch.Tensor:
+        n = self._L.mofa_net_backward_workspace_floats(self.shape, n_points)
+        if self._bws is None or self._bws.numel() < n or self._bws.device != device:
+            self._bws = torch.empty(n, dtype=torch.float32, device=device)
+        return self._bws
 
     def fold(self, exp_code: torch.Tensor, shape_code: torch.Tensor, tex_code: torch.Tensor) -> torch.Tensor:
         """Per-call folded biases from the (already modulated) expression code [30], shape code [50] and
@@ -93,7 +115,7 @@ class HipNet:
                                            lib.ptr(view.weight.detach().contiguous()),
                                            lib.ptr(view.bias.detach().contiguous()), lib.ptr(rays_o), lib.ptr(rays_d),
                                            lib.ptr(z), z_row_stride, None, lib.ptr(viewdirs), R, S, lib.ptr(ws),
-                                           lib.ptr(raw_out), lib.stream()), "mofa_net_forward")
+                                           lib.ptr(raw_out), None, None, lib.stream()), "mofa_net_forward")
         return raw_out
 
     def forward_points(self, pts, viewdirs, S: int, raw_out: torch.Tensor, folded: Optional[torch.Tensor] = None):
@@ -105,6 +127,6 @@ class HipNet:
                                            lib.ptr(folded if folded is not None else self._folded),
                                            lib.ptr(view.weight.detach().contiguous()),
                                            lib.ptr(view.bias.detach().contiguous()), None, None, None, 0, lib.ptr(pts),
-                                           lib.ptr(viewdirs), R, S, lib.ptr(ws), lib.ptr(raw_out), lib.stream()),
-                  "mofa_net_forward")
+                                           lib.ptr(viewdirs), R, S, lib.ptr(ws), lib.ptr(raw_out), None, None,
+                                           lib.stream()), "mofa_net_forward")
         return raw_out

@@ -34,7 +34,21 @@ SIGNATURES = {
     "mofa_net_pack": (C.c_int, [NetShape, C.POINTER(_fp), _fp, _fp]),
     "mofa_net_fold": (C.c_int, [NetShape, C.POINTER(_fp), C.POINTER(_fp), _fp, _fp, _fp, _fp, _fp]),
     "mofa_net_forward": (C.c_int, [NetShape, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _fp, _fp, _i64, _i32, _fp, _fp,
-                                   _fp]),
+                                   _fp, _fp, _fp]),
+    "mofa_net_packed_t_floats": (_sz, [NetShape]),
+    "mofa_net_tape_floats": (_sz, [NetShape, _i64]),
+    "mofa_net_backward_workspace_floats": (_sz, [NetShape, _i64]),
+    "mofa_net_pack_t": (C.c_int, [NetShape, C.POINTER(_fp), _fp, _fp]),
+    "mofa_net_backward": (C.c_int, [NetShape, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _i64, _i32, _fp, _fp, _fp, _fp,
+                                    _fp, _fp]),
+    "mofa_pack_panels_t": (C.c_int, [_fp, _i32, _i32, _i32, _i32, _fp, _i32, _i32, _fp]),
+    "mofa_layer_backward_data": (C.c_int, [_fp, _i32, _fp, _fp, _i32, _fp, _i64, _i32, _fp]),
+    "mofa_head_backward": (C.c_int, [_fp, _i32, _i32, _fp, _i32, _fp, _i32, _fp, _i64, _i64, _fp]),
+    "mofa_bias_grad": (C.c_int, [_fp, _i64, _i64, _i32, _fp, _fp]),
+    "mofa_bias_grad_rays": (C.c_int, [_fp, _i64, _i64, _i32, _i32, _fp, _fp]),
+    "mofa_pe_backward": (C.c_int, [_fp, _i64, _fp, _fp, _fp, _i64, _i64, _i32, _fp, _fp, _fp]),
+    "mofa_composite_backward": (C.c_int, [_fp, _fp, _i64, _fp, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
+                                          _fp]),
     "mofa_panel_floats": (_sz, [_i64, _i32]),
     "mofa_pack_panels": (C.c_int, [_fp, _i32, _i32, _i32, _i32, _fp, _i32, _i32, _i32, _fp]),
     "mofa_to_panels": (C.c_int, [_fp, _i64, _i32, _fp, _i64, _fp]),

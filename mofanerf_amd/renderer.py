@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import lib
+from .autograd import CompositeFn, NetFn, fold_torch, view_bias_torch
 from .hipnet import HipNet, unwrap
 from .model import EnDeUVmap, StyleModule
 
@@ -123,12 +124,15 @@ class Renderer(torch.nn.Module):
         return self._cache[k]
 
     def _fold_codes(self, net, tex_code):
-        """Per-call conditioning: e = scale*sigma[expType] + bias (render_class.py:75-82) and the folded biases."""
+        """Per-call conditioning: e = scale*sigma[expType] + bias (render_class.py:75-82) and the folded biases.
+        With autograd enabled the (tiny, per-call) fold is a differentiable torch expression so that gradients reach the
+        codes; otherwise it is the HIP kernel."""
         style = unwrap(self.idSpecificMod)
-        with torch.no_grad():
-            row = self.shapeCodes[0, :].reshape(1, -1).float().to(self._device())
-            scale, bias = style(row)
-            e = scale * self.expCodes_Sigma[self.expType].to(row.device) + bias
+        row = self.shapeCodes[0, :].reshape(1, -1).float().to(self._device())
+        scale, bias = style(row)
+        e = scale * self.expCodes_Sigma[self.expType].to(row.device) + bias
+        if torch.is_grad_enabled():
+            return fold_torch(self._hip(net), e, row, tex_code.to(row.device).float())
         return self._hip(net).fold(e, row, tex_code.to(row.device))
 
     # ------------------------------------------------------------------------------------------------
@@ -204,7 +208,12 @@ class Renderer(torch.nn.Module):
                 return torch.Tensor(np.random.rand(R, n_s) * raw_noise_std).to(dev).contiguous()
             return (torch.randn(R, n_s, device=dev) * raw_noise_std).contiguous()
 
+        grad = torch.is_grad_enabled()
+
         def composite(raw, zv, zs, n_s, noise):
+            if grad:
+                rgb, disp, acc, depth, weights = CompositeFn.apply(raw, zv, zs, rays_d, noise, bool(white_bkgd))
+                return {"rgb": rgb, "disp": disp, "acc": acc, "depth": depth, "weights": weights}
             o = {k: torch.empty(R, *sh, dtype=torch.float32, device=dev)
                  for k, sh in (("rgb", (3,)), ("disp", ()), ("acc", ()), ("depth", ()), ("weights", (n_s,)))}
             lib.check(L.mofa_composite_forward(lib.ptr(raw), lib.ptr(zv), zs, lib.ptr(rays_d), lib.ptr(noise), R, n_s,
@@ -215,8 +224,14 @@ class Renderer(torch.nn.Module):
 
         def network(net, folded, zv, zs, n_s):
             h = self._hip(net)
-            raw = torch.empty(R, n_s, 4, dtype=torch.float32, device=dev)
             rays_per = max(1, int(self.netchunk) // n_s)
+            if grad:     # tape-keeping forward per sub-batch; the per-ray view bias is a differentiable torch expression
+                vb = view_bias_torch(h, vd)
+                parts = [NetFn.apply(h, rays_o[i:i + rays_per], rays_d[i:i + rays_per],
+                                     zv[i:i + rays_per] if zs else zv, zs, n_s, folded, vb[i:i + rays_per])
+                         for i in range(0, R, rays_per)]
+                return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+            raw = torch.empty(R, n_s, 4, dtype=torch.float32, device=dev)
             for i in range(0, R, rays_per):
                 j = min(R, i + rays_per)
                 h.forward_rays(rays_o[i:j], rays_d[i:j], zv[i:j] if zs else zv, zs, vd[i:j], n_s, raw[i:j], folded)
@@ -238,7 +253,8 @@ class Renderer(torch.nn.Module):
             z_samples = torch.empty(R, Ni, dtype=torch.float32, device=dev)
             z_fine = torch.empty(R, S + Ni, dtype=torch.float32, device=dev)
             z_std = torch.empty(R, dtype=torch.float32, device=dev)
-            lib.check(L.mofa_sample_pdf_merge(lib.ptr(z), z_stride, lib.ptr(c["weights"]), lib.ptr(u), u_stride, R, S,
+            # z_samples are detached in the reference (render_class.py:326): no gradient through the resampling
+            lib.check(L.mofa_sample_pdf_merge(lib.ptr(z), z_stride, lib.ptr(c["weights"].detach()), lib.ptr(u), u_stride, R, S,
                                               Ni, lib.ptr(z_samples), lib.ptr(z_fine), lib.ptr(z_std), st),
                       "mofa_sample_pdf_merge")
             fine = network_fn if network_fine is None else network_fine
@@ -281,8 +297,8 @@ class Renderer(torch.nn.Module):
         else:
             rays_o, rays_d = rays[0], rays[1]
             sh = tuple(rays_d.shape)
-            rays_o = rays_o.detach().reshape(-1, 3).float().to(dev)
-            rays_d = rays_d.detach().reshape(-1, 3).float().to(dev)
+            rays_o = rays_o.reshape(-1, 3).float().to(dev)       # may carry gradients to the camera pose (run_fit.py:281)
+            rays_d = rays_d.reshape(-1, 3).float().to(dev)
             viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
         if c2w_staticcam is not None:      # visualise the effect of viewdirs only (render_class.py:161-163)
             rays_o, rays_d, _ = gen(c2w_staticcam)
@@ -297,11 +313,12 @@ class Renderer(torch.nn.Module):
         ones = torch.ones_like(rays_d[..., :1])
         self.rays = torch.cat([rays_o, rays_d, near * ones, far * ones, viewdirs], -1)
         self.decoding_texCodes = tex_code
-        with torch.no_grad():
-            self._folded_coarse = self._fold_codes(kwargs["network_fn"], tex_code).clone()
-            fine = kwargs.get("network_fine")
-            self._folded_fine = self._fold_codes(fine, tex_code).clone() if fine is not None else None
-            all_ret = self.batchify_rays(chunk, **kwargs)
+        # inference (torch.no_grad(), as the reference's render-only call sites run): pure HIP, nothing recorded;
+        # with autograd enabled (fitting / training) the tape-keeping forward + HIP backward path is used
+        self._folded_coarse = self._fold_codes(kwargs["network_fn"], tex_code).clone()
+        fine = kwargs.get("network_fine")
+        self._folded_fine = self._fold_codes(fine, tex_code).clone() if fine is not None else None
+        all_ret = self.batchify_rays(chunk, **kwargs)
         for k in all_ret:
             all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
         ret_list = [all_ret[k] for k in _OUT_KEYS]

@@ -101,9 +101,10 @@ def render_pair(H, K, angle, arch, chunk, netchunk, device="cuda", seed=0, n_ray
     if n_rays is not None:
         ro, rd = ro[:n_rays].contiguous(), rd[:n_rays].contiguous()
     rays = torch.stack([ro, rd], 0).to(device)
-    rgb, disp, acc, ex = render.render_fitting(H, H, K, chunk=chunk, rays=rays, shapeCodes=bm.to(device),
-                                               uvCodes=tex.to(device), expType=20, expCodes=exp.to(device),
-                                               verbose=True, **kw)
+    with torch.no_grad():
+        rgb, disp, acc, ex = render.render_fitting(H, H, K, chunk=chunk, rays=rays, shapeCodes=bm.to(device),
+                                                   uvCodes=tex.to(device), expType=20, expCodes=exp.to(device),
+                                                   verbose=True, **kw)
     torch.cuda.synchronize()
     hip = to_np(dict(rgb=rgb, disp=disp, acc=acc, rgb0=ex["rgb0"], disp0=ex["disp0"], acc0=ex["acc0"], z_std=ex["z_std"],
                      z_samples=ex["_z_samples"], z_fine=ex["_z_fine"], weights_coarse=ex["_weights0"]))

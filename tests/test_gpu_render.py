@@ -20,9 +20,10 @@ def _fit(g, **over):
     kw = dict(kw)
     kw.update(over)
     H = int(g["H"])
-    out = render.render_fitting(H, H, g["K"], chunk=int(g["chunk"]), c2w=T(g["c2w"]), shapeCodes=T(g["bm"]).to(DEV),
-                                uvCodes=T(g["tex"]).to(DEV), expType=20, expCodes=T(g["exp"]).to(DEV), retraw=True,
-                                verbose=True, **kw)
+    with torch.no_grad():
+        out = render.render_fitting(H, H, g["K"], chunk=int(g["chunk"]), c2w=T(g["c2w"]), shapeCodes=T(g["bm"]).to(DEV),
+                                    uvCodes=T(g["tex"]).to(DEV), expType=20, expCodes=T(g["exp"]).to(DEV), retraw=True,
+                                    verbose=True, **kw)
     torch.cuda.synchronize()
     return out
 
@@ -101,7 +102,8 @@ def _teacher_forced(g, tol=1e-4):
     R = H * H
     outs = {}
     for tag, net, S in (("coarse", kw["network_fn"], 64), ("fine", kw["network_fine"], 128)):
-        folded = render._fold_codes(net, T(g["tex"]).to(DEV))
+        with torch.no_grad():
+            folded = render._fold_codes(net, T(g["tex"]).to(DEV))
         z = T(g[f"z_{tag}"]).contiguous().to(DEV)
         raw = torch.empty(R, S, 4, device=DEV)
         render._hip(net).forward_rays(ro, rd, z, S, vd, S, raw, folded)
@@ -141,7 +143,8 @@ def test_run_network_api():
     vd = torch.nn.functional.normalize(T(rng.normal(size=(19, 3)).astype(np.float32)), dim=-1)
     bm, tex, exp = synth.codes(0)
     render.shapeCodes, render.expType, render.decoding_texCodes = bm.to(DEV), 3, tex.to(DEV)
-    raw = kw["network_query_fn"](pts.to(DEV), vd.to(DEV), kw["network_fine"])
+    with torch.no_grad():
+        raw = kw["network_query_fn"](pts.to(DEV), vd.to(DEV), kw["network_fine"])
     ref = o.run_network(pts, vd, o.fine, bm, tex, 3)
     nan_equal_close(raw.cpu().numpy(), ref.numpy(), 2e-5, 1e-5)
 
@@ -158,8 +161,9 @@ def test_chunk_and_netchunk_invariance_shipped_sizes():
         from oracle import mofa_oracle as orc
         ro, rd = orc.get_rays(32, 32, K, orc.pose_spherical(-60.0, 0.0, 16.0)[:3, :4])
         rays = torch.stack([ro.reshape(-1, 3)[:300], rd.reshape(-1, 3)[:300]], 0).to(DEV)
-        rgb, disp, acc, ex = render.render_fitting(32, 32, K, chunk=chunk, rays=rays, shapeCodes=bm.to(DEV),
-                                                   uvCodes=tex.to(DEV), expType=20, expCodes=exp.to(DEV), **kw)
+        with torch.no_grad():
+            rgb, disp, acc, ex = render.render_fitting(32, 32, K, chunk=chunk, rays=rays, shapeCodes=bm.to(DEV),
+                                                       uvCodes=tex.to(DEV), expType=20, expCodes=exp.to(DEV), **kw)
         outs.append(to_np(dict(rgb=rgb, acc=acc, rgb0=ex["rgb0"], z_std=ex["z_std"])))
     for o in outs[1:]:
         for k in o:
@@ -178,6 +182,6 @@ def test_cpu_tensors_fail_loudly():
     from mofanerf_amd import lib
     render, kw, _ = make_product((8, 64, 10, 64), 0, 4096, "cpu")
     bm, tex, exp = synth.codes(0)
-    with pytest.raises(lib.MofaError):
+    with pytest.raises(lib.MofaError), torch.no_grad():
         render.render_fitting(8, 8, synth.intrinsics(8, 8), chunk=64, c2w=torch.eye(4)[:3], shapeCodes=bm, uvCodes=tex,
                               expType=20, expCodes=exp, **kw)

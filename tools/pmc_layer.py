@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Launch the dominant kernel a few times at the shipped fine-network shape (M=196608 points, K=N=1024) so that
+rocprofv3 --pmc can attribute counters to individual dispatches."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mofanerf_amd import lib
+L = lib.load()
+M, K, N = 196608, 1024, 1024
+x = torch.randn(M * K, device="cuda"); w = torch.randn(N * K, device="cuda") * 0.03
+b = torch.randn(N, device="cuda"); y = torch.empty(M * N, device="cuda")
+for _ in range(4):
+    lib.check(L.mofa_layer_forward(lib.ptr(x), K, None, 0, lib.ptr(w), lib.ptr(b), 0, 1, lib.ptr(y), M, N, 1, lib.stream()), "layer")
+torch.cuda.synchronize()
+print("done")
