@@ -109,7 +109,18 @@ int mofa_net_pack_t(MofaNetShape s, const float* const* weights, float* packed_t
 int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t, const float* tape,
                       const float* d_raw, const float* rays_o, const float* rays_d, const float* z,
                       int64_t z_row_stride, int64_t n_rays, int32_t S, float* workspace, float* d_folded,
-                      float* d_view_bias_rows, float* d_rays_o, float* d_rays_d, void* stream);
+                      float* d_view_bias_rows, float* d_rays_o, float* d_rays_d, float* const* d_weights, void* stream);
+/* d_weights: NULL (fitting: only codes/pose are optimised), or 2D+7 pointers to [out,in] gradient tensors in state-dict
+ * order: the per-point column blocks are OVERWRITTEN with dW = G^T X (fp32 MFMA, contraction over the points, split over
+ * M with a deterministic second-stage sum); the per-call-constant columns are left untouched (host autograd owns them). */
+size_t mofa_weight_grad_workspace_floats(int64_t n_points, int32_t n_padded, int32_t k_padded);
+int mofa_weight_grad(const float* g, int32_t n_padded, const float* x, int32_t k_padded, int64_t m_padded,
+                     int64_t n_points, int32_t n_out, int32_t ncols, float* dst, int32_t ld, int32_t col0,
+                     float* workspace, void* stream);
+int mofa_head_weight_grad(const float* d_raw, int32_t raw_off, int32_t n_out, const float* x, int32_t k_padded,
+                          int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, void* stream);
+int mofa_pe_panels(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride, int64_t n_points,
+                   int32_t S, int64_t m_padded, float* out, void* stream);
 /* pieces of mofa_net_backward (unit-testable) */
 int mofa_pack_panels_t(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, float* dst,
                        int32_t rows_padded, int32_t k_padded, void* stream);

@@ -66,7 +66,10 @@ class NetFn(torch.autograd.Function):
     """raw[R,S,4] = NeRF(PE(o + d z), folded biases, per-ray view bias) with a HIP backward."""
 
     @staticmethod
-    def forward(ctx, h: HipNet, rays_o, rays_d, z, z_row_stride: int, S: int, folded, vbias):
+    def forward(ctx, h: HipNet, rays_o, rays_d, z, z_row_stride: int, S: int, folded, vbias, *weights):
+        """``weights``: empty (fitting: no weight gradients), or the 2D+7 weight tensors in state-dict order — then the
+        backward also returns dW for their per-point column blocks (the constant columns get theirs through the folded
+        biases / view-bias rows, i.e. through ordinary torch autograd)."""
         L = h._L
         R = rays_o.shape[0]
         dev = rays_o.device
@@ -82,6 +85,7 @@ class NetFn(torch.autograd.Function):
         ctx.h, ctx.S, ctx.z_row_stride = h, S, z_row_stride
         ctx.save_for_backward(ro, rd, zc, tape)
         ctx.n_folded, ctx.vb_shape = fo.numel(), tuple(vb.shape)
+        ctx.w_shapes = [tuple(w.shape) for w in weights]
         return raw
 
     @staticmethod
@@ -95,11 +99,12 @@ class NetFn(torch.autograd.Function):
         d_vb = torch.empty(ctx.vb_shape, dtype=torch.float32, device=dev)
         d_o, d_d = torch.empty_like(ro), torch.empty_like(rd)
         ws = h.backward_workspace(R * S, dev)
+        dws = [torch.zeros(sh, dtype=torch.float32, device=dev) for sh in ctx.w_shapes]
         lib.check(L.mofa_net_backward(h.shape, lib.ptr(h.packed()), lib.ptr(h.packed_t()), lib.ptr(tape), lib.ptr(d_raw),
                                       lib.ptr(ro), lib.ptr(rd), lib.ptr(zc), ctx.z_row_stride, R, S, lib.ptr(ws),
-                                      lib.ptr(d_folded), lib.ptr(d_vb), lib.ptr(d_o), lib.ptr(d_d), lib.stream()),
-                  "mofa_net_backward")
-        return None, d_o, d_d, None, None, None, d_folded, d_vb
+                                      lib.ptr(d_folded), lib.ptr(d_vb), lib.ptr(d_o), lib.ptr(d_d),
+                                      lib.ptr_array(dws) if dws else None, lib.stream()), "mofa_net_backward")
+        return (None, d_o, d_d, None, None, None, d_folded, d_vb, *dws)
 
 
 class CompositeFn(torch.autograd.Function):

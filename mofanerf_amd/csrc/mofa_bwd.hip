@@ -347,3 +347,267 @@ int mofa_composite_backward(const float* raw, const float* z, int64_t z_row_stri
 }
 
 }  // extern "C"
+
+// ======================================================================================================
+// Weight gradient  dW[n][k] = sum_m G[m][n] * X[m][k]   (training, run_train.py:349) on fp32 MFMA.
+// The contraction runs over POINTS, so both operands are read "down the rows" of their panels: a lane (i = l&31,
+// g = l>>5) feeds A = G[m0+g][n0+i] and B = X[m0+g][k0+i] as single dwords (fp32 MFMA operands are one VGPR, so no
+// packing constraint).  Work is split over M: grid = tiles(n) x tiles(k) x splits; each workgroup reduces its slice
+// of points into a [TN x TK] partial, a second kernel sums the partials (deterministic, no atomics).
+// ======================================================================================================
+namespace mofa {
+namespace {
+
+__device__ __forceinline__ void glds16b(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+constexpr int kWgMC = 32;  // points per pipeline stage
+
+template <int TN, int TK>
+__global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ g, const float* __restrict__ x,
+                                                  long long m_padded, long long n_points, int n_padded, int k_padded,
+                                                  int chunks_per_split, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int MC = kWgMC;
+    constexpr int PSTR = MC * 16 + 16;              // LDS stride between 16-feature panels (+16: bank spread)
+    constexpr int GP = TN / 16, XP = TK / 16;       // panels per stage
+    constexpr int STAGE = (GP + XP) * PSTR;
+    constexpr int NI = TN / 64, NJ = TK / 64;       // 2 x 2 waves, wave tile (TN/2) x (TK/2)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wk = wave >> 1;
+    const int n_tiles = n_padded / TN;
+    const int nt = blockIdx.x % n_tiles, kt = blockIdx.x / n_tiles;
+    const int split = blockIdx.y;
+    const int n0 = nt * TN, k0 = kt * TK;
+    const long long total_chunks = (n_points + MC - 1) / MC;
+    const long long c_begin = (long long)split * chunks_per_split;
+    long long c_end = c_begin + chunks_per_split;
+    if (c_end > total_chunks) c_end = total_chunks;
+
+    f32x16 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // one stage = GP + XP panel pieces of MC rows x 64 B = 2 KiB each = 2 wave-instructions of 1 KiB
+    auto stage = [&](int buf, long long chunk) {
+        float* base = smem + buf * STAGE;
+        const long long m0 = chunk * MC;
+        constexpr int PIECES = (GP + XP) * 2;       // 1 KiB pieces
+        for (int pc = wave; pc < PIECES; pc += 4) {
+            const int panel = pc >> 1, half = pc & 1;
+            const float* src = (panel < GP)
+                                   ? g + ((long long)(n0 / 16 + panel) * m_padded + m0 + half * 16) * 16
+                                   : x + ((long long)(k0 / 16 + panel - GP) * m_padded + m0 + half * 16) * 16;
+            glds16b(src + lane * 4, base + panel * PSTR + half * 256);
+        }
+    };
+
+    const int li = lane & 31, gsel = lane >> 5;
+    if (c_begin < c_end) {
+        stage(0, c_begin);
+        __syncthreads();
+        for (long long c = c_begin; c < c_end; ++c) {
+            const int cur = (int)((c - c_begin) & 1);
+            if (c + 1 < c_end) stage(cur ^ 1, c + 1);
+            const float* gs = smem + cur * STAGE;
+            const float* xs = gs + GP * PSTR;
+            const long long m0 = c * MC;
+#pragma unroll 4
+            for (int mp = 0; mp < MC / 2; ++mp) {
+                const int ml = 2 * mp + gsel;                         // this lane's point within the chunk
+                const bool live = (m0 + ml) < n_points;               // rows beyond the batch contribute nothing
+                const int sw = (ml >> 2) & 3;                         // m0 is a multiple of 32: same swizzle as global
+                float a[NI], b[NJ];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int nl = wn * (TN / 2) + 32 * i + li;       // feature within the tile
+                    const float v = gs[(nl >> 4) * PSTR + ml * 16 + ((((nl >> 2) & 3) ^ sw) << 2) + (nl & 3)];
+                    a[i] = live ? v : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int kl = wk * (TK / 2) + 32 * j + li;
+                    b[j] = xs[(kl >> 4) * PSTR + ml * 16 + ((((kl >> 2) & 3) ^ sw) << 2) + (kl & 3)];
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+    // partial[split][n][k], row-major [n_padded][k_padded]
+    float* out = partial + (long long)split * n_padded * k_padded;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * (TN / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * gsel;
+                const int k = k0 + wk * (TK / 2) + 32 * j + li;
+                out[(long long)n * k_padded + k] = acc[i][j][r];
+            }
+}
+
+// dst[n][col0 + k] = sum_s partial[s][n][k]   for n < n_out, k < ncols  (natural PyTorch [out, in] gradient layout)
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int splits, int n_padded,
+                                                      int k_padded, int n_out, int ncols, float* __restrict__ dst,
+                                                      int ld, int col0) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)n_out * ncols) return;
+    const int n = (int)(idx / ncols), k = (int)(idx - (long long)n * ncols);
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += partial[((long long)sp * n_padded + n) * k_padded + k];
+    dst[(long long)n * ld + col0 + k] = s;
+}
+
+// head weight gradient: dst[o][k] = sum_m d_raw[m][off+o] * X[m][k]; one block per 16-feature panel of X
+__global__ __launch_bounds__(256) void k_head_wgrad(const float* __restrict__ d_raw, int raw_off, int n_out,
+                                                    const float* __restrict__ x, long long m_padded,
+                                                    long long n_points, int ncols, float* __restrict__ dst, int ld) {
+    __shared__ float red[256][17];
+    const int panel = blockIdx.x;
+    const float* base = x + (long long)panel * m_padded * 16;
+    for (int o = 0; o < n_out; ++o) {
+        float acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+        for (long long m = threadIdx.x; m < n_points; m += 256) {
+            const float gw = d_raw[m * 4 + raw_off + o];
+            const int sw = (int)(m >> 2) & 3;
+            const f32x4* row = (const f32x4*)(base + m * 16);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 v = row[c ^ sw];
+                acc[4 * c + 0] += gw * v.x, acc[4 * c + 1] += gw * v.y, acc[4 * c + 2] += gw * v.z, acc[4 * c + 3] += gw * v.w;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) red[threadIdx.x][c] = acc[c];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) red[threadIdx.x][c] += red[threadIdx.x + s][c];
+            __syncthreads();
+        }
+        if (threadIdx.x < 16 && panel * 16 + (int)threadIdx.x < ncols)
+            dst[(long long)o * ld + panel * 16 + threadIdx.x] = red[0][threadIdx.x];
+    }
+}
+
+// positional-encoding features of every point as panels [4][m_padded][16] (the X operand of layer 0's weight gradient)
+__global__ __launch_bounds__(256) void k_pe_panels(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                   const float* __restrict__ z, long long z_row_stride, long long n_points,
+                                                   int S, long long m_padded, float* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over m_padded * 64
+    if (idx >= m_padded * 64) return;
+    const int e = idx & 3, p = (idx >> 2) & 3;
+    const long long rowpanel = idx >> 4;
+    const long long m = rowpanel % m_padded;
+    const int panel = (int)(rowpanel / m_padded);
+    const int k = panel * 16 + ((p ^ ((int)(m >> 2) & 3)) << 2) + e;
+    float v = 0.f;
+    if (m < n_points && k < 3 + 6 * MOFA_PE_POINT_FREQS) {
+        const long long r = m / S;
+        const int s = (int)(m - r * S);
+        const float zz = z[r * z_row_stride + s];
+        const int d = k < 3 ? k : ((k - 3) % 6) % 3;
+        const float xd = __fadd_rn(rays_o[r * 3 + d], __fmul_rn(rays_d[r * 3 + d], zz));
+        if (k < 3) v = xd;
+        else {
+            const int j = k - 3, f = j / 6, rr = j - 6 * f;
+            const float arg = xd * (float)(1 << f);
+            v = rr < 3 ? sinf(arg) : cosf(arg);
+        }
+    }
+    out[idx] = v;
+}
+
+template <int TN, int TK>
+int launch_wgrad(const float* g, const float* x, long long m_padded, long long n_points, int n_padded, int k_padded,
+                 int splits, int chunks_per_split, float* partial, hipStream_t st) {
+    constexpr int PSTR = kWgMC * 16 + 16;
+    const size_t lds = 2 * (size_t)(TN / 16 + TK / 16) * PSTR * sizeof(float);
+    const dim3 grid((n_padded / TN) * (k_padded / TK), splits);
+    hipLaunchKernelGGL((k_wgrad<TN, TK>), grid, dim3(256), lds, st, g, x, m_padded, n_points, n_padded, k_padded,
+                       chunks_per_split, partial);
+    return check_launch("k_wgrad");
+}
+
+}  // namespace
+}  // namespace mofa
+
+extern "C" {
+
+/* partial-sum workspace (floats) needed by mofa_weight_grad for a [n_padded x k_padded] block over n_points */
+size_t mofa_weight_grad_workspace_floats(int64_t n_points, int32_t n_padded, int32_t k_padded) {
+    if (n_points <= 0 || n_padded <= 0 || k_padded <= 0) return 0;
+    const int tn = n_padded % 128 == 0 ? 128 : 64, tk = k_padded % 128 == 0 ? 128 : 64;
+    const long long tiles = (long long)(n_padded / tn) * (k_padded / tk);
+    const long long chunks = (n_points + mofa::kWgMC - 1) / mofa::kWgMC;
+    long long splits = (1024 + tiles - 1) / tiles;
+    if (splits > chunks) splits = chunks;
+    if (splits < 1) splits = 1;
+    return (size_t)splits * n_padded * k_padded;
+}
+
+/* dst[n][col0 + k] = sum_m G[m][n] X[m][k]  (n < n_out, k < ncols); G panels [n_padded/16][Mp][16] (ReLU-masked output
+ * gradient), X panels [k_padded/16][Mp][16] (the layer's input), dst row-major with leading dimension ld. */
+int mofa_weight_grad(const float* g, int32_t n_padded, const float* x, int32_t k_padded, int64_t m_padded,
+                     int64_t n_points, int32_t n_out, int32_t ncols, float* dst, int32_t ld, int32_t col0,
+                     float* workspace, void* stream) {
+    MOFA_REQUIRE(g && x && dst && workspace, "weight_grad: null pointer");
+    MOFA_REQUIRE(n_padded % 64 == 0 && k_padded % 64 == 0 && n_out <= n_padded && ncols <= k_padded && n_points > 0 &&
+                     n_points <= m_padded && m_padded % 256 == 0 && col0 >= 0 && col0 + ncols <= ld,
+                 "weight_grad: bad shape n_padded=%d k_padded=%d n_out=%d ncols=%d", n_padded, k_padded, n_out, ncols);
+    const int tn = n_padded % 128 == 0 ? 128 : 64, tk = k_padded % 128 == 0 ? 128 : 64;
+    const long long tiles = (long long)(n_padded / tn) * (k_padded / tk);
+    const long long chunks = (n_points + kWgMC - 1) / kWgMC;
+    long long splits = (1024 + tiles - 1) / tiles;
+    if (splits > chunks) splits = chunks;
+    if (splits < 1) splits = 1;
+    const int cps = (int)((chunks + splits - 1) / splits);
+    splits = (chunks + cps - 1) / cps;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (tn == 128 && tk == 128) rc = launch_wgrad<128, 128>(g, x, m_padded, n_points, n_padded, k_padded, (int)splits, cps, workspace, st);
+    else if (tn == 128) rc = launch_wgrad<128, 64>(g, x, m_padded, n_points, n_padded, k_padded, (int)splits, cps, workspace, st);
+    else if (tk == 128) rc = launch_wgrad<64, 128>(g, x, m_padded, n_points, n_padded, k_padded, (int)splits, cps, workspace, st);
+    else rc = launch_wgrad<64, 64>(g, x, m_padded, n_points, n_padded, k_padded, (int)splits, cps, workspace, st);
+    if (rc != MOFA_OK) return rc;
+    const long long total = (long long)n_out * ncols;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace, (int)splits,
+                       n_padded, k_padded, n_out, ncols, dst, ld, col0);
+    return check_launch("k_wgrad_reduce");
+}
+
+int mofa_head_weight_grad(const float* d_raw, int32_t raw_off, int32_t n_out, const float* x, int32_t k_padded,
+                          int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, void* stream) {
+    MOFA_REQUIRE(d_raw && x && dst && k_padded % 16 == 0 && ncols <= k_padded && n_out >= 1 && raw_off + n_out <= 4,
+                 "head_weight_grad: bad arguments");
+    hipLaunchKernelGGL(k_head_wgrad, dim3(k_padded / 16), dim3(256), 0, (hipStream_t)stream, d_raw, raw_off, n_out, x,
+                       (long long)m_padded, (long long)n_points, ncols, dst, ld);
+    return check_launch("k_head_wgrad");
+}
+
+int mofa_pe_panels(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride, int64_t n_points,
+                   int32_t S, int64_t m_padded, float* out, void* stream) {
+    MOFA_REQUIRE(rays_o && rays_d && z && out && S > 0 && n_points <= m_padded, "pe_panels: bad arguments");
+    hipLaunchKernelGGL(k_pe_panels, dim3((unsigned)((m_padded * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       rays_o, rays_d, z, (long long)z_row_stride, (long long)n_points, S, (long long)m_padded, out);
+    return check_launch("k_pe_panels");
+}
+
+}  // extern "C"

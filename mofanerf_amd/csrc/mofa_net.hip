@@ -26,6 +26,14 @@ int mofa_bias_grad_rays(const float* g, int64_t m_padded, int64_t n_rays, int32_
                         void* stream);
 int mofa_pe_backward(const float* dpe, int64_t m_padded, const float* rays_o, const float* rays_d, const float* z,
                      int64_t z_row_stride, int64_t n_rays, int32_t S, float* d_rays_o, float* d_rays_d, void* stream);
+size_t mofa_weight_grad_workspace_floats(int64_t n_points, int32_t n_padded, int32_t k_padded);
+int mofa_weight_grad(const float* g, int32_t n_padded, const float* x, int32_t k_padded, int64_t m_padded,
+                     int64_t n_points, int32_t n_out, int32_t ncols, float* dst, int32_t ld, int32_t col0,
+                     float* workspace, void* stream);
+int mofa_head_weight_grad(const float* d_raw, int32_t raw_off, int32_t n_out, const float* x, int32_t k_padded,
+                          int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, void* stream);
+int mofa_pe_panels(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride, int64_t n_points,
+                   int32_t S, int64_t m_padded, float* out, void* stream);
 }
 
 namespace mofa {
@@ -217,7 +225,8 @@ size_t mofa_net_tape_floats(MofaNetShape s, int64_t n_points) {
 size_t mofa_net_backward_workspace_floats(MofaNetShape s, int64_t n_points) {
     if (!shape_ok(s) || n_points <= 0) return 0;
     const Plan p = make_plan(s);
-    return (size_t)round_up(n_points, kRowTile) * (4 * (size_t)p.Wp + 64) + 64;
+    return (size_t)round_up(n_points, kRowTile) * (4 * (size_t)p.Wp + 64) + 64 +
+           mofa_weight_grad_workspace_floats(n_points, p.Wp, p.Wp);     // split-M partials of the largest dW block
 }
 
 int mofa_net_pack_t(MofaNetShape s, const float* const* weights, float* packed_t, void* stream) {
@@ -329,7 +338,7 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
 int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t, const float* tape,
                       const float* d_raw, const float* rays_o, const float* rays_d, const float* z,
                       int64_t z_row_stride, int64_t n_rays, int32_t S, float* workspace, float* d_folded,
-                      float* d_view_bias_rows, float* d_rays_o, float* d_rays_d, void* stream) {
+                      float* d_view_bias_rows, float* d_rays_o, float* d_rays_d, float* const* d_weights, void* stream) {
     MOFA_REQUIRE(shape_ok(s), "net_backward: unsupported shape D=%d W=%d", s.D, s.W);
     MOFA_REQUIRE(packed && packed_t && tape && d_raw && rays_o && rays_d && z && workspace && d_folded &&
                      d_view_bias_rows && d_rays_o && d_rays_d,
@@ -343,8 +352,17 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
     float* gS = workspace + 2 * act;   // accumulates d sigmaCodes
     float* gX = workspace + 3 * act;   // accumulates d xyz_code
     float* dpe = workspace + 4 * act;  // [Mp, 64]
+    float* wws = dpe + (size_t)Mp * 64 + 64;  // split-M partial sums of the weight-gradient GEMM
     auto T = [&](int li) -> const float* { return tape + (size_t)Mp * p.L[li].tape_cols; };
     int rc;
+    // dW[li][:, col0[part] : +ncols[part]] = G^T X   (training only: d_weights != NULL; the constant columns are the host's)
+    auto wgrad = [&](int li, int part, const float* g, const float* x) -> int {
+        if (!d_weights) return MOFA_OK;
+        const Layer& l = p.L[li];
+        MOFA_REQUIRE(d_weights[li], "net_backward: d_weights[%d] is null", li);
+        return mofa_weight_grad(g, l.n_padded, x, l.k_padded[part], Mp, M, l.n_out, l.ncols[part], d_weights[li], l.ld,
+                                l.col0[part], wws, stream);
+    };
     // bias gradient of layer li from its masked output gradient g
     auto bgrad = [&](int li, const float* g) -> int {
         return mofa_bias_grad(g, Mp, M, p.L[li].n_padded, d_folded + p.L[li].folded_off, stream);
@@ -364,6 +382,14 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
         const Layer& r = p.L[p.rgb];
         MOFA_TRY(mofa_head_backward(d_raw, 0, 3, packed + r.packed_off, r.k_padded[0], T(p.view), 0, g0, Mp, M, stream));
         MOFA_TRY(mofa_bias_grad_rays(g0, Mp, n_rays, S, p.L[p.view].n_padded, d_view_bias_rows, stream));
+        if (d_weights) {
+            MOFA_REQUIRE(d_weights[p.rgb] && d_weights[p.alpha], "net_backward: head d_weights are null");
+            MOFA_TRY(mofa_head_weight_grad(d_raw, 0, 3, T(p.view), r.k_padded[0], Mp, M, r.ld, d_weights[p.rgb], r.ld, stream));
+            const Layer& a = p.L[p.alpha];
+            MOFA_TRY(mofa_head_weight_grad(d_raw, 3, 1, T(p.bim_skip + n2 - 1), a.k_padded[0], Mp, M, a.ld, d_weights[p.alpha],
+                                           a.ld, stream));
+        }
+        MOFA_TRY(wgrad(p.view, 0, g0, T(p.uv_skip + n2 - 1)));
     }
     // view layer -> d rgbCodes, masked by the last uv layer's ReLU
     MOFA_TRY(bdata(p.view, 0, g0, T(p.uv_skip + n2 - 1), 0, g1));
@@ -371,28 +397,33 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
     // One conditioned stack, walked backwards.  `cur` = masked gradient at its output.  The gradient w.r.t. the stack's
     // input x has two contributions (the skip concat and linears1.Linear0): the first overwrites gx, the second
     // accumulates and applies `final_mask` (the ReLU of the layer that produced x) if given.
-    auto stack_bwd = [&](int first, int skip, float* gx, const float* final_mask) -> int {
+    auto stack_bwd = [&](int first, int skip, const float* xin, float* gx, const float* final_mask) -> int {
         const int last = skip + n2 - 1;
         for (int li = last; li > skip; --li) {
             MOFA_TRY(bgrad(li, cur));
+            MOFA_TRY(wgrad(li, 0, cur, T(li - 1)));
             MOFA_TRY(bdata(li, 0, cur, T(li - 1), 0, spare));
             std::swap(cur, spare);
         }
         MOFA_TRY(bgrad(skip, cur));
+        MOFA_TRY(wgrad(skip, 0, cur, xin));
+        MOFA_TRY(wgrad(skip, 1, cur, T(skip - 1)));
         MOFA_TRY(bdata(skip, 0, cur, nullptr, 0, gx));               // x part of [x | h]
         MOFA_TRY(bdata(skip, 1, cur, T(skip - 1), 0, spare));        // h part, masked by linears1's last ReLU
         std::swap(cur, spare);
         for (int li = skip - 1; li > first; --li) {
             MOFA_TRY(bgrad(li, cur));
+            MOFA_TRY(wgrad(li, 0, cur, T(li - 1)));
             MOFA_TRY(bdata(li, 0, cur, T(li - 1), 0, spare));
             std::swap(cur, spare);
         }
         MOFA_TRY(bgrad(first, cur));
+        MOFA_TRY(wgrad(first, 0, cur, xin));
         MOFA_TRY(bdata(first, 0, cur, final_mask, 1, gx));
         return MOFA_OK;
     };
     // uv stack (input sigmaCodes); the sigma head adds the third contribution and applies the bim stack's last ReLU
-    MOFA_TRY(stack_bwd(p.uv0, p.uv_skip, gS, nullptr));
+    MOFA_TRY(stack_bwd(p.uv0, p.uv_skip, T(p.bim_skip + n2 - 1), gS, nullptr));
     {
         const Layer& a = p.L[p.alpha];
         MOFA_TRY(mofa_head_backward(d_raw, 3, 1, packed + a.packed_off, a.k_padded[0], T(p.bim_skip + n2 - 1), 1, gS, Mp,
@@ -400,16 +431,21 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
     }
     // bim stack (input xyz_code)
     cur = gS, spare = g0;
-    MOFA_TRY(stack_bwd(p.bim0, p.bim_skip, gX, T(p.xyz0 + 3)));
+    MOFA_TRY(stack_bwd(p.bim0, p.bim_skip, T(p.xyz0 + 3), gX, T(p.xyz0 + 3)));
     // xyzEncode Linear3..1, then Linear0 -> gradient w.r.t. the encoding features -> rays
     cur = gX, spare = g0;
     for (int li = p.xyz0 + 3; li > p.xyz0; --li) {
         MOFA_TRY(bgrad(li, cur));
+        MOFA_TRY(wgrad(li, 0, cur, T(li - 1)));
         MOFA_TRY(bdata(li, 0, cur, T(li - 1), 0, spare));
         std::swap(cur, spare);
         if (spare == gX) spare = g1;
     }
     MOFA_TRY(bgrad(p.xyz0, cur));
+    if (d_weights) {   // layer 0's input is the positional encoding itself: regenerate it as panels, then reuse the buffer
+        MOFA_TRY(mofa_pe_panels(rays_o, rays_d, z, z_row_stride, M, S, Mp, dpe, stream));
+        MOFA_TRY(wgrad(p.xyz0, 0, cur, dpe));
+    }
     MOFA_TRY(bdata(p.xyz0, 0, cur, nullptr, 0, dpe));
     MOFA_TRY(mofa_pe_backward(dpe, Mp, rays_o, rays_d, z, z_row_stride, n_rays, S, d_rays_o, d_rays_d, stream));
     return MOFA_OK;

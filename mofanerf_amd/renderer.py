@@ -76,6 +76,11 @@ class Renderer(torch.nn.Module):
             latent.requires_grad = True
         self._hipnets: Dict[int, HipNet] = {}
         self._L = None
+        # render() (training entry) back-propagates into the network weights; render_fitting() optimises only codes /
+        # pose / light, so by default it skips the weight-gradient GEMMs the reference computes and throws away
+        # (run_fit.py never steps the networks); set fit_weight_grads=True to populate weight.grad there too
+        self.fit_weight_grads = False
+        self._weight_grads = False
         self._cache: Dict[tuple, torch.Tensor] = {}
 
     # expCodes_Sigma is a plain list (not registered parameters, render_class.py:53-58): move it with the module
@@ -227,8 +232,9 @@ class Renderer(torch.nn.Module):
             rays_per = max(1, int(self.netchunk) // n_s)
             if grad:     # tape-keeping forward per sub-batch; the per-ray view bias is a differentiable torch expression
                 vb = view_bias_torch(h, vd)
+                wts = [l.weight for l in h._linears] if self._weight_grads else []
                 parts = [NetFn.apply(h, rays_o[i:i + rays_per], rays_d[i:i + rays_per],
-                                     zv[i:i + rays_per] if zs else zv, zs, n_s, folded, vb[i:i + rays_per])
+                                     zv[i:i + rays_per] if zs else zv, zs, n_s, folded, vb[i:i + rays_per], *wts)
                          for i in range(0, R, rays_per)]
                 return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
             raw = torch.empty(R, n_s, 4, dtype=torch.float32, device=dev)
@@ -333,6 +339,7 @@ class Renderer(torch.nn.Module):
         (render_class.py:125-197)."""
         self.shapeCodes, self.uvMap = shapeCodes, uvMap
         self.expType = int(expType)
+        self._weight_grads = True
         code, enlosses = unwrap(self.texEncoder)(uvMap.permute([2, 0, 1]).unsqueeze(0), self.lossList)
         self.lossLog.update(enlosses, 1)
         return self._render_common(H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, code, kwargs)
@@ -346,6 +353,7 @@ class Renderer(torch.nn.Module):
         unwrap(kwargs["network_fn"]).eval()
         self.shapeCodes = shapeCodes
         self.expType = int(expType)
+        self._weight_grads = bool(self.fit_weight_grads)
         if len(self.expCodes_Sigma) == 20:
             self.expCodes_Sigma.append(expCodes)
         else:

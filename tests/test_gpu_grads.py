@@ -47,7 +47,10 @@ def test_composite_backward_vs_autograd(S, white, use_noise):
     loss_of(*o).backward()
     torch.cuda.synchronize()
     assert rel_err(rg.grad.cpu(), r64.grad) < 2e-5
-    assert rel_err(dg.grad.cpu(), d64.grad) < 2e-5
+    # row 0 (acc == 0): torch's autograd returns NaN for d|rays_d| through where(isnan(disp), 0, disp) (0 * NaN); the HIP
+    # backward returns the finite value 0 — compare the other rows, and require finiteness of ours
+    assert torch.isfinite(dg.grad).all()
+    assert rel_err(dg.grad.cpu()[1:], d64.grad[1:]) < 2e-5
 
 
 def _mk(D, W, seed=3):
@@ -75,10 +78,10 @@ def test_net_backward_teacher_forced(D, W, S):
     G = T(rng.normal(size=(R, S, 4)).astype(np.float32))
     # ---- oracle, fp64 autograd -----------------------------------------------------------------------------------
     st64 = {k: v.double().requires_grad_(True) for k, v in st.items()}
-    o64, d64 = o.double().requires_grad_(True), d.double().requires_grad_(True)
+    o64, d64 = o.clone().requires_grad_(True), d.clone().requires_grad_(True)          # leaves stay fp32 so that
     bm64, tex64, e64 = bm.double().requires_grad_(True), tex.double().requires_grad_(True), e.double().requires_grad_(True)
-    pts = (o64[:, None, :] + d64[:, None, :] * z.double()[:, :, None]).reshape(-1, 3)
-    vd = d64 / torch.norm(d64, dim=-1, keepdim=True)
+    pts = (o64[:, None, :] + d64[:, None, :] * z[:, :, None]).reshape(-1, 3).double()   # pts is the SAME fp32 point set
+    vd = (d64 / torch.norm(d64, dim=-1, keepdim=True)).double()
     n = R * S
     x93 = torch.cat([orc.positional_encode(pts, 10), e64.expand(n, -1)], -1)
     v27 = orc.positional_encode(vd[:, None].expand(R, S, 3).reshape(-1, 3), 4)
@@ -88,7 +91,8 @@ def test_net_backward_teacher_forced(D, W, S):
     og, dg = o.to(DEV).requires_grad_(True), d.to(DEV).requires_grad_(True)
     bmg, texg, eg = bm.to(DEV).requires_grad_(True), tex.to(DEV).requires_grad_(True), e.to(DEV).requires_grad_(True)
     vdg = dg / torch.norm(dg, dim=-1, keepdim=True)
-    raw = NetFn.apply(h, og, dg, z.to(DEV), S, S, fold_torch(h, eg, bmg, texg), view_bias_torch(h, vdg))
+    raw = NetFn.apply(h, og, dg, z.to(DEV), S, S, fold_torch(h, eg, bmg, texg), view_bias_torch(h, vdg),
+                      *[l.weight for l in h._linears])            # training form: weight gradients requested
     (raw * G.to(DEV)).sum().backward()
     torch.cuda.synchronize()
     assert rel_err(raw.detach().cpu(), raw_ref.detach()) < 2e-5
@@ -100,9 +104,9 @@ def test_net_backward_teacher_forced(D, W, S):
     for li in (0, 3, 4, 9, 9 + D, len(lin) - 3, len(lin) - 2, len(lin) - 1):
         bkey = keys[2 * li + 1]
         errs["b:" + bkey] = rel_err(lin[li].bias.grad.cpu(), st64[bkey].grad)
-    for li, cols in ((0, slice(63, 93)), (4, slice(0, 50)), (9 + D, slice(0, 256)), (len(lin) - 3, slice(0, 27))):
+    for li in range(len(lin)):          # FULL weight gradients (per-point columns from the MFMA dW kernel + constant columns)
         wkey = keys[2 * li]
-        errs["w_const:" + wkey] = rel_err(lin[li].weight.grad[:, cols].cpu(), st64[wkey].grad[:, cols])
+        errs["w:" + wkey] = rel_err(lin[li].weight.grad.cpu(), st64[wkey].grad)
     print({k: f"{v:.1e}" for k, v in errs.items()})
     # the ray gradients pass through d/dx sin(2^9 x): fp32 forward activations limit them to ~1e-3 relative
     for k, v in errs.items():
@@ -134,6 +138,7 @@ def test_render_fitting_gradients_vs_reference_fixture(golden):
     legitimately between implementations (tiers B/C of compare_render), which perturbs a few rays' contributions."""
     g = golden("grads_small.npz")
     render, kw, _ = make_product((8, 64, 10, 64), 0, 4096, DEV)
+    render.fit_weight_grads = True         # also populate network weight.grad, as the reference's autograd does
     bm, tex, exp = [T(g[k]).to(DEV).requires_grad_(True) for k in ("bm", "tex", "exp")]
     ro, rd = [T(g[k]).to(DEV).requires_grad_(True) for k in ("rays_o", "rays_d")]
     rgb, disp, acc, ex = render.render_fitting(8, 8, None, chunk=64, rays=torch.stack([ro, rd], 0),
@@ -152,6 +157,9 @@ def test_render_fitting_gradients_vs_reference_fixture(golden):
     out["style_scale_w"] = (float(sw @ b / (np.linalg.norm(sw) * np.linalg.norm(b))), rel_err(sw, b))
     ba = kw["network_fine"].alpha_linear[0].bias.grad.cpu().numpy()
     out["b_alpha"] = (1.0, rel_err(ba, g["g_b_alpha"]))
+    for name, t in (("w_rgb", kw["network_fine"].rgb_linear.weight), ("w_xyz0_c", kw["network_fn"].xyzEncode.linears1.Linear0.weight)):
+        a, b = t.grad.cpu().numpy().ravel().astype(np.float64), g["g_" + name].ravel().astype(np.float64)
+        out[name] = (float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)), rel_err(a, b))
     print({k: (round(c, 5), f"{e:.1e}") for k, (c, e) in out.items()})
     for k, (cos, err) in out.items():
         assert cos > 0.99, (k, cos, err)
