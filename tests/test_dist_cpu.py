@@ -45,3 +45,29 @@ def _worker(rank, world, port, n_total, align):
 def test_all_gather_tiles_gloo_world2():
     for n_total, align in ((64 * 64, 64), (1000, 1), (3, 1)):
         mp.spawn(_worker, args=(2, _free_port(), n_total, align), nprocs=2, join=True)
+
+
+def _bucket_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    mdist.init_from_env("gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    extra = torch.nn.Parameter(torch.ones(5))                     # never used in the loss: gradient stays zero
+    bucket = mdist.GradBucket(list(net.parameters()) + [extra])
+    assert bucket.numel == sum(p.numel() for p in net.parameters()) + 5
+    x = torch.full((4, 8), float(rank + 1))
+    bucket.zero()
+    net(x).pow(2).sum().backward()                                # autograd accumulates INTO the bucket views
+    local = bucket.flat.clone()
+    assert local.abs().sum() > 0 and all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in bucket.params)
+    bucket.sync()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    assert torch.allclose(bucket.flat, sum(gathered) / world, atol=1e-6)
+    assert torch.equal(extra.grad, torch.zeros(5))
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_allreduce_gloo_world2():
+    mp.spawn(_bucket_worker, args=(2, _free_port()), nprocs=2, join=True)

