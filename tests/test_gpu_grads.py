@@ -146,7 +146,7 @@ def test_render_fitting_gradients_vs_reference_fixture(golden):
     loss = (rgb - 0.5).abs().mean() + (ex["rgb0"] ** 2).mean()
     loss.backward()
     torch.cuda.synchronize()
-    assert abs(float(loss) - float(g["loss"])) < 1e-4
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4
     nan_equal_close(ex["rgb0"].detach().cpu().numpy(), g["rgb0"], 1e-4)
     out = {}
     for name, t in (("bm", bm), ("tex", tex), ("exp", exp), ("rays_o", ro), ("rays_d", rd)):
