@@ -115,8 +115,21 @@ class _TexEncoderCore(nn.Module):
                                       nn.Linear(code_len, code_len), nn.LeakyReLU(0.1))
         _xavier_relu_(self)
 
+    def _convs(self, x):
+        """The seven 4x4 / stride-2 / pad-1 convolutions as im2col + GEMM.  On this stack MIOpen picks its
+        `naive_conv_*` solvers for these batch-1 shapes (measured: 20 % of a training step's GPU time, 8 ms per
+        backward call) and a 1-workgroup GEMM for the weight gradients; unfold + matmul is ~10x faster in both
+        directions and numerically the same sum of products."""
+        for i in range(7):
+            conv = self.down1[0][2 * i]
+            n, c, h, w = x.shape
+            cols = F.unfold(x, kernel_size=4, padding=1, stride=2)                 # [n, c*16, (h/2)*(w/2)]
+            y = conv.weight.reshape(conv.out_channels, -1) @ cols + conv.bias[None, :, None]
+            x = F.leaky_relu(y.reshape(n, conv.out_channels, h // 2, w // 2), 0.2)
+        return x
+
     def forward(self, x):
-        x = self.down1[0](x).reshape(-1, 256 * 4 * 4)
+        x = (self._convs(x) if x.is_cuda else self.down1[0](x)).reshape(-1, 256 * 4 * 4)
         return self.decoding(self.mu(self.down2(x)))
 
 

@@ -81,6 +81,7 @@ class Renderer(torch.nn.Module):
         # (run_fit.py never steps the networks); set fit_weight_grads=True to populate weight.grad there too
         self.fit_weight_grads = False
         self._weight_grads = False
+        self._tex_cache = None
         self._cache: Dict[tuple, torch.Tensor] = {}
 
     # expCodes_Sigma is a plain list (not registered parameters, render_class.py:53-58): move it with the module
@@ -340,7 +341,17 @@ class Renderer(torch.nn.Module):
         self.shapeCodes, self.uvMap = shapeCodes, uvMap
         self.expType = int(expType)
         self._weight_grads = True
-        code, enlosses = unwrap(self.texEncoder)(uvMap.permute([2, 0, 1]).unsqueeze(0), self.lossList)
+        enc = unwrap(self.texEncoder)
+        if torch.is_grad_enabled():
+            code, enlosses = enc(uvMap.permute([2, 0, 1]).unsqueeze(0), self.lossList)
+        else:
+            # render-only (bulk rendering shows the same UV map for every expression/view of an identity,
+            # render_refine_trainSet.py:288-289): the code is cached per (map storage, map version, encoder weights)
+            key = (uvMap.data_ptr(), uvMap._version, tuple(uvMap.shape)) + tuple((p.data_ptr(), p._version) for p in enc.parameters())
+            if self._tex_cache is None or self._tex_cache[0] != key:
+                code, enlosses = enc(uvMap.permute([2, 0, 1]).unsqueeze(0), self.lossList)
+                self._tex_cache = (key, code, enlosses)
+            _, code, enlosses = self._tex_cache
         self.lossLog.update(enlosses, 1)
         return self._render_common(H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, code, kwargs)
 
