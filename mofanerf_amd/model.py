@@ -116,10 +116,10 @@ class _TexEncoderCore(nn.Module):
         _xavier_relu_(self)
 
     def _convs(self, x):
-        """The seven 4x4 / stride-2 / pad-1 convolutions as im2col + GEMM.  On this stack MIOpen picks its
-        `naive_conv_*` solvers for these batch-1 shapes (measured: 20 % of a training step's GPU time, 8 ms per
-        backward call) and a 1-workgroup GEMM for the weight gradients; unfold + matmul is ~10x faster in both
-        directions and numerically the same sum of products."""
+        """im2col + GEMM form of the seven 4x4 / stride-2 / pad-1 convolutions — kept ONLY as the B arm of
+        tools/tex_encoder_ab.py.  Measured on MI355X: MIOpen 1.67 ms vs this 2.11 ms per forward+backward in steady
+        state (0.24 vs 0.41 ms forward); the `naive_conv_*` kernels a profile of the first steps shows are MIOpen's
+        one-off solver search, not the steady state.  The encoder is 0.2 % of a training step, so it stays on MIOpen."""
         for i in range(7):
             conv = self.down1[0][2 * i]
             n, c, h, w = x.shape
@@ -129,7 +129,7 @@ class _TexEncoderCore(nn.Module):
         return x
 
     def forward(self, x):
-        x = (self._convs(x) if x.is_cuda else self.down1[0](x)).reshape(-1, 256 * 4 * 4)
+        x = self.down1[0](x).reshape(-1, 256 * 4 * 4)
         return self.decoding(self.mu(self.down2(x)))
 
 
