@@ -23,10 +23,10 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+        if backend is None:      # MOFA_DIST_BACKEND=gloo lets several ranks share one GPU (functional test of the N>1 path)
+            backend = os.environ.get("MOFA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -56,7 +56,12 @@ def all_gather_tiles(local: torch.Tensor, n_total: int, world: int, rank: int, a
     pad = torch.zeros(mx, *local.shape[1:], dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     out = torch.empty(world * mx, *local.shape[1:], dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":      # test configuration only: stage through the host
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, pad.cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, pad, group=group)
     return torch.cat([out[r * mx: r * mx + (e - b)] for r, (b, e) in enumerate(sizes)], 0)
 
 
@@ -64,7 +69,7 @@ def barrier_max(seconds: float, device) -> float:
     """Max over ranks of a local duration (bench timing contract)."""
     if not (dist.is_available() and dist.is_initialized()):
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
