@@ -32,7 +32,8 @@ def stale() -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not stale():
         return OUT
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    extra = [f"-DMOFA_LAYER_WAVES={os.environ['MOFA_LAYER_WAVES']}"] if os.environ.get("MOFA_LAYER_WAVES") else []
+    cmd = [hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", os.environ.get("MOFA_LIB_OUT", OUT)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)

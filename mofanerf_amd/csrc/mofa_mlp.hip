@@ -99,8 +99,11 @@ __device__ __forceinline__ void mma_panel(const float* __restrict__ Xt, const fl
 // GLDS: stage operands with LDS-DMA (true) or through registers (false; kept as the A/B arm).
 // BWD: backward-data epilogue (no bias/ReLU; optional accumulate into y and ReLU mask from the saved activation):
 //      dX[m][k] = sum_n G[m][n] * W[n][k]  is the same GEMM with the transposed weight pack as "Wp".
+#ifndef MOFA_LAYER_WAVES
+#define MOFA_LAYER_WAVES 2  // min waves per SIMD the register allocator must leave room for (= workgroups per CU)
+#endif
 template <int BN, bool L0, bool GLDS, bool BWD = false>
-__global__ __launch_bounds__(256, 2) void k_layer(const LayerArgs a) {
+__global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BM = kRowTile;
     constexpr int WAVES_N = BN / 64;
@@ -246,11 +249,13 @@ __global__ __launch_bounds__(256, 2) void k_layer(const LayerArgs a) {
     }
     // epilogue: bias + ReLU, one 16-B store per accumulator quad into the next layer's panels
     f32x4 bv[NI][4];
-    if (!a.bias_row_div) {  // one bias row for every point: fetch it once
+    int boff = n0 + wn * 64 + 4 * g;
+    asm volatile("" : "+v"(boff));  // opaque AFTER the K loop: keeps hipcc from hoisting the 8 bias loads (32 VGPRs) above it
+    if (!a.bias_row_div) {  // one bias row for every point: fetch it once, all 8 loads in flight together
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(a.bias + n0 + wn * 64 + 32 * i + 8 * q + 4 * g);
+            for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(a.bias + boff + 32 * i + 8 * q);
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -487,7 +492,8 @@ int dispatch_layer(LayerArgs a, bool l0, hipStream_t st) {
     MOFA_REQUIRE(a.m_padded > 0 && a.m_padded % kRowTile == 0, "m_padded=%lld must be a positive multiple of %d",
                  a.m_padded, kRowTile);
     MOFA_REQUIRE(a.n_padded > 0 && a.n_padded % 64 == 0, "n_padded=%d must be a positive multiple of 64", a.n_padded);
-    if (a.n_padded % 128 == 0) return l0 ? launch_layer<128, true>(a, st) : launch_layer<128, false>(a, st);
+    static const bool force64 = getenv("MOFA_BN64") != nullptr;   // measurement knob (tools/microbench_layer.py)
+    if (a.n_padded % 128 == 0 && !force64) return l0 ? launch_layer<128, true>(a, st) : launch_layer<128, false>(a, st);
     return l0 ? launch_layer<64, true>(a, st) : launch_layer<64, false>(a, st);
 }
 

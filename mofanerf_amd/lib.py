@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmofanerf_hip.so")
+LIB_PATH = os.environ.get("MOFA_LIB") or os.path.join(_HERE, "libmofanerf_hip.so")   # MOFA_LIB: A/B builds (tools/)
 
 _f = C.POINTER(C.c_float)
 _fp = C.c_void_p      # device pointers travel as integers
