@@ -360,8 +360,9 @@ class Renderer(torch.nn.Module):
                        network_query_fn=None, **kwargs):
         """Fitting / novel-view entry: texture code given directly, expression code stored at slot 20
         (render_class.py:354-437)."""
-        unwrap(kwargs["network_fine"]).eval()
-        unwrap(kwargs["network_fn"]).eval()
+        for k in ("network_fine", "network_fn"):            # (the reference crashes on network_fine=None; tolerated here)
+            if kwargs.get(k) is not None:
+                unwrap(kwargs[k]).eval()
         self.shapeCodes = shapeCodes
         self.expType = int(expType)
         self._weight_grads = bool(self.fit_weight_grads)

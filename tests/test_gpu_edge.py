@@ -46,8 +46,10 @@ def test_ragged_sample_counts_and_coarse_only(Ns, Ni):
         return
     nan_equal_close(ex["rgb0"].cpu().numpy(), r_ex["rgb0"].numpy(), 1e-4)
     d = r_ex["_dbg"]
+    w_err = float((ex["_weights0"].cpu() - d["weights_coarse"]).abs().max())
+    assert w_err < 2e-5
     agree, expl = classify_samples(d["z_coarse"], d["weights_coarse"], torch.linspace(0., 1., Ni), ex["_z_samples"].cpu(),
-                                   d["z_samples"])
+                                   d["z_samples"], w_err=w_err)
     assert (agree | expl).all()
     clean = agree.all(-1).numpy()
     assert clean.any()
