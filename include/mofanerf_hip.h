@@ -116,7 +116,8 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
 size_t mofa_weight_grad_workspace_floats(int64_t n_points, int32_t n_padded, int32_t k_padded);
 int mofa_weight_grad(const float* g, int32_t n_padded, const float* x, int32_t k_padded, int64_t m_padded,
                      int64_t n_points, int32_t n_out, int32_t ncols, float* dst, int32_t ld, int32_t col0,
-                     float* workspace, void* stream);
+                     float* bias_out /* NULL or [n_padded] = sum_m G[m][:] from the same pass */, float* workspace,
+                     void* stream);
 int mofa_head_weight_grad(const float* d_raw, int32_t raw_off, int32_t n_out, const float* x, int32_t k_padded,
                           int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, void* stream);
 int mofa_pe_panels(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride, int64_t n_points,

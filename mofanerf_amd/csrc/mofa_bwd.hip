@@ -363,14 +363,19 @@ __device__ __forceinline__ void glds16b(const float* g, float* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-constexpr int kWgMC = 32;  // points per pipeline stage
+// points per pipeline stage: 16 for the 128 x 256 tile (24 KiB / stage, like the forward kernel), 32 for the small tiles
+template <int TN, int TK>
+struct WgCfg {
+    static constexpr int MC = (TN == 128 && TK == 256) ? 16 : 32;
+};
 
 template <int TN, int TK>
 __global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ g, const float* __restrict__ x,
                                                   long long m_padded, long long n_points, int n_padded, int k_padded,
-                                                  int chunks_per_split, float* __restrict__ partial) {
+                                                  int chunks_per_split, float* __restrict__ partial,
+                                                  float* __restrict__ bias_partial) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int MC = kWgMC;
+    constexpr int MC = WgCfg<TN, TK>::MC;
     constexpr int PSTR = MC * 16 + 16;              // LDS stride between 16-feature panels (+16: bank spread)
     constexpr int GP = TN / 16, XP = TK / 16;       // panels per stage
     constexpr int STAGE = (GP + XP) * PSTR;
@@ -395,19 +400,23 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ g, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // one stage = GP + XP panel pieces of MC rows x 64 B = 2 KiB each = 2 wave-instructions of 1 KiB
+    // one stage = GP + XP panel pieces of MC rows x 64 B, moved as 1 KiB (16-row) wave-instructions
     auto stage = [&](int buf, long long chunk) {
         float* base = smem + buf * STAGE;
         const long long m0 = chunk * MC;
-        constexpr int PIECES = (GP + XP) * 2;       // 1 KiB pieces
+        constexpr int PPP = MC / 16;                // 1 KiB pieces per panel
+        constexpr int PIECES = (GP + XP) * PPP;
         for (int pc = wave; pc < PIECES; pc += 4) {
-            const int panel = pc >> 1, half = pc & 1;
+            const int panel = pc / PPP, part = pc % PPP;
             const float* src = (panel < GP)
-                                   ? g + ((long long)(n0 / 16 + panel) * m_padded + m0 + half * 16) * 16
-                                   : x + ((long long)(k0 / 16 + panel - GP) * m_padded + m0 + half * 16) * 16;
-            glds16b(src + lane * 4, base + panel * PSTR + half * 256);
+                                   ? g + ((long long)(n0 / 16 + panel) * m_padded + m0 + part * 16) * 16
+                                   : x + ((long long)(k0 / 16 + panel - GP) * m_padded + m0 + part * 16) * 16;
+            glds16b(src + lane * 4, base + panel * PSTR + part * 256);
         }
     };
+    float bsum[NI];                                 // bias gradient rides along: sum_m G[m][n] for this lane's features
+#pragma unroll
+    for (int i = 0; i < NI; ++i) bsum[i] = 0.f;
 
     const int li = lane & 31, gsel = lane >> 5;
     if (c_begin < c_end) {
@@ -423,13 +432,14 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ g, c
             for (int mp = 0; mp < MC / 2; ++mp) {
                 const int ml = 2 * mp + gsel;                         // this lane's point within the chunk
                 const bool live = (m0 + ml) < n_points;               // rows beyond the batch contribute nothing
-                const int sw = (ml >> 2) & 3;                         // m0 is a multiple of 32: same swizzle as global
+                const int sw = (ml >> 2) & 3;                         // m0 is a multiple of 16: same swizzle as global
                 float a[NI], b[NJ];
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int nl = wn * (TN / 2) + 32 * i + li;       // feature within the tile
                     const float v = gs[(nl >> 4) * PSTR + ml * 16 + ((((nl >> 2) & 3) ^ sw) << 2) + (nl & 3)];
                     a[i] = live ? v : 0.f;
+                    bsum[i] += a[i];
                 }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
@@ -443,6 +453,13 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ g, c
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
             __syncthreads();
+        }
+    }
+    if (bias_partial && kt == 0 && wk == 0) {       // one column of workgroups owns the bias partials [split][n_padded]
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);      // even + odd points
+            if (lane < 32) bias_partial[(long long)split * n_padded + n0 + wn * (TN / 2) + 32 * i + li] = tot;
         }
     }
     // partial[split][n][k], row-major [n_padded][k_padded]
@@ -469,6 +486,15 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     float s = 0.f;
     for (int sp = 0; sp < splits; ++sp) s += partial[((long long)sp * n_padded + n) * k_padded + k];
     dst[(long long)n * ld + col0 + k] = s;
+}
+
+__global__ __launch_bounds__(256) void k_bias_reduce(const float* __restrict__ partial, int splits, int n_padded,
+                                                     float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_padded) return;
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += partial[(long long)sp * n_padded + n];
+    out[n] = s;
 }
 
 // head weight gradient: dst[o][k] = sum_m d_raw[m][off+o] * X[m][k]; one block per 16-feature panel of X
@@ -537,13 +563,32 @@ __global__ __launch_bounds__(256) void k_pe_panels(const float* __restrict__ ray
 
 template <int TN, int TK>
 int launch_wgrad(const float* g, const float* x, long long m_padded, long long n_points, int n_padded, int k_padded,
-                 int splits, int chunks_per_split, float* partial, hipStream_t st) {
-    constexpr int PSTR = kWgMC * 16 + 16;
+                 int splits, int chunks_per_split, float* partial, float* bias_partial, hipStream_t st) {
+    constexpr int PSTR = WgCfg<TN, TK>::MC * 16 + 16;
     const size_t lds = 2 * (size_t)(TN / 16 + TK / 16) * PSTR * sizeof(float);
     const dim3 grid((n_padded / TN) * (k_padded / TK), splits);
     hipLaunchKernelGGL((k_wgrad<TN, TK>), grid, dim3(256), lds, st, g, x, m_padded, n_points, n_padded, k_padded,
-                       chunks_per_split, partial);
+                       chunks_per_split, partial, bias_partial);
     return check_launch("k_wgrad");
+}
+
+// tile / split plan shared by the workspace query and the launch
+struct WgPlan {
+    int tn, tk, mc, splits, cps;
+};
+inline WgPlan wg_plan(long long n_points, int n_padded, int k_padded) {
+    WgPlan p;
+    p.tn = n_padded % 128 == 0 ? 128 : 64;
+    p.tk = (p.tn == 128 && k_padded % 256 == 0) ? 256 : (k_padded % 128 == 0 ? 128 : 64);
+    p.mc = (p.tn == 128 && p.tk == 256) ? 16 : 32;
+    const long long tiles = (long long)(n_padded / p.tn) * (k_padded / p.tk);
+    const long long chunks = (n_points + p.mc - 1) / p.mc;
+    long long splits = (1024 + tiles - 1) / tiles;
+    if (splits > chunks) splits = chunks;
+    if (splits < 1) splits = 1;
+    p.cps = (int)((chunks + splits - 1) / splits);
+    p.splits = (int)((chunks + p.cps - 1) / p.cps);
+    return p;
 }
 
 }  // namespace
@@ -554,42 +599,39 @@ extern "C" {
 /* partial-sum workspace (floats) needed by mofa_weight_grad for a [n_padded x k_padded] block over n_points */
 size_t mofa_weight_grad_workspace_floats(int64_t n_points, int32_t n_padded, int32_t k_padded) {
     if (n_points <= 0 || n_padded <= 0 || k_padded <= 0) return 0;
-    const int tn = n_padded % 128 == 0 ? 128 : 64, tk = k_padded % 128 == 0 ? 128 : 64;
-    const long long tiles = (long long)(n_padded / tn) * (k_padded / tk);
-    const long long chunks = (n_points + mofa::kWgMC - 1) / mofa::kWgMC;
-    long long splits = (1024 + tiles - 1) / tiles;
-    if (splits > chunks) splits = chunks;
-    if (splits < 1) splits = 1;
-    return (size_t)splits * n_padded * k_padded;
+    const WgPlan p = wg_plan(n_points, n_padded, k_padded);
+    return (size_t)p.splits * n_padded * ((size_t)k_padded + 1);     // dW partials + bias partials
 }
 
 /* dst[n][col0 + k] = sum_m G[m][n] X[m][k]  (n < n_out, k < ncols); G panels [n_padded/16][Mp][16] (ReLU-masked output
- * gradient), X panels [k_padded/16][Mp][16] (the layer's input), dst row-major with leading dimension ld. */
+ * gradient), X panels [k_padded/16][Mp][16] (the layer's input), dst row-major with leading dimension ld.
+ * bias_out (may be NULL): [n_padded] = sum_m G[m][n], produced by the same pass over G. */
 int mofa_weight_grad(const float* g, int32_t n_padded, const float* x, int32_t k_padded, int64_t m_padded,
                      int64_t n_points, int32_t n_out, int32_t ncols, float* dst, int32_t ld, int32_t col0,
-                     float* workspace, void* stream) {
+                     float* bias_out, float* workspace, void* stream) {
     MOFA_REQUIRE(g && x && dst && workspace, "weight_grad: null pointer");
     MOFA_REQUIRE(n_padded % 64 == 0 && k_padded % 64 == 0 && n_out <= n_padded && ncols <= k_padded && n_points > 0 &&
                      n_points <= m_padded && m_padded % 256 == 0 && col0 >= 0 && col0 + ncols <= ld,
                  "weight_grad: bad shape n_padded=%d k_padded=%d n_out=%d ncols=%d", n_padded, k_padded, n_out, ncols);
-    const int tn = n_padded % 128 == 0 ? 128 : 64, tk = k_padded % 128 == 0 ? 128 : 64;
-    const long long tiles = (long long)(n_padded / tn) * (k_padded / tk);
-    const long long chunks = (n_points + kWgMC - 1) / kWgMC;
-    long long splits = (1024 + tiles - 1) / tiles;
-    if (splits > chunks) splits = chunks;
-    if (splits < 1) splits = 1;
-    const int cps = (int)((chunks + splits - 1) / splits);
-    splits = (chunks + cps - 1) / cps;
+    const WgPlan p = wg_plan(n_points, n_padded, k_padded);
+    float* bias_partial = bias_out ? workspace + (size_t)p.splits * n_padded * k_padded : nullptr;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (tn == 128 && tk == 128) rc = launch_wgrad<128, 128>(g, x, m_padded, n_points, n_padded, k_padded, (int)splits, cps, workspace, st);
-    else if (tn == 128) rc = launch_wgrad<128, 64>(g, x, m_padded, n_points, n_padded, k_padded, (int)splits, cps, workspace, st);
-    else if (tk == 128) rc = launch_wgrad<64, 128>(g, x, m_padded, n_points, n_padded, k_padded, (int)splits, cps, workspace, st);
-    else rc = launch_wgrad<64, 64>(g, x, m_padded, n_points, n_padded, k_padded, (int)splits, cps, workspace, st);
+#define MOFA_WG(TN, TK) \
+    rc = launch_wgrad<TN, TK>(g, x, m_padded, n_points, n_padded, k_padded, p.splits, p.cps, workspace, bias_partial, st)
+    if (p.tn == 128 && p.tk == 256) MOFA_WG(128, 256);
+    else if (p.tn == 128 && p.tk == 128) MOFA_WG(128, 128);
+    else if (p.tn == 128) MOFA_WG(128, 64);
+    else if (p.tk == 128) MOFA_WG(64, 128);
+    else MOFA_WG(64, 64);
+#undef MOFA_WG
     if (rc != MOFA_OK) return rc;
     const long long total = (long long)n_out * ncols;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace, (int)splits,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace, p.splits,
                        n_padded, k_padded, n_out, ncols, dst, ld, col0);
+    if (bias_out)
+        hipLaunchKernelGGL(k_bias_reduce, dim3((unsigned)((n_padded + 255) / 256)), dim3(256), 0, st, bias_partial, p.splits,
+                           n_padded, bias_out);
     return check_launch("k_wgrad_reduce");
 }
 

@@ -29,7 +29,7 @@ int mofa_pe_backward(const float* dpe, int64_t m_padded, const float* rays_o, co
 size_t mofa_weight_grad_workspace_floats(int64_t n_points, int32_t n_padded, int32_t k_padded);
 int mofa_weight_grad(const float* g, int32_t n_padded, const float* x, int32_t k_padded, int64_t m_padded,
                      int64_t n_points, int32_t n_out, int32_t ncols, float* dst, int32_t ld, int32_t col0,
-                     float* workspace, void* stream);
+                     float* bias_out, float* workspace, void* stream);
 int mofa_head_weight_grad(const float* d_raw, int32_t raw_off, int32_t n_out, const float* x, int32_t k_padded,
                           int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, void* stream);
 int mofa_pe_panels(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride, int64_t n_points,
@@ -226,7 +226,7 @@ size_t mofa_net_backward_workspace_floats(MofaNetShape s, int64_t n_points) {
     if (!shape_ok(s) || n_points <= 0) return 0;
     const Plan p = make_plan(s);
     return (size_t)round_up(n_points, kRowTile) * (4 * (size_t)p.Wp + 64) + 64 +
-           mofa_weight_grad_workspace_floats(n_points, p.Wp, p.Wp);     // split-M partials of the largest dW block
+           mofa_weight_grad_workspace_floats(n_points, p.Wp, p.Wp) + 64;  // split-M partials of the largest dW block
 }
 
 int mofa_net_pack_t(MofaNetShape s, const float* const* weights, float* packed_t, void* stream) {
@@ -361,10 +361,14 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
         const Layer& l = p.L[li];
         MOFA_REQUIRE(d_weights[li], "net_backward: d_weights[%d] is null", li);
         return mofa_weight_grad(g, l.n_padded, x, l.k_padded[part], Mp, M, l.n_out, l.ncols[part], d_weights[li], l.ld,
-                                l.col0[part], wws, stream);
+                                l.col0[part], (part == 0 && l.fold != kView) ? d_folded + l.folded_off : nullptr, wws,
+                                stream);
     };
-    // bias gradient of layer li from its masked output gradient g
+    // bias gradient of layer li from its masked output gradient g.  Training: produced by the weight-gradient kernel's
+    // pass over G (part 0).  Fitting: only the five code-conditioned layers need it (the others' biases are not optimised;
+    // their slots are zeroed below).
     auto bgrad = [&](int li, const float* g) -> int {
+        if (d_weights || p.L[li].fold == kNone) return MOFA_OK;
         return mofa_bias_grad(g, Mp, M, p.L[li].n_padded, d_folded + p.L[li].folded_off, stream);
     };
     // dX = G @ W[:, part]
@@ -374,6 +378,8 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
                                         l.k_padded[part], stream);
     };
     const int n2 = s.D - 5;
+    if (!d_weights && hipMemsetAsync(d_folded, 0, p.folded_floats * sizeof(float), (hipStream_t)stream) != hipSuccess)
+        return check_launch("hipMemsetAsync(d_folded)");
     // heads' bias gradients
     MOFA_TRY(mofa_internal_raw_colsum(d_raw, M, 3, 1, d_folded + p.L[p.alpha].folded_off, stream));
     MOFA_TRY(mofa_internal_raw_colsum(d_raw, M, 0, 3, d_folded + p.L[p.rgb].folded_off, stream));

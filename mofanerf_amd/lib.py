@@ -42,7 +42,7 @@ SIGNATURES = {
     "mofa_net_backward": (C.c_int, [NetShape, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _i64, _i32, _fp, _fp, _fp, _fp,
                                     _fp, C.POINTER(_fp), _fp]),
     "mofa_weight_grad_workspace_floats": (_sz, [_i64, _i32, _i32]),
-    "mofa_weight_grad": (C.c_int, [_fp, _i32, _fp, _i32, _i64, _i64, _i32, _i32, _fp, _i32, _i32, _fp, _fp]),
+    "mofa_weight_grad": (C.c_int, [_fp, _i32, _fp, _i32, _i64, _i64, _i32, _i32, _fp, _i32, _i32, _fp, _fp, _fp]),
     "mofa_head_weight_grad": (C.c_int, [_fp, _i32, _i32, _fp, _i32, _i64, _i64, _i32, _fp, _i32, _fp]),
     "mofa_pe_panels": (C.c_int, [_fp, _fp, _fp, _i64, _i64, _i32, _i64, _fp, _fp]),
     "mofa_pack_panels_t": (C.c_int, [_fp, _i32, _i32, _i32, _i32, _fp, _i32, _i32, _fp]),
