@@ -58,7 +58,7 @@ for mode in sys.argv[1:] or ["fit", "train"]:
         uv = torch.rand(512, 512, 3, device=dev)
         target = torch.rand(n, 3, device=dev)
         bm = synth.codes(0)[0].to(dev).expand(n, -1)
-        dt = timed(lambda: steps.train_step(render, kw, opt, bucket, 512, 512, K, rays, target, bm, uv, 3, chunk=n))
+        dt = timed(lambda: steps.train_step(render, kw, opt, bucket, 512, 512, K, rays, target, bm, uv, 3, chunk=n), warm=4, it=4)  # MIOpen searches conv solvers during the first calls
         flop = 3 * fwd_flop * n          # forward + backward-data + weight gradients
     print(json.dumps({"mode": mode, "rays_per_step": n, "ms_per_step": round(dt * 1e3, 2), "rays_per_s": round(n / dt, 1),
                       "algorithmic_tflops": round(flop / dt / 1e12, 2), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}),
