@@ -15,7 +15,6 @@ There is no eager/CPU fallback: CPU tensors or a missing library raise ``MofaErr
 from __future__ import annotations
 
 import os
-import time
 from typing import Dict, Optional
 
 import numpy as np
@@ -377,28 +376,28 @@ class Renderer(torch.nn.Module):
                     savedir=None, render_factor=0, shapeCodes=None, name=None):
         """Render one image per pose (render_class.py:199-237).  Existing outputs are skipped so a bulk render can
         resume.  Images are written as PNG when ``savedir`` is given and an encoder is importable."""
-        H, W, focal = hwf
-        if render_factor != 0:
-            H, W, focal = H // render_factor, W // render_factor, focal / render_factor
-        if savedir is not None:
-            filename = os.path.join(savedir, "{}.png".format(name))
-            if os.path.exists(filename):
-                print("exists")
-                return 0, 0
-        rgbs, disps = [], []
-        t = time.time()
-        for i, c2w in enumerate(render_poses):
-            print(i, time.time() - t)
-            t = time.time()
-            rgb, disp, acc, _ = self.render(H, W, K, chunk=chunk, c2w=c2w[:3, :4], shapeCodes=shapeCodes[i, :].reshape(1, -1),
-                                            uvMap=uvMap[i, :], expType=expType[i], **render_kwargs)
-            rgbs.append(rgb.cpu().numpy())
-            disps.append(disp.cpu().numpy())
+        height, width, focal = hwf
+        if render_factor:                                   # render downsampled
+            height, width, focal = height // render_factor, width // render_factor, focal / render_factor
+
+        def out_file(i):
+            stem = name if name is not None else "{:03d}".format(i)
+            return os.path.join(savedir, stem + ".png")
+
+        if savedir is not None and os.path.exists(os.path.join(savedir, "{}.png".format(name))):
+            print("exists")                                 # bulk renders resume by skipping finished images
+            return 0, 0
+        from .io import write_png
+        frames, disparities = [], []
+        for i, pose in enumerate(render_poses):
+            rgb, disp, _acc, _extras = self.render(height, width, K, chunk=chunk, c2w=pose[:3, :4],
+                                                   shapeCodes=shapeCodes[i, :].reshape(1, -1), uvMap=uvMap[i, :],
+                                                   expType=expType[i], **render_kwargs)
+            frames.append(rgb.detach().cpu().numpy())
+            disparities.append(disp.detach().cpu().numpy())
             if savedir is not None:
-                from .io import write_png
-                fn = os.path.join(savedir, "{}.png".format(name) if name is not None else "{:03d}.png".format(i))
-                write_png(fn, (255 * np.clip(rgbs[-1], 0, 1)).astype(np.uint8))
-        return np.stack(rgbs, 0), np.stack(disps, 0)
+                write_png(out_file(i), (255 * np.clip(frames[-1], 0, 1)).astype(np.uint8))
+        return np.stack(frames, 0), np.stack(disparities, 0)
 
 
 myRenderer = Renderer   # the reference's class name
