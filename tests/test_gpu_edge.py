@@ -180,3 +180,31 @@ def test_unsupported_flags_fail_loudly():
         kw["network_fn"](torch.zeros(1, 93, device=DEV), None, None, None)
     with pytest.raises(lib.MofaError):
         lib.check(lib.load().mofa_composite_forward(1, 1, 0, 1, None, 4, 300, 0, 1, 1, 1, 1, 1, None), "composite S=300")
+
+
+def test_bulk_render_tool_and_ray_helpers(tmp_path):
+    """Config-4 job shape at toy size (2 identities x 1 expression x 2 views, 16x16, small nets) + resume; rays helpers."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bulk_render", os.path.join(root, "tools", "bulk_render.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = ["--out", str(tmp_path), "--identities", "2", "--expressions", "1", "--views", "2", "--size", "16", "--arch", "8", "64",
+            "10", "64"]
+    assert mod.main(argv) == 4
+    assert sorted(os.listdir(tmp_path / "000")) == ["00_0.png", "00_1.png"]
+    assert mod.main(argv) == 0                                        # everything already on disk: nothing re-rendered
+    from mofanerf_amd import rays
+    K = synth.intrinsics(32, 32)
+    c2w = rays.pose_spherical(25.0, 0.0, 16.0)
+    assert torch.equal(c2w, orc.pose_spherical(25.0, 0.0, 16.0))
+    ro, rd = rays.get_rays(32, 32, K, c2w[:3, :4], device=DEV)
+    ro_ref, rd_ref = orc.get_rays(32, 32, K, c2w[:3, :4])
+    assert torch.equal(rd.cpu(), rd_ref) and torch.equal(ro.cpu(), ro_ref.contiguous())
+    pose = c2w[:3, :4].clone().to(DEV).requires_grad_(True)
+    rows, cols = torch.tensor([0, 5, 31], device=DEV), torch.tensor([3, 17, 31], device=DEV)
+    r = rays.rays_at_pixels(K, pose, rows, cols)
+    assert torch.allclose(r[1].detach().cpu(), rd_ref[rows.cpu(), cols.cpu()], atol=1e-6)
+    r[1].sum().backward()
+    assert pose.grad is not None and float(pose.grad.abs().sum()) > 0
