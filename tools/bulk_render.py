@@ -50,7 +50,7 @@ def main(argv=None):
                     pose = rays.pose_spherical(float(ang), 0.0, 16.0)[None]
                     r = render.render_path(pose, [a.size, a.size, float(K[0][0])], K, args.chunk, kw, uvMap=uv,
                                            expType=torch.tensor([e]), savedir=d, shapeCodes=shape, name=f"{e:02d}_{v}")
-                    n += 0 if r == (0, 0) else 1
+                    n += 0 if isinstance(r[0], int) else 1          # (0, 0) = already on disk
         return n
 
     torch.cuda.synchronize(); t0 = time.perf_counter()
