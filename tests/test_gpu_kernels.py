@@ -321,3 +321,44 @@ def test_sample_pdf_golden(golden):
     agree, expl = classify_samples(z, ww, torch.linspace(0., 1., 64), zs, ref)
     assert (agree | expl).all()
     nan_equal_close(zs[0].numpy(), ref[0].numpy(), 1e-5)               # all-zero weights -> uniform pdf
+
+
+def test_layer_pipeline_race_screen_full_size():
+    """The LDS-DMA double buffer relies on `vmcnt(0)` + `s_barrier` ordering: run the shipped fine-net layer shape
+    (196,608 points x 1024 x 1024, 6,144 workgroups) repeatedly — also with a second stream hammering HBM — and require
+    bit-identical outputs every time, plus agreement with a float64 reference on sampled rows."""
+    M, K, N = 196608, 1024, 1024
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(M * K, device=DEV, generator=g)           # any values: interpreted as panels
+    w = torch.randn(N * K, device=DEV, generator=g) * 0.03
+    b = torch.randn(N, device=DEV, generator=g)
+    y = torch.empty(M * N, device=DEV)
+    args = lambda out: (lib.ptr(x), K, None, 0, lib.ptr(w), lib.ptr(b), 0, 1, lib.ptr(out), M, N, 1, lib.stream())
+    lib.check(L().mofa_layer_forward(*args(y)), "layer")
+    ref = y.clone()
+    side = torch.cuda.Stream()
+    junk = torch.empty(1 << 28, device=DEV)
+    for it in range(6):
+        if it % 2:
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    junk.add_(1.0)                                # concurrent HBM traffic
+        y.fill_(float("nan"))
+        lib.check(L().mofa_layer_forward(*args(y)), "layer")
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref), f"run {it} differs"
+    # sampled rows against float64 (un-panel with the documented address formula)
+    rows = torch.tensor([0, 1, 255, 256, 70001, M - 1], device=DEV)
+    xr = torch.empty(len(rows), K, device=DEV); yr = torch.empty(len(rows), N, device=DEV)
+    k = torch.arange(K, device=DEV)
+    for i, r in enumerate(rows.tolist()):
+        idx = (k // 16) * M * 16 + r * 16 + ((((k % 16) // 4) ^ ((r // 4) % 4)) * 4) + k % 4
+        xr[i] = x[idx]
+        yr[i] = ref[idx]                                           # K == N: same index map
+    n = torch.arange(N, device=DEV)
+    kk = torch.arange(K, device=DEV)
+    wd = torch.empty(N, K, device=DEV)
+    widx = (kk[None, :] // 16) * N * 16 + n[:, None] * 16 + ((((kk[None, :] % 16) // 4) ^ ((n[:, None] // 4) % 4)) * 4) + kk[None, :] % 4
+    wd = w[widx]
+    want = torch.relu(xr.double() @ wd.double().T + b.double()).float()
+    nan_equal_close(yr.cpu().numpy(), want.cpu().numpy(), 3e-5)
