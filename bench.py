@@ -124,10 +124,14 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-rays", type=int, default=1024, help="rays in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--arch", type=int, nargs=4, default=list(ARCH), metavar=("Dc", "Wc", "Df", "Wf"),
+                    help="network sizes; default = shipped config (8 256 10 1024).  '8 256 8 256' is the labelled variant "
+                         "BASELINE.md lists (fine net as small as the coarse one)")
     ap.add_argument("--size", type=int, default=512, help="image side (512 = the benchmark; smaller only for functional tests)")
     a = ap.parse_args()
-    global H, W
+    global H, W, ARCH
     H = W = a.size
+    ARCH = tuple(a.arch)
 
     rank, world, local = mdist.init_from_env()
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N>1)"
@@ -198,7 +202,7 @@ def main():
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{H}x{W} novel view, 64 coarse + 128 fine samples/ray, coarse 256x8 + fine 1024x10, "
+            "config": {"workload": f"{H}x{W} novel view, 64 coarse + 128 fine samples/ray, coarse {ARCH[1]}x{ARCH[0]} + fine {ARCH[3]}x{ARCH[2]}, "
                                    "chunk=netchunk=196608, seeded Xavier weights (BASELINE.json configs[1])",
                        "rays_per_step": n_total, "parallelism": f"ray-rows x{world} + all-gather",
                        "gflop_per_ray_folded": round(flops_per_ray(True) / 1e9, 4),
