@@ -119,6 +119,7 @@ def cpu_baseline(n_rays, seed=0):
 
 
 def main():
+    global H, W, ARCH
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -129,7 +130,6 @@ def main():
                          "BASELINE.md lists (fine net as small as the coarse one)")
     ap.add_argument("--size", type=int, default=512, help="image side (512 = the benchmark; smaller only for functional tests)")
     a = ap.parse_args()
-    global H, W, ARCH
     H = W = a.size
     ARCH = tuple(a.arch)
 
