@@ -433,6 +433,179 @@ __global__ __launch_bounds__(256) void k_positional_encode(const float* __restri
     out[idx] = pe_feature(k, x[r * 3], x[r * 3 + 1], x[r * 3 + 2], nf);
 }
 
+// ======================================================================================================
+// Persistent whole-network kernel for widths <= 256 (coarse net; fine net of the 256x8 variant).
+// One workgroup (8 waves) owns ALL features of a 256-point tile, so consecutive layers of that tile depend only on
+// this workgroup's own stores: the 2D+5 MFMA layers run back to back in ONE launch (no per-layer launch ramp/tail, no
+// inter-workgroup synchronisation), each workgroup looping over its point tiles.  Same panels, same LDS-DMA pipeline and
+// bit-identical arithmetic as k_layer; activations still round-trip through (L2-resident) global panels because a
+// 256 x 256 fp32 tile (256 KiB) does not fit in the 160 KiB LDS.
+// ======================================================================================================
+constexpr int kMaxFusedLayers = 40;
+
+struct FusedLayer {
+    long long x1_off, x2_off, y_off;  // float offsets into the activation arena; x1_off < 0: layer 0 (positional encoding)
+    long long w_off;                  // into the packed weights
+    long long bias_off;               // into `folded` (bias_row_div == 0) or into `view_bias_rows`
+    int k1p, k2p, n_padded, bias_row_div;
+};
+
+struct FusedArgs {
+    const float* arena;   // activation buffers (workspace or tape)
+    float* arena_w;
+    const float* packed;
+    const float* folded;
+    const float* view_bias_rows;
+    const float* rays_o;
+    const float* rays_d;
+    const float* z;
+    const float* pts;
+    long long z_row_stride, n_points, m_padded, bias_rows;
+    int S, n_layers, m_tiles;
+    FusedLayer L[kMaxFusedLayers];
+};
+
+__global__ __launch_bounds__(512, 2) void k_mlp_fused(const FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BM = kRowTile, BNMAX = 256, NI = 2, NJ = 4;
+    constexpr int STAGE = (BM + BNMAX) * 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3, wm = wave >> 2;          // 4 (features) x 2 (points) waves, wave tile 64 x 128
+    const int lr = lane & 31, g = lane >> 5;
+
+    for (int mt = blockIdx.x; mt < a.m_tiles; mt += gridDim.x) {
+        const long long m0 = (long long)mt * BM;
+        // layer 0: threads 0..255 own one point row each
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (tid < BM) {
+            long long m = m0 + tid;
+            if (m >= a.n_points) m = a.n_points - 1;
+            if (a.pts) {
+                px = a.pts[m * 3 + 0], py = a.pts[m * 3 + 1], pz = a.pts[m * 3 + 2];
+            } else {
+                const long long r = m / a.S;
+                const int s = (int)(m - r * a.S);
+                const float zz = a.z[r * a.z_row_stride + s];
+                px = __fadd_rn(a.rays_o[r * 3 + 0], __fmul_rn(a.rays_d[r * 3 + 0], zz));
+                py = __fadd_rn(a.rays_o[r * 3 + 1], __fmul_rn(a.rays_d[r * 3 + 1], zz));
+                pz = __fadd_rn(a.rays_o[r * 3 + 2], __fmul_rn(a.rays_d[r * 3 + 2], zz));
+            }
+        }
+        for (int li = 0; li < a.n_layers; ++li) {
+            const FusedLayer& l = a.L[li];
+            const bool l0 = l.x1_off < 0;
+            const int KT = l.k1p + l.k2p;
+            const int np = l.n_padded;
+            const bool active = wn * 64 < np;          // wave-uniform: this wave's feature rows exist in this layer
+            const float* wbase = a.packed + l.w_off;
+
+            auto stage_issue = [&](int buf, int kt) {
+                float* xs = smem + buf * STAGE;
+                float* ws = xs + BM * 16;
+                if (l0) {
+                    if (tid < BM) {
+                        const int swz = (tid >> 2) & 3;
+#pragma unroll 1
+                        for (int kk = 0; kk < 16; ++kk) {
+                            const float v = pe_feature(kt * 16 + kk, px, py, pz, 3 + 6 * MOFA_PE_POINT_FREQS);
+                            xs[tid * 16 + ((((kk >> 2) & 3) ^ swz) << 2) + (kk & 3)] = v;
+                        }
+                    }
+                } else {
+                    const float* src = (kt < l.k1p ? a.arena + l.x1_off + ((long long)kt * a.m_padded + m0) * 16
+                                                   : a.arena + l.x2_off + ((long long)(kt - l.k1p) * a.m_padded + m0) * 16);
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) glds16(src + (r * 512 + tid) * 4, xs + (r * 512 + wave * 64) * 4);
+                }
+                const float* wsrc = wbase + (long long)kt * np * 16;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    if ((r * 512 + wave * 64) * 4 < np * 16)   // wave-uniform guard for layers narrower than 256
+                        glds16(wsrc + (r * 512 + tid) * 4, ws + (r * 512 + wave * 64) * 4);
+            };
+
+            f32x16 acc[NI][NJ];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+            stage_issue(0, 0);
+            __syncthreads();
+            for (int kt = 0; kt < KT; ++kt) {
+                const int cur = kt & 1;
+                if (kt + 1 < KT) stage_issue(cur ^ 1, kt + 1);
+                const float* xs = smem + cur * STAGE;
+                if (active) mma_panel<NI, NJ>(xs, xs + BM * 16, wm * 128, wn * 64, lane, acc);
+                __syncthreads();
+            }
+            if (active) {
+                float* y = a.arena_w + l.y_off;
+                f32x4 bv[NI][4];
+                int boff = wn * 64 + 4 * g;
+                asm volatile("" : "+v"(boff));
+                if (!l.bias_row_div) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(a.folded + l.bias_off + boff + 32 * i + 8 * q);
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const long long m = m0 + wm * 128 + 32 * j + lr;
+                    if (l.bias_row_div) {
+                        long long brow = m / l.bias_row_div;
+                        if (brow >= a.bias_rows) brow = a.bias_rows - 1;
+                        const float* bias = a.view_bias_rows + l.bias_off + brow * np + boff;
+#pragma unroll
+                        for (int i = 0; i < NI; ++i)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(bias + 32 * i + 8 * q);
+                    }
+                    const int msw = (int)(m >> 2) & 3;
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int n = wn * 64 + 32 * i + 8 * q + 4 * g;
+                            f32x4 v;
+                            v.x = fmaxf(acc[i][j][4 * q + 0] + bv[i][q].x, 0.f);
+                            v.y = fmaxf(acc[i][j][4 * q + 1] + bv[i][q].y, 0.f);
+                            v.z = fmaxf(acc[i][j][4 * q + 2] + bv[i][q].z, 0.f);
+                            v.w = fmaxf(acc[i][j][4 * q + 3] + bv[i][q].w, 0.f);
+                            *(f32x4*)(y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
+                        }
+                    }
+                }
+            }
+            // this workgroup's stores of layer li feed its own loads of layer li+1
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+}
+
+int launch_fused(const FusedArgs& a, hipStream_t st) {
+    int cus = 256;
+    static int cached = 0;
+    if (!cached) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cached = prop.multiProcessorCount;
+        else
+            cached = 256;
+    }
+    cus = cached;
+    const int grid = a.m_tiles < cus ? a.m_tiles : cus;
+    const size_t lds = 2 * (size_t)(kRowTile + 256) * 16 * sizeof(float);
+    hipLaunchKernelGGL(k_mlp_fused, dim3(grid), dim3(512), lds, st, a);
+    return check_launch("k_mlp_fused");
+}
+
 inline int stage_mode() {  // MOFA_STAGE=reg selects the register-staged A/B arm; default is LDS-DMA
     const char* e = getenv("MOFA_STAGE");
     return (e && e[0] == 'r') ? 0 : 1;
@@ -632,6 +805,28 @@ int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops) {
     *total_ms = ms, *launches = (int64_t)g_prof.used, *padded_flops = g_prof.flops;
     g_prof.used = 0;
     return MOFA_OK;
+}
+
+// internal (used by mofa_net.hip): run a list of MFMA layers of one network (all widths <= 256) as ONE persistent launch
+int mofa_internal_fused_forward(const float* arena, float* arena_w, const float* packed, const float* folded,
+                                const float* view_bias_rows, long long bias_rows, const float* rays_o, const float* rays_d,
+                                const float* z, long long z_row_stride, const float* pts, long long n_points, int S,
+                                long long m_padded, int n_layers, const long long* x1_off, const long long* x2_off,
+                                const long long* y_off, const long long* w_off, const long long* bias_off, const int* k1p,
+                                const int* k2p, const int* n_padded, const int* bias_row_div, void* stream) {
+    MOFA_REQUIRE(n_layers > 0 && n_layers <= kMaxFusedLayers, "fused_forward: %d layers (max %d)", n_layers, kMaxFusedLayers);
+    MOFA_REQUIRE(m_padded > 0 && m_padded % kRowTile == 0, "fused_forward: m_padded=%lld", m_padded);
+    FusedArgs a{};
+    a.arena = arena, a.arena_w = arena_w, a.packed = packed, a.folded = folded, a.view_bias_rows = view_bias_rows;
+    a.rays_o = rays_o, a.rays_d = rays_d, a.z = z, a.pts = pts;
+    a.z_row_stride = z_row_stride, a.n_points = n_points, a.m_padded = m_padded, a.bias_rows = bias_rows;
+    a.S = S > 0 ? S : 1, a.n_layers = n_layers, a.m_tiles = (int)(m_padded / kRowTile);
+    for (int i = 0; i < n_layers; ++i) {
+        MOFA_REQUIRE(n_padded[i] > 0 && n_padded[i] <= 256 && n_padded[i] % 64 == 0, "fused_forward: layer %d has n_padded=%d", i,
+                     n_padded[i]);
+        a.L[i] = FusedLayer{x1_off[i], x2_off[i], y_off[i], w_off[i], bias_off[i], k1p[i], k2p[i], n_padded[i], bias_row_div[i]};
+    }
+    return launch_fused(a, (hipStream_t)stream);
 }
 
 // internal (used by mofa_net.hip)

@@ -2,6 +2,7 @@
 // launch sequence of one run_network call (models/render_class.py:69-94 + models/model.py:121-137).
 // Pure launch code: no allocation, no host synchronisation, every buffer is the caller's.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <utility>
@@ -15,6 +16,12 @@ int mofa_internal_fold_bias(const float* w, int n_out, int ld, int col0, int nco
 int mofa_internal_dense_rows(const float* w, int n_out, int ld, int col0, int ncols, float* dst, int k_padded,
                              void* stream);
 int mofa_internal_raw_colsum(const float* d_raw, long long n_points, int off, int n, float* out, void* stream);
+int mofa_internal_fused_forward(const float* arena, float* arena_w, const float* packed, const float* folded,
+                                const float* view_bias_rows, long long bias_rows, const float* rays_o, const float* rays_d,
+                                const float* z, long long z_row_stride, const float* pts, long long n_points, int S,
+                                long long m_padded, int n_layers, const long long* x1_off, const long long* x2_off,
+                                const long long* y_off, const long long* w_off, const long long* bias_off, const int* k1p,
+                                const int* k2p, const int* n_padded, const int* bias_row_div, void* stream);
 int mofa_layer_backward_data(const float* g, int32_t g_k, const float* wt_packed, const float* mask, int32_t accumulate,
                              float* dx, int64_t m_padded, int32_t k_out_padded, void* stream);
 int mofa_pack_panels_t(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, float* dst,
@@ -271,63 +278,96 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     auto slot = [&](int li, float* fallback) -> float* {
         return tape ? tape + (size_t)Mp * p.L[li].tape_cols : fallback;
     };
-    auto run = [&](int li, const float* x1, const float* x2, float* y) -> int {
-        const Layer& l = p.L[li];
-        return mofa_layer_forward(x1, l.k_padded[0], x2, x2 ? l.k_padded[1] : 0, packed + l.packed_off,
-                                  folded + l.folded_off, 0, 1, y, Mp, l.n_padded, 1, stream);
+    // ---- the MFMA layers in execution order: (layer, inputs, output) -------------------------------------------
+    struct Step {
+        int li;
+        const float* x1;
+        const float* x2;
+        float* y;
     };
-    int rc;
-    // xyzEncode
-    float* xyz;
-    {
-        const Layer& l = p.L[p.xyz0];
-        float* y0 = slot(p.xyz0, t0);
-        MOFA_TRY(mofa_layer0_forward(rays_o, rays_d, z, z_row_stride, pts, M, S, packed + l.packed_off,
-                                     folded + l.folded_off, y0, Mp, l.n_padded, stream));
-        float* y1 = slot(p.xyz0 + 1, t1);
-        MOFA_TRY(run(p.xyz0 + 1, y0, nullptr, y1));
-        float* y2 = slot(p.xyz0 + 2, t0);
-        MOFA_TRY(run(p.xyz0 + 2, y1, nullptr, y2));
-        xyz = slot(p.xyz0 + 3, bufA);
-        MOFA_TRY(run(p.xyz0 + 3, y2, nullptr, xyz));
-    }
+    std::vector<Step> steps;
+    steps.reserve(p.L.size());
+    float* y0 = slot(p.xyz0, t0);
+    steps.push_back({p.xyz0, nullptr, nullptr, y0});                       // layer 0: positional encoding prologue
+    float* y1 = slot(p.xyz0 + 1, t1);
+    steps.push_back({p.xyz0 + 1, y0, nullptr, y1});
+    float* y2 = slot(p.xyz0 + 2, t0);
+    steps.push_back({p.xyz0 + 2, y1, nullptr, y2});
+    float* xyz = slot(p.xyz0 + 3, bufA);
+    steps.push_back({p.xyz0 + 3, y2, nullptr, xyz});
     // one conditioned skipMLP: x -> linears1 (5 layers) -> [x | h] -> linears2 (D-5 layers) -> out
-    auto cond = [&](int first, int skip, const float* x, float* out_fb, float* pa, float* pb, float** out) -> int {
+    auto cond = [&](int first, int skip, const float* x, float* out_fb, float* pa, float* pb) -> float* {
         const float* cur = x;
         float* pp[2] = {pa, pb};
         int w = 0;
         for (int li = first; li < skip; ++li) {
             float* y = slot(li, pp[w]);
-            MOFA_TRY(run(li, cur, nullptr, y));
+            steps.push_back({li, cur, nullptr, y});
             cur = y, w ^= 1;
         }
         const int last = skip + (s.D - 5) - 1;
         for (int li = skip; li <= last; ++li) {
             float* y = slot(li, (li == last) ? out_fb : pp[w]);
-            MOFA_TRY(run(li, li == skip ? x : cur, li == skip ? cur : nullptr, y));
+            steps.push_back({li, li == skip ? x : cur, li == skip ? cur : nullptr, y});
             cur = y, w ^= 1;
         }
-        *out = const_cast<float*>(cur);
-        return MOFA_OK;
+        return const_cast<float*>(cur);
     };
-    float *sigma = nullptr, *rgbc = nullptr;
-    MOFA_TRY(cond(p.bim0, p.bim_skip, xyz, bufB, t0, t1, &sigma));
+    float* sigma = cond(p.bim0, p.bim_skip, xyz, bufB, t0, t1);
+    float* rgbc = cond(p.uv0, p.uv_skip, sigma, bufA, t0, t1);  // without a tape rgbCodes reuses xyz_code's buffer
+    float* v = slot(p.view, t0);
+    steps.push_back({p.view, rgbc, nullptr, v});
+
+    int rc;
+    if (!view_bias_rows) {
+        // per-ray bias b + W[:, :27] @ PE(viewdir) from the ORIGINAL (unpacked) view-layer tensors
+        const Layer& l = p.L[p.view];
+        MOFA_TRY(mofa_view_bias(viewdirs, n_rays, view_w, l.n_out, l.ld, view_b, vbias, l.n_padded, stream));
+        view_bias_rows = vbias;
+    }
+    // ---- dispatch: one persistent launch for widths <= 256 (every layer of a point tile lives in one workgroup), else
+    //      one launch per layer.  MOFA_FUSED=0/1 overrides the heuristic (tests / A-B).
+    const char* fused_env = getenv("MOFA_FUSED");
+    const bool fused = p.Wp <= 256 && (fused_env ? fused_env[0] == '1' : Mp / kRowTile >= 128);
+    if (fused) {
+        const float* arena = tape ? tape : workspace;
+        const int n = (int)steps.size();
+        std::vector<long long> x1(n), x2(n), yo(n), wo(n), bo(n);
+        std::vector<int> k1(n), k2(n), np(n), div(n);
+        for (int i = 0; i < n; ++i) {
+            const Layer& l = p.L[steps[i].li];
+            x1[i] = steps[i].x1 ? steps[i].x1 - arena : -1;
+            x2[i] = steps[i].x2 ? steps[i].x2 - arena : 0;
+            yo[i] = steps[i].y - arena;
+            wo[i] = (long long)l.packed_off;
+            const bool view = steps[i].li == p.view;
+            bo[i] = view ? 0 : (long long)l.folded_off;
+            k1[i] = l.k_padded[0] / 16, k2[i] = steps[i].x2 ? l.k_padded[1] / 16 : 0;
+            np[i] = l.n_padded, div[i] = view ? S : 0;
+        }
+        MOFA_TRY(mofa_internal_fused_forward(arena, const_cast<float*>(arena), packed, folded, view_bias_rows, n_rays, rays_o,
+                                             rays_d, z, z_row_stride, pts, M, S, Mp, n, x1.data(), x2.data(), yo.data(),
+                                             wo.data(), bo.data(), k1.data(), k2.data(), np.data(), div.data(), stream));
+    } else {
+        for (const Step& st : steps) {
+            const Layer& l = p.L[st.li];
+            if (!st.x1) {
+                MOFA_TRY(mofa_layer0_forward(rays_o, rays_d, z, z_row_stride, pts, M, S, packed + l.packed_off,
+                                             folded + l.folded_off, st.y, Mp, l.n_padded, stream));
+            } else if (st.li == p.view) {
+                MOFA_TRY(mofa_layer_forward(st.x1, l.k_padded[0], nullptr, 0, packed + l.packed_off, view_bias_rows, S,
+                                            n_rays, st.y, Mp, l.n_padded, 1, stream));
+            } else {
+                MOFA_TRY(mofa_layer_forward(st.x1, l.k_padded[0], st.x2, st.x2 ? l.k_padded[1] : 0, packed + l.packed_off,
+                                            folded + l.folded_off, 0, 1, st.y, Mp, l.n_padded, 1, stream));
+            }
+        }
+    }
+    // ---- heads: sigma from sigmaCodes, rgb from the view layer's output ------------------------------------------
     {
         const Layer& l = p.L[p.alpha];
         MOFA_TRY(mofa_head_forward(sigma, l.k_padded[0], Mp, packed + l.packed_off, folded + l.folded_off, 1, raw_out,
                                    3, M, stream));
-    }
-    MOFA_TRY(cond(p.uv0, p.uv_skip, sigma, bufA, t0, t1, &rgbc));  // without a tape rgbCodes reuses xyz_code's buffer
-    {
-        const Layer& l = p.L[p.view];
-        if (!view_bias_rows) {
-            // per-ray bias b + W[:, :27] @ PE(viewdir) from the ORIGINAL (unpacked) view-layer tensors
-            MOFA_TRY(mofa_view_bias(viewdirs, n_rays, view_w, l.n_out, l.ld, view_b, vbias, l.n_padded, stream));
-            view_bias_rows = vbias;
-        }
-        float* v = slot(p.view, t0);
-        MOFA_TRY(mofa_layer_forward(rgbc, l.k_padded[0], nullptr, 0, packed + l.packed_off, view_bias_rows, S, n_rays, v,
-                                    Mp, l.n_padded, 1, stream));
         const Layer& r = p.L[p.rgb];
         MOFA_TRY(mofa_head_forward(v, r.k_padded[0], Mp, packed + r.packed_off, folded + r.folded_off, 3, raw_out, 0,
                                    M, stream));

@@ -362,3 +362,35 @@ def test_layer_pipeline_race_screen_full_size():
     wd = w[widx]
     want = torch.relu(xr.double() @ wd.double().T + b.double()).float()
     nan_equal_close(yr.cpu().numpy(), want.cpu().numpy(), 3e-5)
+
+
+@pytest.mark.parametrize("D,W,R,S", [(8, 256, 40, 64), (10, 96, 9, 128), (8, 64, 130, 64), (8, 192, 17, 32)])
+def test_persistent_fused_network_is_bit_identical_to_per_layer_launches(D, W, R, S, monkeypatch):
+    """Widths <= 256 run the whole MLP as ONE persistent launch (k_mlp_fused); it must reproduce the per-layer path
+    bit for bit, in inference mode (recycled buffers) and in tape mode (every layer output kept)."""
+    from mofanerf_amd.autograd import NetFn, fold_torch, view_bias_torch
+    from mofanerf_amd.hipnet import HipNet
+    from mofanerf_amd.model import NeRF
+    rng = np.random.default_rng(D + W + R)
+    net = NeRF(D=D, W=W, input_ch=93, input_ch_views=27, input_ch_textureCodes=256, input_ch_shapeCodes=50,
+               use_viewdirs=True)
+    net.load_state_dict(synth.nerf_state(D, W, 1))
+    h = HipNet(net.to(DEV))
+    o = dev(rng.uniform(-2, 2, (R, 3)).astype(np.float32))
+    d = dev(rng.normal(0, 0.3, (R, 3)).astype(np.float32))
+    z = dev(np.sort(rng.uniform(8, 26, (R, S)).astype(np.float32), -1))
+    vd = torch.nn.functional.normalize(d, dim=-1).contiguous()
+    bm, tex, e = synth.codes(3)
+    folded = h.fold(e.to(DEV), bm.to(DEV), tex.to(DEV)).clone()
+    outs, tapes = {}, {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MOFA_FUSED", mode)
+        raw = torch.full((R, S, 4), float("nan"), device=DEV)
+        h.forward_rays(o, d, z, S, vd, S, raw, folded)
+        outs[mode] = raw.clone()
+        with torch.enable_grad():
+            tapes[mode] = NetFn.apply(h, o, d, z, S, S, folded, view_bias_torch(h, vd).detach()).detach().clone()
+        torch.cuda.synchronize()
+    assert torch.equal(outs["0"], outs["1"]) and torch.isfinite(outs["1"]).all()
+    assert torch.equal(tapes["0"], tapes["1"])
+    nan_equal_close(tapes["1"].cpu().numpy(), outs["1"].cpu().numpy(), 2e-5)
