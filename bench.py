@@ -55,17 +55,6 @@ def flops_per_ray(folded=True):
                 (N_SAMPLES + N_IMPORTANCE) * schema.mac_per_point(Df, Wf, folded))
 
 
-def layer_kernel_flops_per_ray():
-    """Algorithmic FLOPs executed by the dominant kernel (all Linear layers except layer 0 — its own kernel variant —
-    and the two small heads), per ray."""
-    Dc, Wc, Df, Wf = ARCH
-    tot = 0
-    for (D, Wd, S) in ((Dc, Wc, N_SAMPLES), (Df, Wf, N_SAMPLES + N_IMPORTANCE)):
-        mac = schema.mac_per_point(D, Wd, True) - 63 * Wd - Wd - 3 * (Wd // 2)
-        tot += 2 * S * mac
-    return tot
-
-
 def build_product(device, seed=0):
     Dc, Wc, Df, Wf = ARCH
     args = factory.default_args(netdepth=Dc, netwidth=Wc, netdepth_fine=Df, netwidth_fine=Wf, no_reload=True,
@@ -180,16 +169,21 @@ def main():
         frame = step(a.warmup + i)
     sync()
     dt = time.perf_counter() - t0
-    ms, launches, pflops = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-    lib.check(L.mofa_prof_end(ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(pflops)), "mofa_prof_end")
+    ms2, launches2, pflops2 = (ctypes.c_double * 2)(), (ctypes.c_int64 * 2)(), (ctypes.c_double * 2)()
+    lib.check(L.mofa_prof_end(ms2, launches2, pflops2), "mofa_prof_end")
     dt = mdist.barrier_max(dt, dev)
     assert frame.shape == (n_total, 5) and bool(torch.isfinite(frame[:, :3]).all())
 
     if rank == 0:
         rays_per_s = n_total * a.steps / dt
-        my_rays = (e - b) * a.steps
-        alg_flops = layer_kernel_flops_per_ray() * my_rays               # algorithmic work of this rank's k_layer launches
-        achieved = alg_flops / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        # dominant kernel = the one with the larger summed time: [0] per-layer MFMA kernel, [1] persistent network kernel.
+        # Its algorithmic FLOPs are 2*M*K*N of its launches; at the benchmark sizes nothing is padded (K, N multiples of 64,
+        # M a multiple of 256), except layer 0's K = 63 -> 64 inside the persistent kernel (0.1 %).
+        dom = 0 if ms2[0] >= ms2[1] else 1
+        kname = ["mofa::k_layer<128,false,true> (fp32 MFMA Linear+bias+ReLU)",
+                 "mofa::k_mlp_fused (persistent fp32-MFMA network kernel, widths <= 256)"][dom]
+        ms_dom, launches_dom, alg_flops = ms2[dom], launches2[dom], pflops2[dom]
+        achieved = alg_flops / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
         traffic, tinfo = None, {}
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")       # PMC-derived bytes/launch (separate --pmc passes)
         if os.path.exists(tpath):
@@ -208,13 +202,16 @@ def main():
                        "gflop_per_ray_folded": round(flops_per_ray(True) / 1e9, 4),
                        "gflop_per_ray_nominal": round(flops_per_ray(False) / 1e9, 4)},
             "whole_path_tflops": round(flops_per_ray(True) * rays_per_s / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": "mofa::k_layer<128,false,true> (fp32 MFMA Linear+bias+ReLU)",
+            "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "launches": int(launches.value),
-                         "avg_launch_ms": round(ms.value / max(1, launches.value), 4),
-                         "algorithmic_gflop_per_launch": round(alg_flops / max(1, launches.value) / 1e9, 3),
-                         "padded_over_algorithmic": round(pflops.value / alg_flops, 4) if alg_flops else None, **tinfo},
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic if dom == 0 else None,
+                         "launches": int(launches_dom), "avg_launch_ms": round(ms_dom / max(1, launches_dom), 4),
+                         "algorithmic_gflop_per_launch": round(alg_flops / max(1, launches_dom) / 1e9, 3),
+                         "share_of_timed_region": round(ms_dom * 1e-3 / dt, 4),
+                         "other_network_kernel": {"kernel": ["k_layer<128,false,true>", "k_mlp_fused"][1 - dom],
+                                                  "launches": int(launches2[1 - dom]), "total_ms": round(ms2[1 - dom], 2),
+                                                  "tflops": round(pflops2[1 - dom] / (ms2[1 - dom] * 1e-3) / 1e12, 2) if ms2[1 - dom] > 0 else None},
+                         **(tinfo if dom == 0 else {})},
         }
         if world == 1 and a.cpu_rays > 0:
             out["cpu_baseline"] = cpu_baseline(a.cpu_rays)

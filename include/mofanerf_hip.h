@@ -162,9 +162,10 @@ int mofa_view_bias(const float* viewdirs, int64_t n_rays, const float* w, int32_
 int mofa_positional_encode(const float* x, int64_t n, int32_t n_freqs, float* out, void* stream);
 
 /* ---- measurement hook ------------------------------------------------------------------------
- * Between mofa_prof_begin() and mofa_prof_end() every launch of the dominant kernel (the BN=128 MFMA layer kernel)
- * is bracketed by hipEventRecord on its own stream.  mofa_prof_end() synchronises those events (host blocks) and
- * returns the summed kernel time, the launch count and the padded FLOPs they executed.  Used by bench.py only. */
+ * Between mofa_prof_begin() and mofa_prof_end() every launch of the two MFMA network kernels — [0] the per-layer kernel
+ * k_layer<128,false,*> and [1] the persistent whole-network kernel k_mlp_fused (widths <= 256) — is bracketed by
+ * hipEventRecord on its own stream.  mofa_prof_end() synchronises those events (host blocks) and fills three arrays of
+ * length 2: summed kernel time, launch count, padded FLOPs executed.  Used by bench.py only. */
 int mofa_prof_begin(void);
 int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops);
 

@@ -616,10 +616,28 @@ inline int stage_mode() {  // MOFA_STAGE=reg selects the register-staged A/B arm
 struct ProfState {
     bool on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    std::vector<int> kind;     // 0: k_layer<128,false,*> launch, 1: k_mlp_fused launch
     size_t used = 0;
-    double flops = 0.0;
+    double flops[2] = {0.0, 0.0};
 };
 ProfState g_prof;
+
+inline int prof_open(hipStream_t st, int kind) {
+    if (g_prof.used == g_prof.ev.size()) {
+        hipEvent_t e0, e1;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return check_launch("hipEventCreate");
+        g_prof.ev.emplace_back(e0, e1);
+        g_prof.kind.push_back(kind);
+    }
+    g_prof.kind[g_prof.used] = kind;
+    (void)hipEventRecord(g_prof.ev[g_prof.used].first, st);
+    return MOFA_OK;
+}
+inline void prof_close(hipStream_t st, int kind, double flops) {
+    (void)hipEventRecord(g_prof.ev[g_prof.used].second, st);
+    g_prof.used++;
+    g_prof.flops[kind] += flops;
+}
 
 template <int BN, bool L0, bool BWD = false>
 int launch_layer(LayerArgs a, hipStream_t st) {
@@ -631,25 +649,14 @@ int launch_layer(LayerArgs a, hipStream_t st) {
     const unsigned grid = (unsigned)round_up(total, 8);
     const size_t lds = 2 * (size_t)(kRowTile + BN) * 16 * sizeof(float);
     const bool prof = g_prof.on && BN == 128 && !L0 && !BWD;
-    if (prof) {
-        if (g_prof.used == g_prof.ev.size()) {
-            hipEvent_t e0, e1;
-            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return check_launch("hipEventCreate");
-            g_prof.ev.emplace_back(e0, e1);
-        }
-        (void)hipEventRecord(g_prof.ev[g_prof.used].first, st);
-    }
+    if (prof && prof_open(st, 0) != MOFA_OK) return MOFA_EHIP;
     if constexpr (BWD)
         hipLaunchKernelGGL((k_layer<BN, false, true, true>), dim3(grid), dim3(256), lds, st, a);
     else if (stage_mode())
         hipLaunchKernelGGL((k_layer<BN, L0, true>), dim3(grid), dim3(256), lds, st, a);
     else
         hipLaunchKernelGGL((k_layer<BN, L0, false>), dim3(grid), dim3(256), lds, st, a);
-    if (prof) {
-        (void)hipEventRecord(g_prof.ev[g_prof.used].second, st);
-        g_prof.used++;
-        g_prof.flops += 2.0 * (double)a.m_padded * (double)a.n_padded * 16.0 * (double)(a.k1p + a.k2p);
-    }
+    if (prof) prof_close(st, 0, 2.0 * (double)a.m_padded * (double)a.n_padded * 16.0 * (double)(a.k1p + a.k2p));
     return check_launch(BWD ? "k_layer<BWD>" : (L0 ? "k_layer<L0>" : "k_layer"));
 }
 
@@ -787,22 +794,23 @@ int mofa_positional_encode(const float* x, int64_t n, int32_t n_freqs, float* ou
 }
 
 int mofa_prof_begin(void) {
-    g_prof.on = true, g_prof.used = 0, g_prof.flops = 0.0;
+    g_prof.on = true, g_prof.used = 0, g_prof.flops[0] = g_prof.flops[1] = 0.0;
     return MOFA_OK;
 }
 
+/* arrays of 2: [0] = the per-layer MFMA kernel k_layer<128,false,*>, [1] = the persistent kernel k_mlp_fused */
 int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops) {
     MOFA_REQUIRE(total_ms && launches && padded_flops, "prof_end: null pointer");
     g_prof.on = false;
-    double ms = 0.0;
+    total_ms[0] = total_ms[1] = 0.0, launches[0] = launches[1] = 0;
     for (size_t i = 0; i < g_prof.used; ++i) {
         if (hipEventSynchronize(g_prof.ev[i].second) != hipSuccess) return check_launch("hipEventSynchronize");
         float t = 0.f;
         if (hipEventElapsedTime(&t, g_prof.ev[i].first, g_prof.ev[i].second) != hipSuccess)
             return check_launch("hipEventElapsedTime");
-        ms += (double)t;
+        total_ms[g_prof.kind[i]] += (double)t, launches[g_prof.kind[i]] += 1;
     }
-    *total_ms = ms, *launches = (int64_t)g_prof.used, *padded_flops = g_prof.flops;
+    padded_flops[0] = g_prof.flops[0], padded_flops[1] = g_prof.flops[1];
     g_prof.used = 0;
     return MOFA_OK;
 }
@@ -826,7 +834,14 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
                      n_padded[i]);
         a.L[i] = FusedLayer{x1_off[i], x2_off[i], y_off[i], w_off[i], bias_off[i], k1p[i], k2p[i], n_padded[i], bias_row_div[i]};
     }
-    return launch_fused(a, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (!g_prof.on) return launch_fused(a, st);
+    double flops = 0.0;
+    for (int i = 0; i < n_layers; ++i) flops += 2.0 * (double)m_padded * (double)n_padded[i] * 16.0 * (double)(k1p[i] + k2p[i]);
+    if (prof_open(st, 1) != MOFA_OK) return MOFA_EHIP;
+    const int rc = launch_fused(a, st);
+    prof_close(st, 1, flops);
+    return rc;
 }
 
 // internal (used by mofa_net.hip)
