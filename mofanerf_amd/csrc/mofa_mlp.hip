@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void k_positional_encode(const float* __restri
 
 // ======================================================================================================
 // Persistent whole-network kernel for widths <= 256 (coarse net; fine net of the 256x8 variant).
-// One workgroup (8 waves) owns ALL features of a 256-point tile, so consecutive layers of that tile depend only on
+// One workgroup owns ALL features of a 128-point half tile, so consecutive layers of that tile depend only on
 // this workgroup's own stores: the 2D+5 MFMA layers run back to back in ONE launch (no per-layer launch ramp/tail, no
 // inter-workgroup synchronisation), each workgroup looping over its point tiles.  Same panels, same LDS-DMA pipeline and
 // bit-identical arithmetic as k_layer; activations still round-trip through (L2-resident) global panels because a
@@ -465,21 +465,24 @@ struct FusedArgs {
     FusedLayer L[kMaxFusedLayers];
 };
 
-__global__ __launch_bounds__(512, 2) void k_mlp_fused(const FusedArgs a) {
+__global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int BM = kRowTile, BNMAX = 256, NI = 2, NJ = 4;
-    constexpr int STAGE = (BM + BNMAX) * 16;
+    // 4 waves side by side over the (<= 256) features, each 64 features x 128 points (8 accumulators of 32x32): a workgroup
+    // owns ALL features of a 128-point half tile.  48 KiB of LDS and <= 256 VGPRs -> two INDEPENDENT workgroups per CU, so
+    // one's barrier / LDS-latency bubbles hide under the other's MFMAs (an 8-wave, 256-point variant measured 2 % slower).
+    constexpr int TM = 128, BNMAX = 256, NI = 2, NJ = 4;
+    constexpr int STAGE = (TM + BNMAX) * 16;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 3, wm = wave >> 2;          // 4 (features) x 2 (points) waves, wave tile 64 x 128
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, g = lane >> 5;
+    const int half_tiles = a.m_tiles * 2;
 
-    for (int mt = blockIdx.x; mt < a.m_tiles; mt += gridDim.x) {
-        const long long m0 = (long long)mt * BM;
-        // layer 0: threads 0..255 own one point row each
+    for (int ht = blockIdx.x; ht < half_tiles; ht += gridDim.x) {
+        const long long m0 = (long long)ht * TM;
+        // layer 0: thread t generates features [8*(t>>7), +8) of each 16-wide panel for point row t & 127
         float px = 0.f, py = 0.f, pz = 0.f;
-        if (tid < BM) {
-            long long m = m0 + tid;
+        {
+            long long m = m0 + (tid & (TM - 1));
             if (m >= a.n_points) m = a.n_points - 1;
             if (a.pts) {
                 px = a.pts[m * 3 + 0], py = a.pts[m * 3 + 1], pz = a.pts[m * 3 + 2];
@@ -502,27 +505,26 @@ __global__ __launch_bounds__(512, 2) void k_mlp_fused(const FusedArgs a) {
 
             auto stage_issue = [&](int buf, int kt) {
                 float* xs = smem + buf * STAGE;
-                float* ws = xs + BM * 16;
+                float* ws = xs + TM * 16;
                 if (l0) {
-                    if (tid < BM) {
-                        const int swz = (tid >> 2) & 3;
+                    const int row = tid & (TM - 1), k0 = (tid >> 7) * 8;
+                    const int swz = (row >> 2) & 3;
 #pragma unroll 1
-                        for (int kk = 0; kk < 16; ++kk) {
-                            const float v = pe_feature(kt * 16 + kk, px, py, pz, 3 + 6 * MOFA_PE_POINT_FREQS);
-                            xs[tid * 16 + ((((kk >> 2) & 3) ^ swz) << 2) + (kk & 3)] = v;
-                        }
+                    for (int kk = k0; kk < k0 + 8; ++kk) {
+                        const float v = pe_feature(kt * 16 + kk, px, py, pz, 3 + 6 * MOFA_PE_POINT_FREQS);
+                        xs[row * 16 + ((((kk >> 2) & 3) ^ swz) << 2) + (kk & 3)] = v;
                     }
                 } else {
                     const float* src = (kt < l.k1p ? a.arena + l.x1_off + ((long long)kt * a.m_padded + m0) * 16
                                                    : a.arena + l.x2_off + ((long long)(kt - l.k1p) * a.m_padded + m0) * 16);
 #pragma unroll
-                    for (int r = 0; r < 2; ++r) glds16(src + (r * 512 + tid) * 4, xs + (r * 512 + wave * 64) * 4);
+                    for (int r = 0; r < 2; ++r) glds16(src + (r * 256 + tid) * 4, xs + (r * 256 + wn * 64) * 4);
                 }
                 const float* wsrc = wbase + (long long)kt * np * 16;
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
-                    if ((r * 512 + wave * 64) * 4 < np * 16)   // wave-uniform guard for layers narrower than 256
-                        glds16(wsrc + (r * 512 + tid) * 4, ws + (r * 512 + wave * 64) * 4);
+                for (int r = 0; r < 4; ++r)
+                    if ((r * 256 + wn * 64) * 4 < np * 16)   // wave-uniform guard for layers narrower than 256
+                        glds16(wsrc + (r * 256 + tid) * 4, ws + (r * 256 + wn * 64) * 4);
             };
 
             f32x16 acc[NI][NJ];
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_fused(const FusedArgs a) {
                 const int cur = kt & 1;
                 if (kt + 1 < KT) stage_issue(cur ^ 1, kt + 1);
                 const float* xs = smem + cur * STAGE;
-                if (active) mma_panel<NI, NJ>(xs, xs + BM * 16, wm * 128, wn * 64, lane, acc);
+                if (active) mma_panel<NI, NJ>(xs, xs + TM * 16, 0, wn * 64, lane, acc);
                 __syncthreads();
             }
             if (active) {
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_fused(const FusedArgs a) {
                 }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const long long m = m0 + wm * 128 + 32 * j + lr;
+                    const long long m = m0 + 32 * j + lr;
                     if (l.bias_row_div) {
                         long long brow = m / l.bias_row_div;
                         if (brow >= a.bias_rows) brow = a.bias_rows - 1;
@@ -589,20 +591,19 @@ __global__ __launch_bounds__(512, 2) void k_mlp_fused(const FusedArgs a) {
 }
 
 int launch_fused(const FusedArgs& a, hipStream_t st) {
-    int cus = 256;
-    static int cached = 0;
-    if (!cached) {
+    static int cus = 0;
+    if (!cus) {
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            cached = prop.multiProcessorCount;
-        else
-            cached = 256;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+               prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount
+                  : 256;
     }
-    cus = cached;
-    const int grid = a.m_tiles < cus ? a.m_tiles : cus;
-    const size_t lds = 2 * (size_t)(kRowTile + 256) * 16 * sizeof(float);
-    hipLaunchKernelGGL(k_mlp_fused, dim3(grid), dim3(512), lds, st, a);
+    const int half_tiles = a.m_tiles * 2;
+    const int grid = half_tiles < 2 * cus ? half_tiles : 2 * cus;      // two resident workgroups per CU
+    const size_t lds = 2 * (size_t)(128 + 256) * 16 * sizeof(float);   // 48 KiB
+    hipLaunchKernelGGL(k_mlp_fused, dim3(grid), dim3(256), lds, st, a);
     return check_launch("k_mlp_fused");
 }
 
