@@ -92,7 +92,18 @@ int mofa_net_fold(MofaNetShape s, const float* const* weights, const float* cons
 int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, const float* view_w,
                      const float* view_b, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
                      const float* pts, const float* viewdirs, int64_t n_rays, int32_t S, float* workspace,
-                     float* raw_out, float* tape, const float* view_bias_rows, void* stream);
+                     float* raw_out, float* tape, const float* view_bias_rows, const uint16_t* packed_split,
+                     int32_t split_pieces, void* stream);
+/* packed_split / split_pieces: NULL / 0 for the shipped exact-fp32 path.  OPT-IN (MOFA_GEMM=bf16x3|bf16x6): weights
+ * pre-split into `split_pieces` (2 or 3) bf16 planes by mofa_net_pack_split; layers whose width is a multiple of 128
+ * then run k_layer_split (split-product emulation of the fp32 products on the bf16 matrix pipe, fp32 accumulation). */
+size_t mofa_net_packed_split_elems(MofaNetShape s, int32_t pieces);   /* uint16 elements */
+int mofa_net_pack_split(MofaNetShape s, const float* const* weights, uint16_t* dst, int32_t pieces, void* stream);
+int mofa_pack_split(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, uint16_t* dst,
+                    int32_t rows_padded, int32_t panel0, int32_t k_padded, int32_t pieces, void* stream);
+int mofa_layer_forward_split(const float* x1, int32_t k1, const float* x2, int32_t k2, const uint16_t* w_split,
+                             int32_t pieces, const float* bias, int32_t bias_row_div, int64_t bias_rows, float* y,
+                             int64_t m_padded, int32_t n_padded, int32_t relu, void* stream);
 
 /* ---- backward (run_fit.py:305-313 photometric fitting, run_train.py:333-357 training) -----------------------
  * Backward of mofa_net_forward given d_raw [n_rays,S,4] and the tape of that forward:

@@ -81,7 +81,7 @@ class NetFn(torch.autograd.Function):
         ws = h.workspace(R * S, R, dev)
         lib.check(L.mofa_net_forward(h.shape, lib.ptr(h.packed()), lib.ptr(fo), None, None, lib.ptr(ro), lib.ptr(rd),
                                      lib.ptr(zc), z_row_stride, None, None, R, S, lib.ptr(ws), lib.ptr(raw), lib.ptr(tape),
-                                     lib.ptr(vb), lib.stream()), "mofa_net_forward(tape)")
+                                     lib.ptr(vb), None, 0, lib.stream()), "mofa_net_forward(tape)")
         ctx.h, ctx.S, ctx.z_row_stride = h, S, z_row_stride
         ctx.save_for_backward(ro, rd, zc, tape)
         ctx.n_folded, ctx.vb_shape = fo.numel(), tuple(vb.shape)

@@ -607,6 +607,186 @@ int launch_fused(const FusedArgs& a, hipStream_t st) {
     return check_launch("k_mlp_fused");
 }
 
+// ======================================================================================================
+// OPT-IN split-product layer kernel (MOFA_GEMM=bf16x3 | bf16x6; default OFF — the shipped path is exact fp32 MFMA).
+// Every fp32 operand is split EXACTLY into bf16 pieces by truncation (a = a1 + a2 + a3, 8+8+8 significand bits) and the
+// product a*b is replaced by the partial products with piece index i + j <= P-1 on the 16x faster bf16 matrix pipe
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulation): P = 3 -> 6 products (drops terms < 2^-23 |ab|: fp32-equivalent,
+// measured 3.6e-7 on RGB, tools/split_precision_study.py), P = 2 -> 3 products (~2^-15 |ab|; 1.2e-5 on RGB).
+// Activations stay fp32 panels in HBM/LDS and are split in registers (5.5 VALU ops per element, hidden under the
+// other wave's MFMAs); weights are pre-split into P bf16 planes (mofa_net_pack_split).  Both operands use the same
+// (lane, element) -> k assignment, so the instruction's internal k ordering is irrelevant.  C/D layout = the fp32 kernel's.
+// ======================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct SplitArgs {
+    LayerArgs base;              // x1/x2/bias/y/... as for k_layer (base.w unused)
+    const unsigned short* ws;    // split weights: [panel][plane][n_padded][16] bf16, 16-B chunks swizzled by (row>>3)&1
+};
+
+__device__ __forceinline__ unsigned pack_hi16(unsigned x0, unsigned x1) { return __builtin_amdgcn_perm(x1, x0, 0x07060302u); }
+
+// 8 fp32 values -> P bf16x8 pieces (exact truncation split)
+template <int P>
+__device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, bf16x8 (&out)[P]) {
+    float r[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        u32x4 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = pack_hi16(__float_as_uint(r[2 * i]), __float_as_uint(r[2 * i + 1]));
+        out[p] = __builtin_bit_cast(bf16x8, w);
+        if (p + 1 < P) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = r[i] - __uint_as_float(__float_as_uint(r[i]) & 0xFFFF0000u);
+        }
+    }
+}
+
+template <int BN, int P>
+__global__ __launch_bounds__(256, 2) void k_layer_split(const SplitArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const LayerArgs& a = sa.base;
+    constexpr int BM = kRowTile;
+    constexpr int WAVES_N = BN / 64, WAVES_M = 4 / WAVES_N;
+    constexpr int NI = 2, NJ = (BM / WAVES_M) / 32;
+    constexpr int WPLANE = BN * 8;                       // floats (= BN rows x 32 B) of one weight plane tile
+    constexpr int STAGE = BM * 16 + P * WPLANE;          // floats per pipeline stage
+    constexpr int XR = BM / 64;
+
+    const int per_xcd = gridDim.x >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= a.total_tiles) return;
+    const int mt = logical / a.n_tiles, nt = logical - mt * a.n_tiles;
+    const long long m0 = (long long)mt * BM;
+    const int n0 = nt * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WAVES_N, wm = wave / WAVES_N;
+    const int KT = a.k1p + a.k2p;
+    const int lr = lane & 31, g = lane >> 5, sw = (lane >> 2) & 3;
+
+    auto stage_issue = [&](int buf, int kt) {
+        float* xs = smem + buf * STAGE;
+        const float* src = (kt < a.k1p ? a.x1 + ((long long)kt * a.m_padded + m0) * 16
+                                       : a.x2 + ((long long)(kt - a.k1p) * a.m_padded + m0) * 16);
+#pragma unroll
+        for (int r = 0; r < XR; ++r) glds16(src + (r * 256 + tid) * 4, xs + (r * 256 + wave * 64) * 4);
+        // weight planes: BN rows x 32 B each = BN*8 floats; 256 threads x 16 B = 1024 floats per round
+        const float* wsrc = (const float*)(sa.ws + (((long long)kt * P) * a.n_padded + n0) * 16);
+        float* ws = xs + BM * 16;
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int r = 0; r < WPLANE / 1024; ++r)
+                glds16(wsrc + (long long)p * a.n_padded * 8 + (r * 256 + tid) * 4, ws + p * WPLANE + (r * 256 + wave * 64) * 4);
+    };
+
+    f32x16 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    stage_issue(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) stage_issue(cur ^ 1, kt + 1);
+        const float* xs = smem + cur * STAGE;
+        const float* ws = xs + BM * 16;
+        // weight fragments: lane (row, g) holds k = 8g .. 8g+7 of each plane (one 16-B read per plane)
+        bf16x8 wf[NI][P];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row = wn * 64 + 32 * i + lr;
+            const int chunk = g ^ ((row >> 3) & 1);
+#pragma unroll
+            for (int p = 0; p < P; ++p) wf[i][p] = *(const bf16x8*)(ws + p * WPLANE + row * 8 + chunk * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int row = wm * (32 * NJ) + 32 * j + lr;
+            const f32x4 lo = *(const f32x4*)(xs + row * 16 + (((2 * g) ^ sw) << 2));
+            const f32x4 hi = *(const f32x4*)(xs + row * 16 + (((2 * g + 1) ^ sw) << 2));
+            bf16x8 xf[P];
+            split8<P>(lo, hi, xf);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                // smallest partial products first
+#pragma unroll
+                for (int t = P - 1; t >= 0; --t)
+#pragma unroll
+                    for (int pw = 0; pw <= t; ++pw)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][pw], xf[t - pw], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue identical to k_layer's forward epilogue
+    f32x4 bv[NI][4];
+    int boff = n0 + wn * 64 + 4 * g;
+    asm volatile("" : "+v"(boff));
+    if (!a.bias_row_div) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(a.bias + boff + 32 * i + 8 * q);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const long long m = m0 + wm * (32 * NJ) + 32 * j + lr;
+        if (a.bias_row_div) {
+            long long brow = m / a.bias_row_div;
+            if (brow >= a.bias_rows) brow = a.bias_rows - 1;
+            const float* bias = a.bias + brow * a.n_padded + n0 + wn * 64 + 4 * g;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(bias + 32 * i + 8 * q);
+        }
+        const int msw = (int)(m >> 2) & 3;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + 32 * i + 8 * q + 4 * g;
+                f32x4 v;
+                v.x = acc[i][j][4 * q + 0] + bv[i][q].x;
+                v.y = acc[i][j][4 * q + 1] + bv[i][q].y;
+                v.z = acc[i][j][4 * q + 2] + bv[i][q].z;
+                v.w = acc[i][j][4 * q + 3] + bv[i][q].w;
+                if (a.relu) {
+                    v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                }
+                *(f32x4*)(a.y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
+            }
+        }
+    }
+}
+
+// weights -> P bf16 planes: dst[((panel0+panel)*P + plane)*rows_padded + row][16], chunk (k/8) swizzled by (row>>3)&1
+__global__ __launch_bounds__(256) void k_pack_split(const float* __restrict__ w, int n_out, int ld, int col0, int ncols,
+                                                    unsigned short* __restrict__ dst, int rows_padded, int panel0,
+                                                    int k_padded, int P) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;       // over rows_padded * k_padded
+    if (idx >= (long long)rows_padded * k_padded) return;
+    const int e = idx & 7, gph = (idx >> 3) & 1;
+    const long long rowpanel = idx >> 4;
+    const int row = (int)(rowpanel % rows_padded), panel = (int)(rowpanel / rows_padded);
+    const int k = panel * 16 + 8 * (gph ^ ((row >> 3) & 1)) + e;
+    float r = (row < n_out && k < ncols) ? w[(long long)row * ld + col0 + k] : 0.f;
+    for (int p = 0; p < P; ++p) {
+        const unsigned bits = __float_as_uint(r) & 0xFFFF0000u;
+        dst[(((long long)(panel0 + panel) * P + p) * rows_padded + row) * 16 + gph * 8 + e] = (unsigned short)(bits >> 16);
+        r = r - __uint_as_float(bits);
+    }
+}
+
 inline int stage_mode() {  // MOFA_STAGE=reg selects the register-staged A/B arm; default is LDS-DMA
     const char* e = getenv("MOFA_STAGE");
     return (e && e[0] == 'r') ? 0 : 1;
@@ -659,6 +839,22 @@ int launch_layer(LayerArgs a, hipStream_t st) {
         hipLaunchKernelGGL((k_layer<BN, L0, false>), dim3(grid), dim3(256), lds, st, a);
     if (prof) prof_close(st, 0, 2.0 * (double)a.m_padded * (double)a.n_padded * 16.0 * (double)(a.k1p + a.k2p));
     return check_launch(BWD ? "k_layer<BWD>" : (L0 ? "k_layer<L0>" : "k_layer"));
+}
+
+template <int P>
+int launch_layer_split(LayerArgs a, const unsigned short* ws, hipStream_t st) {
+    constexpr int BN = 128;
+    a.n_tiles = a.n_padded / BN;
+    const long long total = (a.m_padded / kRowTile) * a.n_tiles;
+    MOFA_REQUIRE(total > 0 && total < (1ll << 30), "layer_split: tile count %lld out of range", total);
+    a.total_tiles = (int)total;
+    SplitArgs sa{a, ws};
+    const size_t lds = 2 * (size_t)(kRowTile * 16 + P * BN * 8) * sizeof(float);
+    const bool prof = g_prof.on;
+    if (prof && prof_open(st, 0) != MOFA_OK) return MOFA_EHIP;
+    hipLaunchKernelGGL((k_layer_split<BN, P>), dim3((unsigned)round_up(total, 8)), dim3(256), lds, st, sa);
+    if (prof) prof_close(st, 0, 2.0 * (double)a.m_padded * (double)a.n_padded * 16.0 * (double)(a.k1p + a.k2p));
+    return check_launch("k_layer_split");
 }
 
 int dispatch_layer_bwd(LayerArgs a, hipStream_t st) {
@@ -752,6 +948,32 @@ int mofa_pack_panels_t(const float* w, int32_t n_out, int32_t ld, int32_t col0, 
     hipLaunchKernelGGL(k_pack_panels_t, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, w, n_out, ld, col0,
                        ncols, dst, rows_padded, k_padded);
     return check_launch("k_pack_panels_t");
+}
+
+/* OPT-IN split-product variant of mofa_layer_forward (pieces = 2: bf16x3, 3: bf16x6); w_split from mofa_pack_split. */
+int mofa_layer_forward_split(const float* x1, int32_t k1, const float* x2, int32_t k2, const uint16_t* w_split,
+                             int32_t pieces, const float* bias, int32_t bias_row_div, int64_t bias_rows, float* y,
+                             int64_t m_padded, int32_t n_padded, int32_t relu, void* stream) {
+    MOFA_REQUIRE(x1 && w_split && bias && y, "layer_forward_split: null pointer");
+    MOFA_REQUIRE(k1 > 0 && k1 % 16 == 0 && k2 >= 0 && k2 % 16 == 0 && (k2 == 0 || x2), "layer_forward_split: bad K");
+    MOFA_REQUIRE(n_padded % 128 == 0 && m_padded % kRowTile == 0 && (pieces == 2 || pieces == 3),
+                 "layer_forward_split: needs n_padded %% 128 == 0 and pieces in {2,3} (got %d, %d)", n_padded, pieces);
+    LayerArgs a{};
+    a.x1 = x1, a.x2 = x2, a.bias = bias, a.y = y;
+    a.k1p = k1 / 16, a.k2p = k2 / 16, a.n_padded = n_padded, a.m_padded = m_padded;
+    a.bias_row_div = bias_row_div, a.bias_rows = bias_rows, a.relu = relu;
+    return pieces == 3 ? launch_layer_split<3>(a, w_split, (hipStream_t)stream) : launch_layer_split<2>(a, w_split, (hipStream_t)stream);
+}
+
+int mofa_pack_split(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, uint16_t* dst,
+                    int32_t rows_padded, int32_t panel0, int32_t k_padded, int32_t pieces, void* stream) {
+    MOFA_REQUIRE(w && dst && (pieces == 2 || pieces == 3), "pack_split: bad arguments");
+    MOFA_REQUIRE(rows_padded >= n_out && k_padded % 16 == 0 && k_padded >= ncols && col0 >= 0 && col0 + ncols <= ld,
+                 "pack_split: bad shape");
+    const long long total = (long long)rows_padded * k_padded;
+    hipLaunchKernelGGL(k_pack_split, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, w, n_out, ld, col0, ncols,
+                       dst, rows_padded, panel0, k_padded, pieces);
+    return check_launch("k_pack_split");
 }
 
 int mofa_layer0_forward(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,

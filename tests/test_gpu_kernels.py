@@ -394,3 +394,66 @@ def test_persistent_fused_network_is_bit_identical_to_per_layer_launches(D, W, R
     assert torch.equal(outs["0"], outs["1"]) and torch.isfinite(outs["1"]).all()
     assert torch.equal(tapes["0"], tapes["1"])
     nan_equal_close(tapes["1"].cpu().numpy(), outs["1"].cpu().numpy(), 2e-5)
+
+
+@pytest.mark.parametrize("pieces,tol", [(3, 1.5e-5), (2, 2e-3)])
+@pytest.mark.parametrize("M,K,N,k2", [(512, 128, 128, 0), (1024, 1024, 256, 0), (777, 256, 128, 256)])
+def test_opt_in_split_product_layer(M, K, N, k2, pieces, tol):
+    """OPT-IN mode (default off): fp32 products emulated by bf16 partial products on the bf16 matrix pipe.
+    pieces=3 (bf16x6) must be fp32-equivalent; pieces=2 (bf16x3) ~2^-15 relative per product."""
+    rng = np.random.default_rng(M + K + N + pieces)
+    x = dev(rng.normal(size=(M, K)).astype(np.float32))
+    x2 = dev(rng.normal(size=(M, k2)).astype(np.float32)) if k2 else None
+    w = dev((rng.normal(size=(N, K + k2)) / np.sqrt(K + k2)).astype(np.float32))
+    b = dev(rng.normal(size=(N,)).astype(np.float32))
+    Mp = (M + 255) // 256 * 256
+    st = lib.stream()
+    p1 = torch.empty(L().mofa_panel_floats(Mp, K), device=DEV)
+    lib.check(L().mofa_to_panels(lib.ptr(x), M, K, lib.ptr(p1), Mp, st), "to_panels")
+    p2 = None
+    if k2:
+        p2 = torch.empty(L().mofa_panel_floats(Mp, k2), device=DEV)
+        lib.check(L().mofa_to_panels(lib.ptr(x2), M, k2, lib.ptr(p2), Mp, st), "to_panels")
+    ws = torch.empty(pieces * N * (K + k2), dtype=torch.int16, device=DEV)
+    lib.check(L().mofa_pack_split(lib.ptr(w), N, K + k2, 0, K, ws.data_ptr(), N, 0, K, pieces, st), "pack_split")
+    if k2:
+        lib.check(L().mofa_pack_split(lib.ptr(w), N, K + k2, K, k2, ws.data_ptr(), N, K // 16, k2, pieces, st), "pack_split")
+    yp = torch.full((Mp * N,), float("nan"), device=DEV)
+    lib.check(L().mofa_layer_forward_split(lib.ptr(p1), K, lib.ptr(p2), k2, ws.data_ptr(), pieces, lib.ptr(b), 0, 1, lib.ptr(yp),
+                                           Mp, N, 1, st), "layer_split")
+    y = torch.empty(M, N, device=DEV)
+    lib.check(L().mofa_from_panels(lib.ptr(yp), Mp, M, N, lib.ptr(y), st), "from_panels")
+    xin = x if x2 is None else torch.cat([x, x2], 1)
+    ref = torch.relu(xin.double().cpu() @ w.double().cpu().T + b.double().cpu()).float().numpy()
+    err = nan_equal_close(y.cpu().numpy(), ref, tol)
+    print(f"pieces={pieces} M={M} K={K + k2} N={N}: max abs err {err:.2e}")
+
+
+def test_opt_in_split_product_network(monkeypatch):
+    """Whole fine-size-like network (10 x 128) under MOFA_GEMM=bf16x6 / bf16x3 vs the default exact-fp32 path."""
+    from mofanerf_amd.hipnet import HipNet
+    from mofanerf_amd.model import NeRF
+    rng = np.random.default_rng(0)
+    net = NeRF(D=10, W=128, input_ch=93, input_ch_views=27, input_ch_textureCodes=256, input_ch_shapeCodes=50,
+               use_viewdirs=True)
+    net.load_state_dict(synth.nerf_state(10, 128, 0, "fine"))
+    h = HipNet(net.to(DEV))
+    R, S = 64, 128
+    o = dev(rng.uniform(-2, 2, (R, 3)).astype(np.float32))
+    d = dev(rng.normal(0, 0.3, (R, 3)).astype(np.float32))
+    z = dev(np.sort(rng.uniform(8, 26, (R, S)).astype(np.float32), -1))
+    vd = torch.nn.functional.normalize(d, dim=-1).contiguous()
+    bm, tex, e = synth.codes(3)
+    folded = h.fold(e.to(DEV), bm.to(DEV), tex.to(DEV)).clone()
+    monkeypatch.setenv("MOFA_FUSED", "0")
+    outs = {}
+    for mode in ("fp32", "bf16x6", "bf16x3"):
+        monkeypatch.setenv("MOFA_GEMM", mode)
+        raw = torch.empty(R, S, 4, device=DEV)
+        h.forward_rays(o, d, z, S, vd, S, raw, folded)
+        torch.cuda.synchronize()
+        outs[mode] = raw.cpu().numpy()
+    e6 = nan_equal_close(outs["bf16x6"], outs["fp32"], 3e-5)
+    e3 = nan_equal_close(outs["bf16x3"], outs["fp32"], 3e-3)
+    print(f"raw: bf16x6 vs fp32 {e6:.2e}, bf16x3 vs fp32 {e3:.2e}")
+    assert e6 < e3
