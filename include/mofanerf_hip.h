@@ -95,15 +95,18 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
                      float* raw_out, float* tape, const float* view_bias_rows, const uint16_t* packed_split,
                      int32_t split_pieces, void* stream);
 /* packed_split / split_pieces: NULL / 0 for the shipped exact-fp32 path.  OPT-IN (MOFA_GEMM=bf16x3|bf16x6): weights
- * pre-split into `split_pieces` (2 or 3) bf16 planes by mofa_net_pack_split; layers whose width is a multiple of 128
- * then run k_layer_split (split-product emulation of the fp32 products on the bf16 matrix pipe, fp32 accumulation). */
+ * split_pieces = 2 or 3 makes layers whose width is a multiple of 128 run the split-product kernel (emulation of the fp32
+ * products on the bf16 matrix pipe, fp32 accumulation); packed_split may stay NULL (operands are split in registers from the
+ * ordinary fp32 panels) or point to weights pre-split into bf16 planes by mofa_net_pack_split (kernel v1). */
 size_t mofa_net_packed_split_elems(MofaNetShape s, int32_t pieces);   /* uint16 elements */
 int mofa_net_pack_split(MofaNetShape s, const float* const* weights, uint16_t* dst, int32_t pieces, void* stream);
 int mofa_pack_split(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, uint16_t* dst,
                     int32_t rows_padded, int32_t panel0, int32_t k_padded, int32_t pieces, void* stream);
+/* w_packed (the ordinary fp32 panels) selects v2: both operands split in registers, 3-stage LDS ring; w_split (bf16 planes from
+ * mofa_pack_split) selects v1.  At least one of them must be given. */
 int mofa_layer_forward_split(const float* x1, int32_t k1, const float* x2, int32_t k2, const uint16_t* w_split,
-                             int32_t pieces, const float* bias, int32_t bias_row_div, int64_t bias_rows, float* y,
-                             int64_t m_padded, int32_t n_padded, int32_t relu, void* stream);
+                             const float* w_packed, int32_t pieces, const float* bias, int32_t bias_row_div,
+                             int64_t bias_rows, float* y, int64_t m_padded, int32_t n_padded, int32_t relu, void* stream);
 
 /* ---- backward (run_fit.py:305-313 photometric fitting, run_train.py:333-357 training) -----------------------
  * Backward of mofa_net_forward given d_raw [n_rays,S,4] and the tape of that forward:

@@ -769,6 +769,132 @@ __global__ __launch_bounds__(256, 2) void k_layer_split(const SplitArgs sa) {
     }
 }
 
+// v2 of the opt-in split-product kernel: BOTH operands stay fp32 panels (the ordinary packed weights) and are split in
+// registers; 3-stage LDS ring (24 KiB / stage, 72 KiB / workgroup -> two workgroups per CU) with a prefetch distance of two
+// panels: LDS-DMA loads stay in flight ACROSS the barrier (counted s_waitcnt vmcnt + raw s_barrier), because a bf16x6
+// panel lasts only ~1.5k MFMA cycles per wave — shorter than an L2/HBM round trip.
+template <int BN, int P>
+__global__ __launch_bounds__(256, 2) void k_layer_split2(const LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BM = kRowTile;
+    constexpr int WAVES_N = BN / 64, WAVES_M = 4 / WAVES_N;
+    constexpr int NI = 2, NJ = (BM / WAVES_M) / 32;
+    constexpr int STAGE = (BM + BN) * 16;
+    constexpr int XR = BM / 64, WR = BN / 64;
+    constexpr int LOADS = XR + WR;                     // LDS-DMA instructions per thread per stage
+
+    const int per_xcd = gridDim.x >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= a.total_tiles) return;
+    const int mt = logical / a.n_tiles, nt = logical - mt * a.n_tiles;
+    const long long m0 = (long long)mt * BM;
+    const int n0 = nt * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WAVES_N, wm = wave / WAVES_N;
+    const int KT = a.k1p + a.k2p;
+    const int lr = lane & 31, g = lane >> 5, sw = (lane >> 2) & 3;
+
+    auto stage_issue = [&](int buf, int kt) {
+        float* xs = smem + buf * STAGE;
+        float* ws = xs + BM * 16;
+        const float* src = (kt < a.k1p ? a.x1 + ((long long)kt * a.m_padded + m0) * 16
+                                       : a.x2 + ((long long)(kt - a.k1p) * a.m_padded + m0) * 16);
+#pragma unroll
+        for (int r = 0; r < XR; ++r) glds16(src + (r * 256 + tid) * 4, xs + (r * 256 + wave * 64) * 4);
+        const float* wsrc = a.w + ((long long)kt * a.n_padded + n0) * 16;
+#pragma unroll
+        for (int r = 0; r < WR; ++r) glds16(wsrc + (r * 256 + tid) * 4, ws + (r * 256 + wave * 64) * 4);
+    };
+
+    f32x16 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    stage_issue(0, 0);
+    if (KT > 1) stage_issue(1, 1);
+    int cur = 0, nxt2 = 2;                              // ring positions of panel kt and panel kt+2
+    for (int kt = 0; kt < KT; ++kt) {
+        // this wave's loads of panel kt have landed once at most the LOADS newer ones (panel kt+1) are still in flight
+        if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // ... and every other wave's too; also: everyone is done with panel kt-1
+        if (kt + 2 < KT) stage_issue(nxt2, kt + 2);     // refill the buffer panel kt-1 just vacated
+        const float* xs = smem + cur * STAGE;
+        const float* ws = xs + BM * 16;
+        bf16x8 wf[NI][P];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row = wn * 64 + 32 * i + lr;
+            const f32x4 lo = *(const f32x4*)(ws + row * 16 + (((2 * g) ^ sw) << 2));
+            const f32x4 hi = *(const f32x4*)(ws + row * 16 + (((2 * g + 1) ^ sw) << 2));
+            split8<P>(lo, hi, wf[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int row = wm * (32 * NJ) + 32 * j + lr;
+            const f32x4 lo = *(const f32x4*)(xs + row * 16 + (((2 * g) ^ sw) << 2));
+            const f32x4 hi = *(const f32x4*)(xs + row * 16 + (((2 * g + 1) ^ sw) << 2));
+            bf16x8 xf[P];
+            split8<P>(lo, hi, xf);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                for (int t = P - 1; t >= 0; --t)
+#pragma unroll
+                    for (int pw = 0; pw <= t; ++pw)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][pw], xf[t - pw], acc[i][j], 0, 0, 0);
+            }
+        }
+        cur = (cur == 2) ? 0 : cur + 1;
+        nxt2 = (nxt2 == 2) ? 0 : nxt2 + 1;
+    }
+
+    f32x4 bv[NI][4];
+    int boff = n0 + wn * 64 + 4 * g;
+    asm volatile("" : "+v"(boff));
+    if (!a.bias_row_div) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(a.bias + boff + 32 * i + 8 * q);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const long long m = m0 + wm * (32 * NJ) + 32 * j + lr;
+        if (a.bias_row_div) {
+            long long brow = m / a.bias_row_div;
+            if (brow >= a.bias_rows) brow = a.bias_rows - 1;
+            const float* bias = a.bias + brow * a.n_padded + n0 + wn * 64 + 4 * g;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(bias + 32 * i + 8 * q);
+        }
+        const int msw = (int)(m >> 2) & 3;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + 32 * i + 8 * q + 4 * g;
+                f32x4 v;
+                v.x = acc[i][j][4 * q + 0] + bv[i][q].x;
+                v.y = acc[i][j][4 * q + 1] + bv[i][q].y;
+                v.z = acc[i][j][4 * q + 2] + bv[i][q].z;
+                v.w = acc[i][j][4 * q + 3] + bv[i][q].w;
+                if (a.relu) {
+                    v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                }
+                *(f32x4*)(a.y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
+            }
+        }
+    }
+}
+
 // weights -> P bf16 planes: dst[((panel0+panel)*P + plane)*rows_padded + row][16], chunk (k/8) swizzled by (row>>3)&1
 __global__ __launch_bounds__(256) void k_pack_split(const float* __restrict__ w, int n_out, int ld, int col0, int ncols,
                                                     unsigned short* __restrict__ dst, int rows_padded, int panel0,
@@ -849,10 +975,23 @@ int launch_layer_split(LayerArgs a, const unsigned short* ws, hipStream_t st) {
     MOFA_REQUIRE(total > 0 && total < (1ll << 30), "layer_split: tile count %lld out of range", total);
     a.total_tiles = (int)total;
     SplitArgs sa{a, ws};
-    const size_t lds = 2 * (size_t)(kRowTile * 16 + P * BN * 8) * sizeof(float);
     const bool prof = g_prof.on;
     if (prof && prof_open(st, 0) != MOFA_OK) return MOFA_EHIP;
-    hipLaunchKernelGGL((k_layer_split<BN, P>), dim3((unsigned)round_up(total, 8)), dim3(256), lds, st, sa);
+    const char* ver = getenv("MOFA_SPLIT_V");
+    if (a.w && !(ws && ver && ver[0] == '1')) {          // v2 (default): fp32 weight panels split in registers, 3-stage ring
+        const size_t lds2 = 3 * (size_t)(kRowTile + BN) * 16 * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)k_layer_split2<BN, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) !=
+                hipSuccess)
+                return check_launch("hipFuncSetAttribute(k_layer_split2)");
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_layer_split2<BN, P>), dim3((unsigned)round_up(total, 8)), dim3(256), lds2, st, a);
+    } else {
+        const size_t lds = 2 * (size_t)(kRowTile * 16 + P * BN * 8) * sizeof(float);
+        hipLaunchKernelGGL((k_layer_split<BN, P>), dim3((unsigned)round_up(total, 8)), dim3(256), lds, st, sa);
+    }
     if (prof) prof_close(st, 0, 2.0 * (double)a.m_padded * (double)a.n_padded * 16.0 * (double)(a.k1p + a.k2p));
     return check_launch("k_layer_split");
 }
@@ -952,14 +1091,14 @@ int mofa_pack_panels_t(const float* w, int32_t n_out, int32_t ld, int32_t col0, 
 
 /* OPT-IN split-product variant of mofa_layer_forward (pieces = 2: bf16x3, 3: bf16x6); w_split from mofa_pack_split. */
 int mofa_layer_forward_split(const float* x1, int32_t k1, const float* x2, int32_t k2, const uint16_t* w_split,
-                             int32_t pieces, const float* bias, int32_t bias_row_div, int64_t bias_rows, float* y,
-                             int64_t m_padded, int32_t n_padded, int32_t relu, void* stream) {
-    MOFA_REQUIRE(x1 && w_split && bias && y, "layer_forward_split: null pointer");
+                             const float* w_packed, int32_t pieces, const float* bias, int32_t bias_row_div,
+                             int64_t bias_rows, float* y, int64_t m_padded, int32_t n_padded, int32_t relu, void* stream) {
+    MOFA_REQUIRE(x1 && (w_split || w_packed) && bias && y, "layer_forward_split: null pointer");
     MOFA_REQUIRE(k1 > 0 && k1 % 16 == 0 && k2 >= 0 && k2 % 16 == 0 && (k2 == 0 || x2), "layer_forward_split: bad K");
     MOFA_REQUIRE(n_padded % 128 == 0 && m_padded % kRowTile == 0 && (pieces == 2 || pieces == 3),
                  "layer_forward_split: needs n_padded %% 128 == 0 and pieces in {2,3} (got %d, %d)", n_padded, pieces);
     LayerArgs a{};
-    a.x1 = x1, a.x2 = x2, a.bias = bias, a.y = y;
+    a.x1 = x1, a.x2 = x2, a.bias = bias, a.y = y, a.w = w_packed;   // w_packed != NULL -> v2 (operands split in registers)
     a.k1p = k1 / 16, a.k2p = k2 / 16, a.n_padded = n_padded, a.m_padded = m_padded;
     a.bias_row_div = bias_row_div, a.bias_rows = bias_rows, a.relu = relu;
     return pieces == 3 ? launch_layer_split<3>(a, w_split, (hipStream_t)stream) : launch_layer_split<2>(a, w_split, (hipStream_t)stream);

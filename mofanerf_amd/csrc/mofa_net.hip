@@ -17,8 +17,8 @@ int mofa_internal_dense_rows(const float* w, int n_out, int ld, int col0, int nc
                              void* stream);
 int mofa_internal_raw_colsum(const float* d_raw, long long n_points, int off, int n, float* out, void* stream);
 int mofa_layer_forward_split(const float* x1, int32_t k1, const float* x2, int32_t k2, const uint16_t* w_split,
-                             int32_t pieces, const float* bias, int32_t bias_row_div, int64_t bias_rows, float* y,
-                             int64_t m_padded, int32_t n_padded, int32_t relu, void* stream);
+                             const float* w_packed, int32_t pieces, const float* bias, int32_t bias_row_div,
+                             int64_t bias_rows, float* y, int64_t m_padded, int32_t n_padded, int32_t relu, void* stream);
 int mofa_pack_split(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, uint16_t* dst,
                     int32_t rows_padded, int32_t panel0, int32_t k_padded, int32_t pieces, void* stream);
 int mofa_internal_fused_forward(const float* arena, float* arena_w, const float* packed, const float* folded,
@@ -292,7 +292,7 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
                      float* raw_out, float* tape, const float* view_bias_rows, const uint16_t* packed_split,
                      int32_t split_pieces, void* stream) {
     MOFA_REQUIRE(shape_ok(s), "net_forward: unsupported shape D=%d W=%d", s.D, s.W);
-    MOFA_REQUIRE(!packed_split || split_pieces == 2 || split_pieces == 3, "net_forward: split_pieces must be 2 or 3");
+    MOFA_REQUIRE(split_pieces == 0 || split_pieces == 2 || split_pieces == 3, "net_forward: split_pieces must be 0, 2 or 3");
     MOFA_REQUIRE(packed && folded && workspace && raw_out, "net_forward: null pointer");
     MOFA_REQUIRE(view_bias_rows || (view_w && view_b && viewdirs),
                  "net_forward: need view_bias_rows or (view_w, view_b, viewdirs)");
@@ -386,11 +386,12 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
             if (!st.x1) {
                 MOFA_TRY(mofa_layer0_forward(rays_o, rays_d, z, z_row_stride, pts, M, S, packed + l.packed_off,
                                              folded + l.folded_off, st.y, Mp, l.n_padded, stream));
-            } else if (packed_split && l.n_padded % 128 == 0) {
+            } else if (split_pieces && l.n_padded % 128 == 0) {
                 // OPT-IN split-product path (MOFA_GEMM): bf16 matrix pipe, fp32 accumulation
                 const bool view = st.li == p.view;
                 MOFA_TRY(mofa_layer_forward_split(st.x1, l.k_padded[0], st.x2, st.x2 ? l.k_padded[1] : 0,
-                                                  packed_split + l.split_elems_off * (size_t)split_pieces, split_pieces,
+                                                  packed_split ? packed_split + l.split_elems_off * (size_t)split_pieces : nullptr,
+                                                  packed + l.packed_off, split_pieces,
                                                   view ? view_bias_rows : folded + l.folded_off, view ? S : 0,
                                                   view ? n_rays : 1, st.y, Mp, l.n_padded, 1, stream));
             } else if (st.li == p.view) {

@@ -38,7 +38,8 @@ SIGNATURES = {
     "mofa_net_packed_split_elems": (_sz, [NetShape, _i32]),
     "mofa_net_pack_split": (C.c_int, [NetShape, C.POINTER(_fp), _fp, _i32, _fp]),
     "mofa_pack_split": (C.c_int, [_fp, _i32, _i32, _i32, _i32, _fp, _i32, _i32, _i32, _i32, _fp]),
-    "mofa_layer_forward_split": (C.c_int, [_fp, _i32, _fp, _i32, _fp, _i32, _fp, _i32, _i64, _fp, _i64, _i32, _i32, _fp]),
+    "mofa_layer_forward_split": (C.c_int, [_fp, _i32, _fp, _i32, _fp, _fp, _i32, _fp, _i32, _i64, _fp, _i64, _i32, _i32,
+                                           _fp]),
     "mofa_net_packed_t_floats": (_sz, [NetShape]),
     "mofa_net_tape_floats": (_sz, [NetShape, _i64]),
     "mofa_net_backward_workspace_floats": (_sz, [NetShape, _i64]),

@@ -396,9 +396,10 @@ def test_persistent_fused_network_is_bit_identical_to_per_layer_launches(D, W, R
     nan_equal_close(tapes["1"].cpu().numpy(), outs["1"].cpu().numpy(), 2e-5)
 
 
+@pytest.mark.parametrize("version", [1, 2])
 @pytest.mark.parametrize("pieces,tol", [(3, 1.5e-5), (2, 2e-3)])
-@pytest.mark.parametrize("M,K,N,k2", [(512, 128, 128, 0), (1024, 1024, 256, 0), (777, 256, 128, 256)])
-def test_opt_in_split_product_layer(M, K, N, k2, pieces, tol):
+@pytest.mark.parametrize("M,K,N,k2", [(512, 128, 128, 0), (1024, 1024, 256, 0), (777, 256, 128, 256), (256, 16, 128, 0)])
+def test_opt_in_split_product_layer(M, K, N, k2, pieces, tol, version):
     """OPT-IN mode (default off): fp32 products emulated by bf16 partial products on the bf16 matrix pipe.
     pieces=3 (bf16x6) must be fp32-equivalent; pieces=2 (bf16x3) ~2^-15 relative per product."""
     rng = np.random.default_rng(M + K + N + pieces)
@@ -419,14 +420,19 @@ def test_opt_in_split_product_layer(M, K, N, k2, pieces, tol):
     if k2:
         lib.check(L().mofa_pack_split(lib.ptr(w), N, K + k2, K, k2, ws.data_ptr(), N, K // 16, k2, pieces, st), "pack_split")
     yp = torch.full((Mp * N,), float("nan"), device=DEV)
-    lib.check(L().mofa_layer_forward_split(lib.ptr(p1), K, lib.ptr(p2), k2, ws.data_ptr(), pieces, lib.ptr(b), 0, 1, lib.ptr(yp),
-                                           Mp, N, 1, st), "layer_split")
+    wp = torch.empty(N * (K + k2), device=DEV)
+    lib.check(L().mofa_pack_panels(lib.ptr(w), N, K + k2, 0, K, lib.ptr(wp), N, 0, K, st), "pack")
+    if k2:
+        lib.check(L().mofa_pack_panels(lib.ptr(w), N, K + k2, K, k2, lib.ptr(wp), N, K // 16, k2, st), "pack")
+    lib.check(L().mofa_layer_forward_split(lib.ptr(p1), K, lib.ptr(p2), k2, ws.data_ptr() if version == 1 else None,
+                                           lib.ptr(wp) if version == 2 else None, pieces, lib.ptr(b), 0, 1, lib.ptr(yp), Mp, N, 1,
+                                           st), "layer_split")
     y = torch.empty(M, N, device=DEV)
     lib.check(L().mofa_from_panels(lib.ptr(yp), Mp, M, N, lib.ptr(y), st), "from_panels")
     xin = x if x2 is None else torch.cat([x, x2], 1)
     ref = torch.relu(xin.double().cpu() @ w.double().cpu().T + b.double().cpu()).float().numpy()
     err = nan_equal_close(y.cpu().numpy(), ref, tol)
-    print(f"pieces={pieces} M={M} K={K + k2} N={N}: max abs err {err:.2e}")
+    print(f"v{version} pieces={pieces} M={M} K={K + k2} N={N}: max abs err {err:.2e}")
 
 
 def test_opt_in_split_product_network(monkeypatch):

@@ -13,13 +13,16 @@ L = lib.load()
 dev = "cuda"
 
 
-def run_split(M, K, N, pieces, iters=10):
+def run_split(M, K, N, pieces, iters=10, version=2):
     x = torch.randn(M * K, device=dev); w = torch.randn(N, K, device=dev) * 0.03
     b = torch.randn(N, device=dev); y = torch.empty(M * N, device=dev)
     ws = torch.empty(pieces * N * K, dtype=torch.int16, device=dev)
+    wp = torch.empty(N * K, device=dev)
     st = lib.stream()
     lib.check(L.mofa_pack_split(lib.ptr(w.contiguous()), N, K, 0, K, ws.data_ptr(), N, 0, K, pieces, st), "pack_split")
-    args = (lib.ptr(x), K, None, 0, ws.data_ptr(), pieces, lib.ptr(b), 0, 1, lib.ptr(y), M, N, 1, st)
+    lib.check(L.mofa_pack_panels(lib.ptr(w.contiguous()), N, K, 0, K, lib.ptr(wp), N, 0, K, st), "pack")
+    args = (lib.ptr(x), K, None, 0, ws.data_ptr() if version == 1 else None, lib.ptr(wp) if version == 2 else None, pieces,
+            lib.ptr(b), 0, 1, lib.ptr(y), M, N, 1, st)
     for _ in range(3):
         lib.check(L.mofa_layer_forward_split(*args), "layer_split")
     torch.cuda.synchronize()
@@ -55,10 +58,11 @@ def run(M, K, N, k2=0, iters=10):
 
 
 if __name__ == "__main__" and "--split" in sys.argv:
-    for pieces, name in ((3, "bf16x6"), (2, "bf16x3")):
+    for version in (1, 2):
+      for pieces, name in ((3, "bf16x6"), (2, "bf16x3")):
         for (M, K, N) in ((196608, 1024, 1024), (196608, 1024, 512), (196608, 256, 256)):
-            ms, tf = run_split(M, K, N, pieces)
-            print(f"split {name} M={M} K={K} N={N}: {ms:8.3f} ms  {tf:7.2f} algorithmic TFLOP/s  "
+            ms, tf = run_split(M, K, N, pieces, version=version)
+            print(f"split v{version} {name} M={M} K={K} N={N}: {ms:8.3f} ms  {tf:7.2f} algorithmic TFLOP/s  "
                   f"({tf / 157.3:4.2f}x the fp32-MFMA peak; bf16 pipe at {tf * (6 if pieces == 3 else 3) / 2500 * 100:4.1f}% of 2.5 PF)", flush=True)
     sys.exit(0)
 
