@@ -707,21 +707,35 @@ __global__ __launch_bounds__(256, 2) void k_layer_split(const SplitArgs sa) {
 #pragma unroll
             for (int p = 0; p < P; ++p) wf[i][p] = *(const bf16x8*)(ws + p * WPLANE + row * 8 + chunk * 4);
         }
+        // software pipeline over the point blocks: split block j+1 (VALU) while block j's MFMAs issue
+        f32x4 lo[NJ], hi[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int row = wm * (32 * NJ) + 32 * j + lr;
-            const f32x4 lo = *(const f32x4*)(xs + row * 16 + (((2 * g) ^ sw) << 2));
-            const f32x4 hi = *(const f32x4*)(xs + row * 16 + (((2 * g + 1) ^ sw) << 2));
-            bf16x8 xf[P];
-            split8<P>(lo, hi, xf);
+            lo[j] = *(const f32x4*)(xs + row * 16 + (((2 * g) ^ sw) << 2));
+            hi[j] = *(const f32x4*)(xs + row * 16 + (((2 * g + 1) ^ sw) << 2));
+        }
+        bf16x8 xf[2][P];
+        split8<P>(lo[0], hi[0], xf[0]);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                // smallest partial products first
+        for (int j = 0; j < NJ; ++j) {
+            // smallest partial products first; the two feature blocks alternate so that consecutive MFMAs never wait on
+            // the accumulator the previous one is still producing
 #pragma unroll
-                for (int t = P - 1; t >= 0; --t)
+            for (int t = P - 1; t >= 0; --t)
 #pragma unroll
-                    for (int pw = 0; pw <= t; ++pw)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][pw], xf[t - pw], acc[i][j], 0, 0, 0);
+                for (int pw = 0; pw <= t; ++pw)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][pw], xf[j & 1][t - pw], acc[i][j], 0, 0, 0);
+            if (j + 1 < NJ) {
+                split8<P>(lo[j + 1], hi[j + 1], xf[(j + 1) & 1]);
+                // ask the scheduler to interleave: 1 MFMA, then 4 VALU of the next block's split, ...
+#pragma unroll
+                for (int q = 0; q < NI * P * (P + 1) / 2; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
             }
         }
         __syncthreads();
@@ -834,20 +848,35 @@ __global__ __launch_bounds__(256, 2) void k_layer_split2(const LayerArgs a) {
             const f32x4 hi = *(const f32x4*)(ws + row * 16 + (((2 * g + 1) ^ sw) << 2));
             split8<P>(lo, hi, wf[i]);
         }
+        // software pipeline over the point blocks: split block j+1 (VALU) while block j's MFMAs issue
+        f32x4 lo[NJ], hi[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int row = wm * (32 * NJ) + 32 * j + lr;
-            const f32x4 lo = *(const f32x4*)(xs + row * 16 + (((2 * g) ^ sw) << 2));
-            const f32x4 hi = *(const f32x4*)(xs + row * 16 + (((2 * g + 1) ^ sw) << 2));
-            bf16x8 xf[P];
-            split8<P>(lo, hi, xf);
+            lo[j] = *(const f32x4*)(xs + row * 16 + (((2 * g) ^ sw) << 2));
+            hi[j] = *(const f32x4*)(xs + row * 16 + (((2 * g + 1) ^ sw) << 2));
+        }
+        bf16x8 xf[2][P];
+        split8<P>(lo[0], hi[0], xf[0]);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
+        for (int j = 0; j < NJ; ++j) {
+            // smallest partial products first; the two feature blocks alternate so that consecutive MFMAs never wait on
+            // the accumulator the previous one is still producing
 #pragma unroll
-                for (int t = P - 1; t >= 0; --t)
+            for (int t = P - 1; t >= 0; --t)
 #pragma unroll
-                    for (int pw = 0; pw <= t; ++pw)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][pw], xf[t - pw], acc[i][j], 0, 0, 0);
+                for (int pw = 0; pw <= t; ++pw)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][pw], xf[j & 1][t - pw], acc[i][j], 0, 0, 0);
+            if (j + 1 < NJ) {
+                split8<P>(lo[j + 1], hi[j + 1], xf[(j + 1) & 1]);
+                // ask the scheduler to interleave: 1 MFMA, then 4 VALU of the next block's split, ...
+#pragma unroll
+                for (int q = 0; q < NI * P * (P + 1) / 2; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
             }
         }
         cur = (cur == 2) ? 0 : cur + 1;
