@@ -87,7 +87,7 @@ class HipNet:
             if mode not in ("", "fp32"):
                 raise lib.MofaError(f"MOFA_GEMM={mode!r}: expected fp32 (default), bf16x3 or bf16x6")
             return None, 0
-        if os.environ.get("MOFA_SPLIT_V", "2") != "1":
+        if os.environ.get("MOFA_SPLIT_V", "1") == "2":
             return None, pieces          # kernel v2 splits both operands in registers from the ordinary fp32 panels
         key = (pieces,) + self._key()
         if self._split is None or key != self._split_key:

@@ -122,7 +122,7 @@ def render_pair(H, K, angle, arch, chunk, netchunk, device="cuda", seed=0, n_ray
     return hip, ref
 
 
-def compare_render(hip, ref, u=None, tol=1e-4, min_agree=0.3, verbose=True):
+def compare_render(hip, ref, u=None, tol=1e-4, min_agree=0.15, verbose=True):
     """Parity of a coarse+fine render (dicts of numpy arrays, rays flat).
 
     * coarse outputs (rgb0/acc0/disp0, coarse weights): every ray, ``tol``;
