@@ -617,6 +617,9 @@ int launch_fused(const FusedArgs& a, hipStream_t st) {
 // other wave's MFMAs); weights are pre-split into P bf16 planes (mofa_net_pack_split).  Both operands use the same
 // (lane, element) -> k assignment, so the instruction's internal k ordering is irrelevant.  C/D layout = the fp32 kernel's.
 // ======================================================================================================
+#ifndef MOFA_SPLIT_PIPELINED
+#define MOFA_SPLIT_PIPELINED 0   // 1: software-pipelined split + sched_group_barrier + alternating accumulators (A/B arm)
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -707,6 +710,25 @@ __global__ __launch_bounds__(256, 2) void k_layer_split(const SplitArgs sa) {
 #pragma unroll
             for (int p = 0; p < P; ++p) wf[i][p] = *(const bf16x8*)(ws + p * WPLANE + row * 8 + chunk * 4);
         }
+#if !MOFA_SPLIT_PIPELINED
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int row = wm * (32 * NJ) + 32 * j + lr;
+            const f32x4 lo = *(const f32x4*)(xs + row * 16 + (((2 * g) ^ sw) << 2));
+            const f32x4 hi = *(const f32x4*)(xs + row * 16 + (((2 * g + 1) ^ sw) << 2));
+            bf16x8 xf[P];
+            split8<P>(lo, hi, xf);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                // smallest partial products first
+#pragma unroll
+                for (int t = P - 1; t >= 0; --t)
+#pragma unroll
+                    for (int pw = 0; pw <= t; ++pw)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][pw], xf[t - pw], acc[i][j], 0, 0, 0);
+            }
+        }
+#else
         // software pipeline over the point blocks: split block j+1 (VALU) while block j's MFMAs issue
         f32x4 lo[NJ], hi[NJ];
 #pragma unroll
@@ -738,6 +760,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_split(const SplitArgs sa) {
                 }
             }
         }
+#endif
         __syncthreads();
     }
 
@@ -848,6 +871,25 @@ __global__ __launch_bounds__(256, 2) void k_layer_split2(const LayerArgs a) {
             const f32x4 hi = *(const f32x4*)(ws + row * 16 + (((2 * g + 1) ^ sw) << 2));
             split8<P>(lo, hi, wf[i]);
         }
+#if !MOFA_SPLIT_PIPELINED
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int row = wm * (32 * NJ) + 32 * j + lr;
+            const f32x4 lo = *(const f32x4*)(xs + row * 16 + (((2 * g) ^ sw) << 2));
+            const f32x4 hi = *(const f32x4*)(xs + row * 16 + (((2 * g + 1) ^ sw) << 2));
+            bf16x8 xf[P];
+            split8<P>(lo, hi, xf);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                // smallest partial products first
+#pragma unroll
+                for (int t = P - 1; t >= 0; --t)
+#pragma unroll
+                    for (int pw = 0; pw <= t; ++pw)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][pw], xf[t - pw], acc[i][j], 0, 0, 0);
+            }
+        }
+#else
         // software pipeline over the point blocks: split block j+1 (VALU) while block j's MFMAs issue
         f32x4 lo[NJ], hi[NJ];
 #pragma unroll
@@ -879,6 +921,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_split2(const LayerArgs a) {
                 }
             }
         }
+#endif
         cur = (cur == 2) ? 0 : cur + 1;
         nxt2 = (nxt2 == 2) ? 0 : nxt2 + 1;
     }
