@@ -109,6 +109,11 @@ class GradBucket:
     def sync(self):
         """Average the gradients over the ranks (no-op for a single process)."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.flat.is_cuda and dist.get_backend(self.group) == "gloo":   # functional-test configuration: stage via host
+                host = self.flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                self.flat.copy_(host)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(dist.get_world_size(self.group))
         return self.flat
