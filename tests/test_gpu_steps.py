@@ -91,3 +91,28 @@ def test_data_parallel_training_two_ranks_stay_identical():
     j = json.loads(line)
     assert j["world"] == 2 and j["parameters_identical_across_ranks"] is True
     assert j["loss_rank0"][-1] != j["loss_rank0"][0] and all(np.isfinite(j["loss_rank0"]))
+
+
+def test_bench_two_rank_flow_emits_one_contract_json_line():
+    """bench.py under torch.distributed.run with 2 ranks (gloo on this GPU; the driver's 2/4/8-GPU runs use RCCL): row-block
+    sharding, all-gather of the tiles inside the timed region, max-over-ranks timing, ONE JSON line from rank 0."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--size", "64",
+           "--arch", "8", "64", "10", "64"]
+    out = subprocess.run(cmd, env=dict(os.environ, MOFA_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["unit"] == "rays/s" and "cpu_baseline" not in j
+    assert j["config"]["rays_per_step"] == 64 * 64 and j["dtype"] == "f32"
