@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--arch", type=int, nargs=4, default=list(ARCH), metavar=("Dc", "Wc", "Df", "Wf"),
                     help="network sizes; default = shipped config (8 256 10 1024).  '8 256 8 256' is the labelled variant "
                          "BASELINE.md lists (fine net as small as the coarse one)")
-    ap.add_argument("--gemm", choices=["fp32", "bf16x6", "bf16x3"], default="fp32",
+    ap.add_argument("--gemm", choices=["fp32", "bf16x6", "bf16x3", "fp16x3"], default="fp32",
                     help="fp32 (default, the headline: exact fp32 MFMA).  bf16x6 / bf16x3 = OPT-IN split-product emulation of "
                          "the fp32 products on the bf16 matrix pipe — a labelled experiment, not the headline")
     ap.add_argument("--size", type=int, default=512, help="image side (512 = the benchmark; smaller only for functional tests)")
@@ -185,7 +185,7 @@ def main():
         # M a multiple of 256), except layer 0's K = 63 -> 64 inside the persistent kernel (0.1 %).
         dom = 0 if ms2[0] >= ms2[1] else 1
         kname = ["mofa::k_layer<128,false,true> (fp32 MFMA Linear+bias+ReLU)" if a.gemm == "fp32" else
-                 f"mofa::k_layer_split<128,{3 if a.gemm == 'bf16x6' else 2}> ({a.gemm} split products on bf16 MFMA; peak quoted = fp32 MFMA)",
+                 f"mofa::k_layer_split<128,{3 if a.gemm == 'bf16x6' else 2}> ({a.gemm} split products on the 16-bit matrix pipe; peak quoted = fp32 MFMA)",
                  "mofa::k_mlp_fused (persistent fp32-MFMA network kernel, widths <= 256)"][dom]
         ms_dom, launches_dom, alg_flops = ms2[dom], launches2[dom], pflops2[dom]
         achieved = alg_flops / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
@@ -201,7 +201,7 @@ def main():
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32" if a.gemm == "fp32" else f"f32 emulated by {a.gemm} split products (bf16 MFMA, fp32 accumulation) - OPT-IN EXPERIMENT",
+            "dtype": "f32" if a.gemm == "fp32" else f"f32 emulated by {a.gemm} split products (16-bit MFMA, fp32 accumulation) - OPT-IN EXPERIMENT",
             "data": "synthetic",
             "config": {"workload": f"{H}x{W} novel view, 64 coarse + 128 fine samples/ray, coarse {ARCH[1]}x{ARCH[0]} + fine {ARCH[3]}x{ARCH[2]}, "
                                    "chunk=netchunk=196608, seeded Xavier weights (BASELINE.json configs[1])",

@@ -95,7 +95,7 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
                      float* raw_out, float* tape, const float* view_bias_rows, const uint16_t* packed_split,
                      int32_t split_pieces, void* stream);
 /* packed_split / split_pieces: NULL / 0 for the shipped exact-fp32 path.  OPT-IN (MOFA_GEMM=bf16x3|bf16x6): weights
- * split_pieces = 2 or 3 makes layers whose width is a multiple of 128 run the split-product kernel (emulation of the fp32
+ * split_pieces = 2 (bf16x3), 3 (bf16x6) or -2 (fp16x3: two fp16 pieces, needs |values| < 65504) makes layers whose width is a multiple of 128 run the split-product kernel (emulation of the fp32
  * products on the bf16 matrix pipe, fp32 accumulation); packed_split may stay NULL (operands are split in registers from the
  * ordinary fp32 panels) or point to weights pre-split into bf16 planes by mofa_net_pack_split (kernel v1). */
 size_t mofa_net_packed_split_elems(MofaNetShape s, int32_t pieces);   /* uint16 elements */

@@ -647,8 +647,44 @@ __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, bf16x8 (&
     }
 }
 
-template <int BN, int P>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// 8 fp32 values -> 2 fp16x8 pieces (round-to-nearest split: x = h1 + h2 + O(2^-22 |x|); needs |x| < 65504)
+__device__ __forceinline__ void split8_f16(const f32x4 lo, const f32x4 hi, f16x8 (&out)[2]) {
+    const float r[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const _Float16 h1 = (_Float16)r[i];
+        out[0][i] = h1;
+        out[1][i] = (_Float16)(r[i] - (float)h1);
+    }
+}
+
+template <int P, bool F16>
+struct SplitFrag {
+    using type = bf16x8;
+};
+template <int P>
+struct SplitFrag<P, true> {
+    using type = f16x8;
+};
+
+template <int P, bool F16, typename Frag>
+__device__ __forceinline__ void split_any(const f32x4 lo, const f32x4 hi, Frag (&out)[P]) {
+    if constexpr (F16) split8_f16(lo, hi, out);
+    else split8<P>(lo, hi, out);
+}
+
+template <bool F16, typename Frag>
+__device__ __forceinline__ f32x16 mfma_split(const Frag& a, const Frag& b, const f32x16& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int BN, int P, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void k_layer_split(const SplitArgs sa) {
+    using Frag = typename SplitFrag<P, F16>::type;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const LayerArgs& a = sa.base;
     constexpr int BM = kRowTile;
@@ -702,13 +738,13 @@ __global__ __launch_bounds__(256, 2) void k_layer_split(const SplitArgs sa) {
         const float* xs = smem + cur * STAGE;
         const float* ws = xs + BM * 16;
         // weight fragments: lane (row, g) holds k = 8g .. 8g+7 of each plane (one 16-B read per plane)
-        bf16x8 wf[NI][P];
+        Frag wf[NI][P];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int row = wn * 64 + 32 * i + lr;
             const int chunk = g ^ ((row >> 3) & 1);
 #pragma unroll
-            for (int p = 0; p < P; ++p) wf[i][p] = *(const bf16x8*)(ws + p * WPLANE + row * 8 + chunk * 4);
+            for (int p = 0; p < P; ++p) wf[i][p] = *(const Frag*)(ws + p * WPLANE + row * 8 + chunk * 4);
         }
 #if !MOFA_SPLIT_PIPELINED
 #pragma unroll
@@ -716,8 +752,8 @@ __global__ __launch_bounds__(256, 2) void k_layer_split(const SplitArgs sa) {
             const int row = wm * (32 * NJ) + 32 * j + lr;
             const f32x4 lo = *(const f32x4*)(xs + row * 16 + (((2 * g) ^ sw) << 2));
             const f32x4 hi = *(const f32x4*)(xs + row * 16 + (((2 * g + 1) ^ sw) << 2));
-            bf16x8 xf[P];
-            split8<P>(lo, hi, xf);
+            Frag xf[P];
+            split_any<P, F16>(lo, hi, xf);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 // smallest partial products first
@@ -725,7 +761,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_split(const SplitArgs sa) {
                 for (int t = P - 1; t >= 0; --t)
 #pragma unroll
                     for (int pw = 0; pw <= t; ++pw)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][pw], xf[t - pw], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma_split<F16>(wf[i][pw], xf[t - pw], acc[i][j]);
             }
         }
 #else
@@ -737,8 +773,8 @@ __global__ __launch_bounds__(256, 2) void k_layer_split(const SplitArgs sa) {
             lo[j] = *(const f32x4*)(xs + row * 16 + (((2 * g) ^ sw) << 2));
             hi[j] = *(const f32x4*)(xs + row * 16 + (((2 * g + 1) ^ sw) << 2));
         }
-        bf16x8 xf[2][P];
-        split8<P>(lo[0], hi[0], xf[0]);
+        Frag xf[2][P];
+        split_any<P, F16>(lo[0], hi[0], xf[0]);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             // smallest partial products first; the two feature blocks alternate so that consecutive MFMAs never wait on
@@ -749,9 +785,9 @@ __global__ __launch_bounds__(256, 2) void k_layer_split(const SplitArgs sa) {
                 for (int pw = 0; pw <= t; ++pw)
 #pragma unroll
                     for (int i = 0; i < NI; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][pw], xf[j & 1][t - pw], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma_split<F16>(wf[i][pw], xf[j & 1][t - pw], acc[i][j]);
             if (j + 1 < NJ) {
-                split8<P>(lo[j + 1], hi[j + 1], xf[(j + 1) & 1]);
+                split_any<P, F16>(lo[j + 1], hi[j + 1], xf[(j + 1) & 1]);
                 // ask the scheduler to interleave: 1 MFMA, then 4 VALU of the next block's split, ...
 #pragma unroll
                 for (int q = 0; q < NI * P * (P + 1) / 2; ++q) {
@@ -970,7 +1006,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_split2(const LayerArgs a) {
 // weights -> P bf16 planes: dst[((panel0+panel)*P + plane)*rows_padded + row][16], chunk (k/8) swizzled by (row>>3)&1
 __global__ __launch_bounds__(256) void k_pack_split(const float* __restrict__ w, int n_out, int ld, int col0, int ncols,
                                                     unsigned short* __restrict__ dst, int rows_padded, int panel0,
-                                                    int k_padded, int P) {
+                                                    int k_padded, int P, int fp16) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;       // over rows_padded * k_padded
     if (idx >= (long long)rows_padded * k_padded) return;
     const int e = idx & 7, gph = (idx >> 3) & 1;
@@ -979,9 +1015,16 @@ __global__ __launch_bounds__(256) void k_pack_split(const float* __restrict__ w,
     const int k = panel * 16 + 8 * (gph ^ ((row >> 3) & 1)) + e;
     float r = (row < n_out && k < ncols) ? w[(long long)row * ld + col0 + k] : 0.f;
     for (int p = 0; p < P; ++p) {
-        const unsigned bits = __float_as_uint(r) & 0xFFFF0000u;
-        dst[(((long long)(panel0 + panel) * P + p) * rows_padded + row) * 16 + gph * 8 + e] = (unsigned short)(bits >> 16);
-        r = r - __uint_as_float(bits);
+        const long long o = (((long long)(panel0 + panel) * P + p) * rows_padded + row) * 16 + gph * 8 + e;
+        if (fp16) {
+            const _Float16 h = (_Float16)r;
+            dst[o] = __builtin_bit_cast(unsigned short, h);
+            r = r - (float)h;
+        } else {
+            const unsigned bits = __float_as_uint(r) & 0xFFFF0000u;
+            dst[o] = (unsigned short)(bits >> 16);
+            r = r - __uint_as_float(bits);
+        }
     }
 }
 
@@ -1039,7 +1082,7 @@ int launch_layer(LayerArgs a, hipStream_t st) {
     return check_launch(BWD ? "k_layer<BWD>" : (L0 ? "k_layer<L0>" : "k_layer"));
 }
 
-template <int P>
+template <int P, bool F16 = false>
 int launch_layer_split(LayerArgs a, const unsigned short* ws, hipStream_t st) {
     constexpr int BN = 128;
     a.n_tiles = a.n_padded / BN;
@@ -1050,7 +1093,7 @@ int launch_layer_split(LayerArgs a, const unsigned short* ws, hipStream_t st) {
     const bool prof = g_prof.on;
     if (prof && prof_open(st, 0) != MOFA_OK) return MOFA_EHIP;
     const char* ver = getenv("MOFA_SPLIT_V");
-    if (a.w && !(ws && ver && ver[0] == '1')) {          // v2 (default): fp32 weight panels split in registers, 3-stage ring
+    if (!F16 && a.w && !(ws && ver && ver[0] == '1')) {  // v2: fp32 weight panels split in registers, 3-stage ring (bf16 only)
         const size_t lds2 = 3 * (size_t)(kRowTile + BN) * 16 * sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {
@@ -1062,7 +1105,8 @@ int launch_layer_split(LayerArgs a, const unsigned short* ws, hipStream_t st) {
         hipLaunchKernelGGL((k_layer_split2<BN, P>), dim3((unsigned)round_up(total, 8)), dim3(256), lds2, st, a);
     } else {
         const size_t lds = 2 * (size_t)(kRowTile * 16 + P * BN * 8) * sizeof(float);
-        hipLaunchKernelGGL((k_layer_split<BN, P>), dim3((unsigned)round_up(total, 8)), dim3(256), lds, st, sa);
+        MOFA_REQUIRE(ws, "layer_split: this mode needs the pre-split weight planes");
+        hipLaunchKernelGGL((k_layer_split<BN, P, F16>), dim3((unsigned)round_up(total, 8)), dim3(256), lds, st, sa);
     }
     if (prof) prof_close(st, 0, 2.0 * (double)a.m_padded * (double)a.n_padded * 16.0 * (double)(a.k1p + a.k2p));
     return check_launch("k_layer_split");
@@ -1167,23 +1211,24 @@ int mofa_layer_forward_split(const float* x1, int32_t k1, const float* x2, int32
                              int64_t bias_rows, float* y, int64_t m_padded, int32_t n_padded, int32_t relu, void* stream) {
     MOFA_REQUIRE(x1 && (w_split || w_packed) && bias && y, "layer_forward_split: null pointer");
     MOFA_REQUIRE(k1 > 0 && k1 % 16 == 0 && k2 >= 0 && k2 % 16 == 0 && (k2 == 0 || x2), "layer_forward_split: bad K");
-    MOFA_REQUIRE(n_padded % 128 == 0 && m_padded % kRowTile == 0 && (pieces == 2 || pieces == 3),
-                 "layer_forward_split: needs n_padded %% 128 == 0 and pieces in {2,3} (got %d, %d)", n_padded, pieces);
+    MOFA_REQUIRE(n_padded % 128 == 0 && m_padded % kRowTile == 0 && (pieces == 2 || pieces == 3 || pieces == -2),
+                 "layer_forward_split: needs n_padded %% 128 == 0 and pieces in {2, 3, -2} (got %d, %d)", n_padded, pieces);
     LayerArgs a{};
     a.x1 = x1, a.x2 = x2, a.bias = bias, a.y = y, a.w = w_packed;   // w_packed != NULL -> v2 (operands split in registers)
     a.k1p = k1 / 16, a.k2p = k2 / 16, a.n_padded = n_padded, a.m_padded = m_padded;
     a.bias_row_div = bias_row_div, a.bias_rows = bias_rows, a.relu = relu;
+    if (pieces == -2) return launch_layer_split<2, true>(a, w_split, (hipStream_t)stream);   // fp16x3
     return pieces == 3 ? launch_layer_split<3>(a, w_split, (hipStream_t)stream) : launch_layer_split<2>(a, w_split, (hipStream_t)stream);
 }
 
 int mofa_pack_split(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, uint16_t* dst,
                     int32_t rows_padded, int32_t panel0, int32_t k_padded, int32_t pieces, void* stream) {
-    MOFA_REQUIRE(w && dst && (pieces == 2 || pieces == 3), "pack_split: bad arguments");
+    MOFA_REQUIRE(w && dst && (pieces == 2 || pieces == 3 || pieces == -2), "pack_split: bad arguments");
     MOFA_REQUIRE(rows_padded >= n_out && k_padded % 16 == 0 && k_padded >= ncols && col0 >= 0 && col0 + ncols <= ld,
                  "pack_split: bad shape");
     const long long total = (long long)rows_padded * k_padded;
     hipLaunchKernelGGL(k_pack_split, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, w, n_out, ld, col0, ncols,
-                       dst, rows_padded, panel0, k_padded, pieces);
+                       dst, rows_padded, panel0, k_padded, pieces < 0 ? -pieces : pieces, pieces < 0 ? 1 : 0);
     return check_launch("k_pack_split");
 }
 

@@ -262,17 +262,19 @@ int mofa_net_pack_t(MofaNetShape s, const float* const* weights, float* packed_t
 }
 
 size_t mofa_net_packed_split_elems(MofaNetShape s, int32_t pieces) {
-    return (shape_ok(s) && (pieces == 2 || pieces == 3)) ? make_plan(s).split_elems * (size_t)pieces : 0;
+    const int np = pieces < 0 ? -pieces : pieces;   // negative = fp16 pieces
+    return (shape_ok(s) && (np == 2 || np == 3)) ? make_plan(s).split_elems * (size_t)np : 0;
 }
 
 int mofa_net_pack_split(MofaNetShape s, const float* const* weights, uint16_t* dst, int32_t pieces, void* stream) {
     MOFA_REQUIRE(shape_ok(s), "net_pack_split: unsupported shape D=%d W=%d", s.D, s.W);
-    MOFA_REQUIRE(weights && dst && (pieces == 2 || pieces == 3), "net_pack_split: bad arguments");
+    MOFA_REQUIRE(weights && dst && (pieces == 2 || pieces == 3 || pieces == -2), "net_pack_split: bad arguments");
     const Plan p = make_plan(s);
+    const int np = pieces < 0 ? -pieces : pieces;
     for (size_t li = 0; li < p.L.size(); ++li) {
         const Layer& l = p.L[li];
         if (l.head) continue;
-        uint16_t* d = dst + l.split_elems_off * (size_t)pieces;
+        uint16_t* d = dst + l.split_elems_off * (size_t)np;
         int rc = mofa_pack_split(weights[li], l.n_out, l.ld, l.col0[0], l.ncols[0], d, l.n_padded, 0, l.k_padded[0], pieces,
                                  stream);
         if (rc == MOFA_OK && l.nsrc > 1)
@@ -292,7 +294,8 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
                      float* raw_out, float* tape, const float* view_bias_rows, const uint16_t* packed_split,
                      int32_t split_pieces, void* stream) {
     MOFA_REQUIRE(shape_ok(s), "net_forward: unsupported shape D=%d W=%d", s.D, s.W);
-    MOFA_REQUIRE(split_pieces == 0 || split_pieces == 2 || split_pieces == 3, "net_forward: split_pieces must be 0, 2 or 3");
+    MOFA_REQUIRE(split_pieces == 0 || split_pieces == 2 || split_pieces == 3 || split_pieces == -2,
+                 "net_forward: split_pieces must be 0, 2, 3 or -2");
     MOFA_REQUIRE(packed && folded && workspace && raw_out, "net_forward: null pointer");
     MOFA_REQUIRE(view_bias_rows || (view_w && view_b && viewdirs),
                  "net_forward: need view_bias_rows or (view_w, view_b, viewdirs)");
@@ -390,7 +393,7 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
                 // OPT-IN split-product path (MOFA_GEMM): bf16 matrix pipe, fp32 accumulation
                 const bool view = st.li == p.view;
                 MOFA_TRY(mofa_layer_forward_split(st.x1, l.k_padded[0], st.x2, st.x2 ? l.k_padded[1] : 0,
-                                                  packed_split ? packed_split + l.split_elems_off * (size_t)split_pieces : nullptr,
+                                                  packed_split ? packed_split + l.split_elems_off * (size_t)(split_pieces < 0 ? -split_pieces : split_pieces) : nullptr,
                                                   packed + l.packed_off, split_pieces,
                                                   view ? view_bias_rows : folded + l.folded_off, view ? S : 0,
                                                   view ? n_rays : 1, st.y, Mp, l.n_padded, 1, stream));

@@ -82,12 +82,12 @@ class HipNet:
         2 / 3 bf16 planes.  Returns ``(ptr, pieces)`` or ``(None, 0)``."""
         import os
         mode = os.environ.get("MOFA_GEMM", "")
-        pieces = {"bf16x3": 2, "bf16x6": 3}.get(mode, 0)
+        pieces = {"bf16x3": 2, "bf16x6": 3, "fp16x3": -2}.get(mode, 0)
         if not pieces:
             if mode not in ("", "fp32"):
-                raise lib.MofaError(f"MOFA_GEMM={mode!r}: expected fp32 (default), bf16x3 or bf16x6")
+                raise lib.MofaError(f"MOFA_GEMM={mode!r}: expected fp32 (default), bf16x3, bf16x6 or fp16x3")
             return None, 0
-        if os.environ.get("MOFA_SPLIT_V", "1") == "2":
+        if pieces > 0 and os.environ.get("MOFA_SPLIT_V", "1") == "2":
             return None, pieces          # kernel v2 splits both operands in registers from the ordinary fp32 panels
         key = (pieces,) + self._key()
         if self._split is None or key != self._split_key:

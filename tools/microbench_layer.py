@@ -16,7 +16,7 @@ dev = "cuda"
 def run_split(M, K, N, pieces, iters=10, version=2):
     x = torch.randn(M * K, device=dev); w = torch.randn(N, K, device=dev) * 0.03
     b = torch.randn(N, device=dev); y = torch.empty(M * N, device=dev)
-    ws = torch.empty(pieces * N * K, dtype=torch.int16, device=dev)
+    ws = torch.empty(abs(pieces) * N * K, dtype=torch.int16, device=dev)
     wp = torch.empty(N * K, device=dev)
     st = lib.stream()
     lib.check(L.mofa_pack_split(lib.ptr(w.contiguous()), N, K, 0, K, ws.data_ptr(), N, 0, K, pieces, st), "pack_split")
@@ -59,11 +59,13 @@ def run(M, K, N, k2=0, iters=10):
 
 if __name__ == "__main__" and "--split" in sys.argv:
     for version in (1, 2):
-      for pieces, name in ((3, "bf16x6"), (2, "bf16x3")):
+      for pieces, name in ((3, "bf16x6"), (2, "bf16x3"), (-2, "fp16x3")):
+        if pieces < 0 and version == 2:
+            continue
         for (M, K, N) in ((196608, 1024, 1024), (196608, 1024, 512), (196608, 256, 256)):
             ms, tf = run_split(M, K, N, pieces, version=version)
             print(f"split v{version} {name} M={M} K={K} N={N}: {ms:8.3f} ms  {tf:7.2f} algorithmic TFLOP/s  "
-                  f"({tf / 157.3:4.2f}x the fp32-MFMA peak; bf16 pipe at {tf * (6 if pieces == 3 else 3) / 2500 * 100:4.1f}% of 2.5 PF)", flush=True)
+                  f"({tf / 157.3:4.2f}x the fp32-MFMA peak; 16-bit pipe at {tf * (6 if pieces == 3 else 3) / 2500 * 100:4.1f}% of 2.5 PF)", flush=True)
     sys.exit(0)
 
 if __name__ == "__main__":

@@ -24,9 +24,18 @@ def split3(a):
     return a1, a2, a3
 
 
-def make_linear(terms):
+def split_f16(a):
+    a1 = a.to(torch.float16).float(); r = a - a1
+    a2 = r.to(torch.float16).float(); r = r - a2
+    a3 = r.to(torch.float16).float()
+    return a1, a2, a3
+
+
+def make_linear(terms, splitter=None):
+    splitter = splitter or split3
+
     def lin(x, w, b=None):
-        xs, ws = split3(x), split3(w)
+        xs, ws = splitter(x), splitter(w)
         out = None
         for (i, j) in terms:                      # small terms first, like a careful accumulation order
             p = xs[i] @ ws[j].t()
@@ -61,8 +70,10 @@ raw0, rgb0 = render()
 assert np.array_equal(rgb0.numpy(), g["rgb"].reshape(-1, 3))
 print(f"fine net {arch[3]}x{arch[2]}, {pts.shape[0]} rays x {pts.shape[1]} samples, identical sample positions")
 orig = F.linear
-for name, terms in TERMS.items():
-    orc.F.linear = make_linear(terms)
+CASES = [(n, t, None) for n, t in TERMS.items()] + [("fp16x3 (2 fp16 pieces, 3 products)", TERMS["x3"], split_f16),
+                                                   ("fp16x1 (plain fp16 inputs)", [(0, 0)], split_f16)]
+for name, terms, splitter in CASES:
+    orc.F.linear = make_linear(terms, splitter)
     raw, rgb = render()
     orc.F.linear = orig
     print(f"{name}: max |raw - raw_fp32| = {float((raw - raw0).abs().max()):.2e}   max |rgb - rgb_fp32| = {float((rgb - rgb0).abs().max()):.2e}")
