@@ -33,6 +33,29 @@ class _NullLogger:
         pass
 
 
+def _unwrap(m):
+    return m.module if isinstance(m, torch.nn.DataParallel) else m
+
+
+def save_checkpoint(path: str, global_step: int, render_kwargs, render, optimizer) -> str:
+    """Write the reference's ``{:06d}.tar`` dictionary (run_train.py:369-379) so that the reference and this package
+    resume from each other's files: same top-level keys, same state-dict key names and shapes (tests/golden/schema.json).
+    ``DataParallel`` wrappers, which the reference unwraps with ``.module``, are accepted either way."""
+    fine = render_kwargs.get("network_fine")
+    blob = {
+        "global_step": global_step,
+        "network_fn_state_dict": _unwrap(render_kwargs["network_fn"]).state_dict(),
+        "network_fine_state_dict": _unwrap(fine).state_dict() if fine is not None else None,
+        "network_render_textureEncoder": _unwrap(render.texEncoder).state_dict(),
+        "network_render_idSpecific": _unwrap(render.idSpecificMod).state_dict(),
+        "optimizer_state_dict": optimizer.state_dict(),
+        "expression_latent_codes_sigma": render.expCodes_Sigma,
+    }
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    torch.save(blob, path)
+    return path
+
+
 def create_nerf(args):
     embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
     if not args.use_viewdirs:

@@ -1,8 +1,13 @@
-"""Minimal image output for ``render_path`` (the reference uses imageio, which is not a dependency here)."""
+"""Image output for ``render_path`` (the reference uses imageio, which is not a dependency here): a PNG encoder and an
+asynchronous sink that keeps quantisation on the device, copies through pinned memory and encodes on worker threads, so
+that the output stage (render_class.py:224-232) overlaps the next frame instead of stalling the render loop."""
+import os
 import struct
 import zlib
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
+import torch
 
 
 def write_png(path: str, img_u8: np.ndarray) -> None:
@@ -16,6 +21,52 @@ def write_png(path: str, img_u8: np.ndarray) -> None:
     def chunk(tag: bytes, data: bytes) -> bytes:
         return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
 
-    with open(path, "wb") as f:
+    tmp = path + ".part"              # finished files only: a resumed bulk render skips whatever exists under `path`
+    with open(tmp, "wb") as f:
         f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
                 chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+    os.replace(tmp, path)
+
+
+class PngSink:
+    """``submit(path, rgb)`` returns immediately; ``close()`` (or leaving the ``with`` block) waits for every file and
+    re-raises the first failure.  ``rgb``: float ``[H,W,3]`` tensor on any device (or a numpy array); quantisation is the
+    reference's ``to8b`` - ``(255 * clip(x, 0, 1))`` truncated to uint8 (tools/run_nerf_helpers.py:12)."""
+
+    def __init__(self, workers: int = 2):
+        self._pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="png")
+        self._pending = []
+
+    @staticmethod
+    def _job(path, host, event):
+        if event is not None:
+            event.synchronize()                          # the D2H copy of THIS frame only
+        write_png(path, host.numpy() if torch.is_tensor(host) else host)
+
+    def submit(self, path: str, rgb) -> None:
+        event = None
+        if torch.is_tensor(rgb):
+            q = (255 * rgb.detach().clamp(0, 1)).to(torch.uint8)
+            if q.is_cuda:
+                host = torch.empty(q.shape, dtype=torch.uint8, pin_memory=True)
+                host.copy_(q, non_blocking=True)
+                event = torch.cuda.Event()
+                event.record()
+            else:
+                host = q
+        else:
+            host = (255 * np.clip(rgb, 0, 1)).astype(np.uint8)
+        self._pending.append(self._pool.submit(self._job, path, host, event))
+
+    def close(self) -> None:
+        pending, self._pending = self._pending, []
+        self._pool.shutdown(wait=True)
+        for f in pending:
+            f.result()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

@@ -387,17 +387,23 @@ class Renderer(torch.nn.Module):
         if savedir is not None and os.path.exists(os.path.join(savedir, "{}.png".format(name))):
             print("exists")                                 # bulk renders resume by skipping finished images
             return 0, 0
-        from .io import write_png
+        from .io import PngSink
         frames, disparities = [], []
-        for i, pose in enumerate(render_poses):
-            rgb, disp, _acc, _extras = self.render(height, width, K, chunk=chunk, c2w=pose[:3, :4],
-                                                   shapeCodes=shapeCodes[i, :].reshape(1, -1), uvMap=uvMap[i, :],
-                                                   expType=expType[i], **render_kwargs)
-            frames.append(rgb.detach().cpu().numpy())
-            disparities.append(disp.detach().cpu().numpy())
-            if savedir is not None:
-                write_png(out_file(i), (255 * np.clip(frames[-1], 0, 1)).astype(np.uint8))
-        return np.stack(frames, 0), np.stack(disparities, 0)
+        shared = getattr(self, "png_sink", None)            # a bulk driver may install one sink for the whole job, so that
+        sink = shared if shared is not None else PngSink()  # encoding overlaps the NEXT render_path call as well
+        try:                                                # quantise on device, pinned D2H, encode on worker threads
+            for i, pose in enumerate(render_poses):
+                rgb, disp, _acc, _extras = self.render(height, width, K, chunk=chunk, c2w=pose[:3, :4],
+                                                       shapeCodes=shapeCodes[i, :].reshape(1, -1), uvMap=uvMap[i, :],
+                                                       expType=expType[i], **render_kwargs)
+                if savedir is not None:
+                    sink.submit(out_file(i), rgb)
+                frames.append(rgb.detach())
+                disparities.append(disp.detach())
+        finally:
+            if shared is None:
+                sink.close()
+        return torch.stack(frames, 0).cpu().numpy(), torch.stack(disparities, 0).cpu().numpy()
 
 
 myRenderer = Renderer   # the reference's class name

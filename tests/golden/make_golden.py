@@ -250,7 +250,41 @@ def g5_render_tex():
                                 rgb0=ex["rgb0"], z_std=ex["z_std"], raw=ex["raw"], losses=ex["losses"]))
 
 
+def g6_schema():
+    """Checkpoint schema as the reference's own modules report it: state-dict key -> shape for both shipped networks, the
+    StyleModule and the texture encoder, the optimizer's param-group layout over ``grad_vars`` (create_model_condition.py:
+    25-63) and the top-level keys run_train.py:371-379 writes.  Shapes only - no weights."""
+    import json
+    r = mk_renderer(196608, 0)
+    coarse = NeRF(D=8, W=256, input_ch_shapeCodes=50, input_ch_textureCodes=256, input_ch=93, output_ch=5, skips=[4],
+                  input_ch_views=27, use_viewdirs=True)
+    fine = NeRF(D=10, W=1024, input_ch_shapeCodes=50, input_ch_textureCodes=256, input_ch=93, output_ch=5, skips=[4],
+                input_ch_views=27, use_viewdirs=True)
+    grad_vars = list(coarse.parameters()) + list(fine.parameters()) + list(r.grad_parameter())
+    opt = torch.optim.Adam(params=grad_vars, lr=5e-5, betas=(0.9, 0.999))
+    sd = lambda m: {k: list(v.shape) for k, v in m.state_dict().items()}
+    out = {
+        "network_fn_state_dict": sd(coarse), "network_fine_state_dict": sd(fine),
+        "network_render_textureEncoder": sd(r.texEncoder), "network_render_idSpecific": sd(r.idSpecificMod),
+        "expression_latent_codes_sigma": [list(t.shape) for t in r.expCodes_Sigma],
+        "grad_vars_shapes": [list(p.shape) for p in grad_vars],
+        "optimizer_param_groups": [{k: (len(v) if k == "params" else v) for k, v in g.items()
+                                    if k in ("params", "lr", "betas", "eps", "weight_decay", "amsgrad")}
+                                   for g in opt.state_dict()["param_groups"]],
+        "top_level_keys": ["global_step", "network_fn_state_dict", "network_fine_state_dict",
+                           "network_render_textureEncoder", "network_render_idSpecific", "optimizer_state_dict",
+                           "expression_latent_codes_sigma"],
+        "n_params": {"coarse": sum(p.numel() for p in coarse.parameters()), "fine": sum(p.numel() for p in fine.parameters()),
+                     "texEncoder": sum(p.numel() for p in r.texEncoder.parameters()),
+                     "idSpecific": sum(p.numel() for p in r.idSpecificMod.parameters())},
+    }
+    p = os.path.join(HERE, "schema.json")
+    with open(p, "w") as f:
+        json.dump(out, f, indent=0)
+    print(f"wrote schema.json: {os.path.getsize(p) / 1024:.1f} KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
     for w in which:
-        {"g1": g1_kats, "g2": g2_small, "g3": g3_true, "g4": g4_grads, "g5": g5_render_tex}[w]()
+        {"g1": g1_kats, "g2": g2_small, "g3": g3_true, "g4": g4_grads, "g5": g5_render_tex, "g6": g6_schema}[w]()

@@ -53,8 +53,11 @@ def main(argv=None):
                     n += 0 if isinstance(r[0], int) else 1          # (0, 0) = already on disk
         return n
 
+    from mofanerf_amd.io import PngSink
     torch.cuda.synchronize(); t0 = time.perf_counter()
+    render.png_sink = PngSink(workers=4)                 # one sink for the job: PNG encoding overlaps the following frames
     done = steps.bulk_render_identities(render, kw, list(range(a.identities)), render_identity, rank, world)
+    render.png_sink.close(); render.png_sink = None      # every file is on disk inside the timed region
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     total = torch.tensor([float(sum(done))], dtype=torch.float64)
     if world > 1:
