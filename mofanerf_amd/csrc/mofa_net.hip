@@ -363,7 +363,9 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     // ---- dispatch: one persistent launch for widths <= 256 (every layer of a point tile lives in one workgroup), else
     //      one launch per layer.  MOFA_FUSED=0/1 overrides the heuristic (tests / A-B).
     const char* fused_env = getenv("MOFA_FUSED");
-    const bool fused = p.Wp <= 256 && (fused_env ? fused_env[0] == '1' : Mp / kRowTile >= 128);
+    // the opt-in split-product modes run 128-multiple widths per layer (the persistent kernel is exact-fp32 only)
+    const bool split_here = split_pieces != 0 && packed_split && p.Wp % 128 == 0;
+    const bool fused = p.Wp <= 256 && (fused_env ? fused_env[0] == '1' : (Mp / kRowTile >= 128 && !split_here));
     if (fused) {
         const float* arena = tape ? tape : workspace;
         const int n = (int)steps.size();
