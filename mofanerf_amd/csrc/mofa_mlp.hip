@@ -51,7 +51,28 @@ struct LayerArgs {
     int S;
     int n_tiles;          // n_padded / BN
     int total_tiles;
+    int y_hh;             // opt-in fp16x3 mode only: write y as pre-split fp16 piece panels (store_quad_hh)
 };
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// "hh" activation panels (opt-in fp16x3 mode): same bytes and swizzle as an fp32 panel row (64 B = four
+// 16-B chunks per point and 16 features), but the chunks hold PRE-SPLIT fp16 pieces: chunk 2G = h1 of features 8G..8G+7,
+// chunk 2G+1 = h2 of the same features (x = h1 + h2 + O(2^-23 |x|), both round-to-nearest).  The consuming kernel's
+// operand fragment is then exactly the two 16-B reads it already makes - no conversion work per use.
+// `v` = features n..n+3 (n % 4 == 0) of point m; msw = (m >> 2) & 3.
+__device__ __forceinline__ void store_quad_hh(float* __restrict__ y, long long m_padded, int n, long long m, int msw,
+                                              const f32x4 v) {
+    f16x4 h1, h2;
+    h1.x = (_Float16)v.x, h1.y = (_Float16)v.y, h1.z = (_Float16)v.z, h1.w = (_Float16)v.w;
+    h2.x = (_Float16)(v.x - (float)h1.x), h2.y = (_Float16)(v.y - (float)h1.y);
+    h2.z = (_Float16)(v.z - (float)h1.z), h2.w = (_Float16)(v.w - (float)h1.w);
+    const int G = (n >> 3) & 1, half = (n >> 2) & 1;
+    float* row = y + (long long)(n >> 4) * m_padded * 16 + m * 16 + half * 2;
+    *(f16x4*)(row + (((2 * G) ^ msw) << 2)) = h1;
+    *(f16x4*)(row + (((2 * G + 1) ^ msw) << 2)) = h2;
+}
 
 __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
     // 16 B per lane, LDS destination = wave-uniform base + lane*16 (LDS-DMA, no VGPR round trip)
@@ -102,7 +123,7 @@ __device__ __forceinline__ void mma_panel(const float* __restrict__ Xt, const fl
 #ifndef MOFA_LAYER_WAVES
 #define MOFA_LAYER_WAVES 2  // min waves per SIMD the register allocator must leave room for (= workgroups per CU)
 #endif
-template <int BN, bool L0, bool GLDS, bool BWD = false>
+template <int BN, bool L0, bool GLDS, bool BWD = false, bool HH = false>
 __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BM = kRowTile;
@@ -283,7 +304,8 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
                 if (a.relu) {
                     v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
                 }
-                *(f32x4*)(a.y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
+                if constexpr (HH) store_quad_hh(a.y, a.m_padded, n, m, msw, v);
+                else *(f32x4*)(a.y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
             }
         }
     }
@@ -292,7 +314,7 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
 // ---- heads: sigma = sigmaCodes . w + b (model.py:130), rgb = v . W3 + b3 (model.py:134) ---------
 __global__ __launch_bounds__(256) void k_head(const float* __restrict__ x, int kp, long long m_padded,
                                               const float* __restrict__ w, const float* __restrict__ b, int n_out,
-                                              float* __restrict__ raw, int raw_off, long long n_points) {
+                                              float* __restrict__ raw, int raw_off, long long n_points, int hh) {
     const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
     if (m >= n_points) return;
     const int sw = (int)(m >> 2) & 3;
@@ -300,9 +322,26 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ x, int k
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int kt = 0; kt < kp; ++kt) {
         const f32x4* row = (const f32x4*)(x + ((long long)kt * m_padded + m) * 16);
+        float xv[16];
+        if (hh) {   // pre-split fp16 piece panels (store_quad_hh): x = h1 + h2
+#pragma unroll
+            for (int G = 0; G < 2; ++G) {
+                const f16x8 h1 = __builtin_bit_cast(f16x8, row[(2 * G) ^ sw]);
+                const f16x8 h2 = __builtin_bit_cast(f16x8, row[(2 * G + 1) ^ sw]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[8 * G + e] = (float)h1[e] + (float)h2[e];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 t = row[c ^ sw];
+                xv[4 * c] = t.x, xv[4 * c + 1] = t.y, xv[4 * c + 2] = t.z, xv[4 * c + 3] = t.w;
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const f32x4 v = row[c ^ sw];
+            f32x4 v;
+            v.x = xv[4 * c], v.y = xv[4 * c + 1], v.z = xv[4 * c + 2], v.w = xv[4 * c + 3];
             const int k = kt * 16 + 4 * c;
             for (int o = 0; o < n_out; ++o) {
                 const float* wo = w + (long long)o * K + k;
@@ -647,11 +686,15 @@ __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, bf16x8 (&
     }
 }
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 // 8 fp32 values -> 2 fp16x8 pieces (round-to-nearest split: x = h1 + h2 + O(2^-22 |x|); needs |x| < 65504)
 __device__ __forceinline__ void split8_f16(const f32x4 lo, const f32x4 hi, f16x8 (&out)[2]) {
+#if defined(MOFA_SPLIT_FAKE)      // measurement arm only (wrong numbers): zero-VALU "split" = upper bound of a producer-side split
+    out[0] = __builtin_bit_cast(f16x8, lo);
+    out[1] = __builtin_bit_cast(f16x8, hi);
+    return;
+#endif
     const float r[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -682,8 +725,9 @@ __device__ __forceinline__ f32x16 mfma_split(const Frag& a, const Frag& b, const
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int BN, int P, bool F16 = false>
+template <int BN, int P, bool F16 = false, bool HH = false>
 __global__ __launch_bounds__(256, 2) void k_layer_split(const SplitArgs sa) {
+    static_assert(!HH || (F16 && P == 2), "pre-split activation panels exist for the fp16x3 mode only");
     using Frag = typename SplitFrag<P, F16>::type;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const LayerArgs& a = sa.base;
@@ -753,7 +797,8 @@ __global__ __launch_bounds__(256, 2) void k_layer_split(const SplitArgs sa) {
             const f32x4 lo = *(const f32x4*)(xs + row * 16 + (((2 * g) ^ sw) << 2));
             const f32x4 hi = *(const f32x4*)(xs + row * 16 + (((2 * g + 1) ^ sw) << 2));
             Frag xf[P];
-            split_any<P, F16>(lo, hi, xf);
+            if constexpr (HH) xf[0] = __builtin_bit_cast(Frag, lo), xf[1] = __builtin_bit_cast(Frag, hi);   // pieces as stored
+            else split_any<P, F16>(lo, hi, xf);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 // smallest partial products first
@@ -836,7 +881,8 @@ __global__ __launch_bounds__(256, 2) void k_layer_split(const SplitArgs sa) {
                 if (a.relu) {
                     v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
                 }
-                *(f32x4*)(a.y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
+                if constexpr (HH) store_quad_hh(a.y, a.m_padded, n, m, msw, v);
+                else *(f32x4*)(a.y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
             }
         }
     }
@@ -1072,7 +1118,15 @@ int launch_layer(LayerArgs a, hipStream_t st) {
     const size_t lds = 2 * (size_t)(kRowTile + BN) * 16 * sizeof(float);
     const bool prof = g_prof.on && BN == 128 && !L0 && !BWD;
     if (prof && prof_open(st, 0) != MOFA_OK) return MOFA_EHIP;
-    if constexpr (BWD)
+    bool launched = false;
+    if constexpr (L0 && BN == 128) {
+        if (a.y_hh) {   // opt-in fp16x3 mode: the first layer feeds a split-product layer, so it writes piece panels
+            hipLaunchKernelGGL((k_layer<BN, true, true, false, true>), dim3(grid), dim3(256), lds, st, a);
+            launched = true;
+        }
+    }
+    if (launched) {
+    } else if constexpr (BWD)
         hipLaunchKernelGGL((k_layer<BN, false, true, true>), dim3(grid), dim3(256), lds, st, a);
     else if (stage_mode())
         hipLaunchKernelGGL((k_layer<BN, L0, true>), dim3(grid), dim3(256), lds, st, a);
@@ -1082,7 +1136,7 @@ int launch_layer(LayerArgs a, hipStream_t st) {
     return check_launch(BWD ? "k_layer<BWD>" : (L0 ? "k_layer<L0>" : "k_layer"));
 }
 
-template <int P, bool F16 = false>
+template <int P, bool F16 = false, bool HH = false>
 int launch_layer_split(LayerArgs a, const unsigned short* ws, hipStream_t st) {
     constexpr int BN = 128;
     a.n_tiles = a.n_padded / BN;
@@ -1106,7 +1160,7 @@ int launch_layer_split(LayerArgs a, const unsigned short* ws, hipStream_t st) {
     } else {
         const size_t lds = 2 * (size_t)(kRowTile * 16 + P * BN * 8) * sizeof(float);
         MOFA_REQUIRE(ws, "layer_split: this mode needs the pre-split weight planes");
-        hipLaunchKernelGGL((k_layer_split<BN, P, F16>), dim3((unsigned)round_up(total, 8)), dim3(256), lds, st, sa);
+        hipLaunchKernelGGL((k_layer_split<BN, P, F16, HH>), dim3((unsigned)round_up(total, 8)), dim3(256), lds, st, sa);
     }
     if (prof) prof_close(st, 0, 2.0 * (double)a.m_padded * (double)a.n_padded * 16.0 * (double)(a.k1p + a.k2p));
     return check_launch("k_layer_split");
@@ -1253,7 +1307,7 @@ int mofa_head_forward(const float* x, int32_t k_padded, int64_t m_padded, const 
                      n_points <= m_padded,
                  "head_forward: bad shape");
     hipLaunchKernelGGL(k_head, dim3(blocks_for(n_points)), dim3(256), 0, (hipStream_t)stream, x, k_padded / 16,
-                       (long long)m_padded, w_dense, b, n_out, raw, raw_off, (long long)n_points);
+                       (long long)m_padded, w_dense, b, n_out, raw, raw_off, (long long)n_points, 0);
     return check_launch("k_head");
 }
 
@@ -1295,6 +1349,37 @@ int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops) {
 }
 
 // internal (used by mofa_net.hip): run a list of MFMA layers of one network (all widths <= 256) as ONE persistent launch
+// ---- opt-in fp16x3 mode with pre-split ("hh") activation panels: internal to mofa_net_forward --------------------------
+int mofa_internal_layer0_forward_hh(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
+                                    const float* pts, int64_t n_points, int32_t S, const float* w_packed, const float* bias,
+                                    float* y, int64_t m_padded, int32_t n_padded, void* stream) {
+    MOFA_REQUIRE(n_padded % 128 == 0, "layer0_forward_hh: n_padded %% 128 != 0");
+    LayerArgs a{};
+    a.w = w_packed, a.bias = bias, a.y = y, a.rays_o = rays_o, a.rays_d = rays_d, a.z = z, a.pts = pts;
+    a.z_row_stride = z_row_stride, a.n_points = n_points, a.S = S > 0 ? S : 1;
+    a.k1p = 4, a.k2p = 0, a.n_padded = n_padded, a.m_padded = m_padded, a.relu = 1, a.y_hh = 1;
+    return launch_layer<128, true>(a, (hipStream_t)stream);
+}
+
+int mofa_internal_layer_split_hh(const float* x1, int32_t k1, const float* x2, int32_t k2, const uint16_t* w_split,
+                                 const float* bias, int32_t bias_row_div, int64_t bias_rows, float* y, int64_t m_padded,
+                                 int32_t n_padded, int32_t relu, void* stream) {
+    MOFA_REQUIRE(x1 && w_split && bias && y && n_padded % 128 == 0 && m_padded % kRowTile == 0 && k1 % 16 == 0 && k2 % 16 == 0,
+                 "layer_split_hh: bad arguments");
+    LayerArgs a{};
+    a.x1 = x1, a.x2 = x2, a.bias = bias, a.y = y;
+    a.k1p = k1 / 16, a.k2p = x2 ? k2 / 16 : 0, a.n_padded = n_padded, a.m_padded = m_padded;
+    a.bias_row_div = bias_row_div, a.bias_rows = bias_rows, a.relu = relu, a.y_hh = 1;
+    return launch_layer_split<2, true, true>(a, w_split, (hipStream_t)stream);
+}
+
+int mofa_internal_head_forward_hh(const float* x, int32_t k_padded, int64_t m_padded, const float* w_dense, const float* b,
+                                  int32_t n_out, float* raw, int32_t raw_off, int64_t n_points, void* stream) {
+    hipLaunchKernelGGL(k_head, dim3(blocks_for(n_points)), dim3(256), 0, (hipStream_t)stream, x, k_padded / 16,
+                       (long long)m_padded, w_dense, b, n_out, raw, raw_off, (long long)n_points, 1);
+    return check_launch("k_head(hh)");
+}
+
 int mofa_internal_fused_forward(const float* arena, float* arena_w, const float* packed, const float* folded,
                                 const float* view_bias_rows, long long bias_rows, const float* rays_o, const float* rays_d,
                                 const float* z, long long z_row_stride, const float* pts, long long n_points, int S,

@@ -21,6 +21,14 @@ int mofa_layer_forward_split(const float* x1, int32_t k1, const float* x2, int32
                              int64_t bias_rows, float* y, int64_t m_padded, int32_t n_padded, int32_t relu, void* stream);
 int mofa_pack_split(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, uint16_t* dst,
                     int32_t rows_padded, int32_t panel0, int32_t k_padded, int32_t pieces, void* stream);
+int mofa_internal_layer0_forward_hh(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
+                                    const float* pts, int64_t n_points, int32_t S, const float* w_packed, const float* bias,
+                                    float* y, int64_t m_padded, int32_t n_padded, void* stream);
+int mofa_internal_layer_split_hh(const float* x1, int32_t k1, const float* x2, int32_t k2, const uint16_t* w_split,
+                                 const float* bias, int32_t bias_row_div, int64_t bias_rows, float* y, int64_t m_padded,
+                                 int32_t n_padded, int32_t relu, void* stream);
+int mofa_internal_head_forward_hh(const float* x, int32_t k_padded, int64_t m_padded, const float* w_dense, const float* b,
+                                  int32_t n_out, float* raw, int32_t raw_off, int64_t n_points, void* stream);
 int mofa_internal_fused_forward(const float* arena, float* arena_w, const float* packed, const float* folded,
                                 const float* view_bias_rows, long long bias_rows, const float* rays_o, const float* rays_d,
                                 const float* z, long long z_row_stride, const float* pts, long long n_points, int S,
@@ -366,6 +374,16 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     // the opt-in split-product modes run 128-multiple widths per layer (the persistent kernel is exact-fp32 only)
     const bool split_here = split_pieces != 0 && packed_split && p.Wp % 128 == 0;
     const bool fused = p.Wp <= 256 && (fused_env ? fused_env[0] == '1' : (Mp / kRowTile >= 128 && !split_here));
+    // fp16x3 with pre-split activation panels: every MFMA layer after the first consumes and produces fp16 piece panels
+    // (the split then costs one pass in the producer's epilogue instead of one per consuming N-tile).  Inference only.
+    // Measured (M=196608): +9 % per layer at K=N=1024, -9 % at 256 (the conversion epilogue is amortised over K), so the
+    // default takes it from width 512 up; MOFA_SPLIT_HH=0/1 forces it off/on (A/B, tests).
+    bool hh = split_pieces == -2 && split_here && !tape && !fused;
+    if (hh) {
+        const char* e = getenv("MOFA_SPLIT_HH");
+        hh = e ? e[0] == '1' : p.Wp >= 512;
+        for (const Step& st : steps) hh = hh && p.L[st.li].n_padded % 128 == 0;
+    }
     if (fused) {
         const float* arena = tape ? tape : workspace;
         const int n = (int)steps.size();
@@ -388,7 +406,15 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     } else {
         for (const Step& st : steps) {
             const Layer& l = p.L[st.li];
-            if (!st.x1) {
+            if (!st.x1 && hh) {
+                MOFA_TRY(mofa_internal_layer0_forward_hh(rays_o, rays_d, z, z_row_stride, pts, M, S, packed + l.packed_off,
+                                                         folded + l.folded_off, st.y, Mp, l.n_padded, stream));
+            } else if (hh) {
+                const bool view = st.li == p.view;
+                MOFA_TRY(mofa_internal_layer_split_hh(st.x1, l.k_padded[0], st.x2, st.x2 ? l.k_padded[1] : 0,
+                                                      packed_split + l.split_elems_off * 2, view ? view_bias_rows : folded + l.folded_off,
+                                                      view ? S : 0, view ? n_rays : 1, st.y, Mp, l.n_padded, 1, stream));
+            } else if (!st.x1) {
                 MOFA_TRY(mofa_layer0_forward(rays_o, rays_d, z, z_row_stride, pts, M, S, packed + l.packed_off,
                                              folded + l.folded_off, st.y, Mp, l.n_padded, stream));
             } else if (split_pieces && l.n_padded % 128 == 0) {
@@ -411,11 +437,10 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     // ---- heads: sigma from sigmaCodes, rgb from the view layer's output ------------------------------------------
     {
         const Layer& l = p.L[p.alpha];
-        MOFA_TRY(mofa_head_forward(sigma, l.k_padded[0], Mp, packed + l.packed_off, folded + l.folded_off, 1, raw_out,
-                                   3, M, stream));
+        auto head = hh ? mofa_internal_head_forward_hh : mofa_head_forward;
+        MOFA_TRY(head(sigma, l.k_padded[0], Mp, packed + l.packed_off, folded + l.folded_off, 1, raw_out, 3, M, stream));
         const Layer& r = p.L[p.rgb];
-        MOFA_TRY(mofa_head_forward(v, r.k_padded[0], Mp, packed + r.packed_off, folded + r.folded_off, 3, raw_out, 0,
-                                   M, stream));
+        MOFA_TRY(head(v, r.k_padded[0], Mp, packed + r.packed_off, folded + r.folded_off, 3, raw_out, 0, M, stream));
     }
     return MOFA_OK;
 }

@@ -467,3 +467,36 @@ def test_opt_in_split_product_network(monkeypatch):
     eh = nan_equal_close(outs["fp16x3"], outs["fp32"], 5e-5)
     print(f"raw: bf16x6 vs fp32 {e6:.2e}, bf16x3 vs fp32 {e3:.2e}, fp16x3 vs fp32 {eh:.2e}")
     assert e6 < e3 and eh < e3
+
+
+def test_opt_in_fp16x3_piece_panels(monkeypatch):
+    """fp16x3 can keep activations as PRE-SPLIT fp16 piece panels between layers whenever every layer width is a multiple
+    of 128 (default from width 512 up; forced here for 8 x 256, view layer 128).  Splitting at every use instead (MOFA_SPLIT_HH=0) feeds the matrix pipe the very same
+    pieces, so only the two heads - which then read h1 + h2 instead of the fp32 value, 2^-23 relative - may differ."""
+    from mofanerf_amd.hipnet import HipNet
+    from mofanerf_amd.model import NeRF
+    rng = np.random.default_rng(1)
+    net = NeRF(D=8, W=256, input_ch=93, input_ch_views=27, input_ch_textureCodes=256, input_ch_shapeCodes=50,
+               use_viewdirs=True)
+    net.load_state_dict(synth.nerf_state(8, 256, 0, "coarse"))
+    h = HipNet(net.to(DEV))
+    R, S = 96, 64
+    o = dev(rng.uniform(-2, 2, (R, 3)).astype(np.float32))
+    d = dev(rng.normal(0, 0.3, (R, 3)).astype(np.float32))
+    z = dev(np.sort(rng.uniform(8, 26, (R, S)).astype(np.float32), -1))
+    vd = torch.nn.functional.normalize(d, dim=-1).contiguous()
+    bm, tex, e = synth.codes(2)
+    folded = h.fold(e.to(DEV), bm.to(DEV), tex.to(DEV)).clone()
+    outs = {}
+    for name, gemm, hh in (("fp32", "fp32", "1"), ("panels", "fp16x3", "1"), ("at_use", "fp16x3", "0")):
+        monkeypatch.setenv("MOFA_GEMM", gemm)
+        monkeypatch.setenv("MOFA_SPLIT_HH", hh)
+        raw = torch.full((R, S, 4), float("nan"), device=DEV)
+        h.forward_rays(o, d, z, S, vd, S, raw, folded)
+        torch.cuda.synchronize()
+        outs[name] = raw.cpu().numpy()
+    e_pan = nan_equal_close(outs["panels"], outs["fp32"], 5e-5)
+    e_use = nan_equal_close(outs["at_use"], outs["fp32"], 5e-5)
+    e_rel = nan_equal_close(outs["panels"], outs["at_use"], 1e-6, 1e-6)
+    print(f"raw vs fp32: piece panels {e_pan:.2e}, split at use {e_use:.2e}; panels vs at-use {e_rel:.2e}")
+    assert e_rel > 0 or R * S % 256, "the two modes should differ in the heads' last bits (is the piece-panel path running?)"

@@ -36,6 +36,41 @@ def run_split(M, K, N, pieces, iters=10, version=2):
     return ms, 2.0 * M * K * N / (ms * 1e-3) / 1e12
 
 
+def run_split_hh(M, K, N, iters=10):
+    """fp16x3 with pre-split activation panels (net-internal entry point): time a layer whose INPUT is a real piece-panel
+    tensor (the output of a first call), so operand statistics are those of the running network."""
+    import ctypes as C
+    f = L.mofa_internal_layer_split_hh
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
+                  C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
+    w = torch.randn(N, K, device=dev) * (2.0 / K) ** 0.5
+    b = torch.randn(N, device=dev) * 0.1
+    ws = torch.empty(2 * N * K, dtype=torch.int16, device=dev)
+    st = lib.stream()
+    lib.check(L.mofa_pack_split(lib.ptr(w.contiguous()), N, K, 0, K, ws.data_ptr(), N, 0, K, -2, st), "pack_split")
+    x = torch.zeros(M * K, device=dev)
+    y = torch.empty(M * N, device=dev)
+    # seed: fp32 panels -> (in-register split kernel) would give fp32 output; instead run hh kernel on zeros (-> relu(b)) twice
+    lib.check(f(lib.ptr(x), K, None, 0, ws.data_ptr(), lib.ptr(b), 0, 1, lib.ptr(y), M, N, 1, st), "hh")
+    x2 = y.clone() if K == N else None
+    src = x2 if x2 is not None else x
+    lib.check(f(lib.ptr(src), K, None, 0, ws.data_ptr(), lib.ptr(b), 0, 1, lib.ptr(y), M, N, 1, st), "hh")
+    if K == N:
+        src = y.clone()
+    for _ in range(3):
+        lib.check(f(lib.ptr(src), K, None, 0, ws.data_ptr(), lib.ptr(b), 0, 1, lib.ptr(y), M, N, 1, st), "hh")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        lib.check(f(lib.ptr(src), K, None, 0, ws.data_ptr(), lib.ptr(b), 0, 1, lib.ptr(y), M, N, 1, st), "hh")
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms, 2.0 * M * K * N / (ms * 1e-3) / 1e12
+
+
 def run(M, K, N, k2=0, iters=10):
     x = torch.randn(M * K, device=dev)
     x2 = torch.randn(M * k2, device=dev) if k2 else None
@@ -56,6 +91,15 @@ def run(M, K, N, k2=0, iters=10):
     ms = e0.elapsed_time(e1) / iters
     return ms, 2.0 * M * (K + k2) * N / (ms * 1e-3) / 1e12
 
+
+if __name__ == "__main__" and "--split-hh" in sys.argv:
+    for (M, K, N) in ((196608, 1024, 1024), (196608, 256, 256)):
+        ms, tf = run_split_hh(M, K, N)
+        print(f"split fp16x3 piece panels M={M} K={K} N={N}: {ms:8.3f} ms  {tf:7.2f} algorithmic TFLOP/s  "
+              f"(16-bit pipe at {tf * 3 / 2500 * 100:4.1f}% of 2.5 PF)", flush=True)
+        ms, tf = run_split(M, K, N, -2, version=1)
+        print(f"split fp16x3 split-at-use  M={M} K={K} N={N}: {ms:8.3f} ms  {tf:7.2f} algorithmic TFLOP/s", flush=True)
+    sys.exit(0)
 
 if __name__ == "__main__" and "--split" in sys.argv:
     for version in (1, 2):
