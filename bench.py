@@ -161,7 +161,7 @@ def main():
 
     def sync():
         if world > 1:
-            torch.distributed.barrier()
+            mdist.barrier()
         torch.cuda.synchronize()
 
     for i in range(a.warmup):
@@ -224,7 +224,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.cpu_rays)
         print(json.dumps(out), flush=True)
     if world > 1:
-        torch.distributed.barrier()
+        mdist.barrier()
         torch.distributed.destroy_process_group()
 
 

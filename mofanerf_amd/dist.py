@@ -65,6 +65,17 @@ def all_gather_tiles(local: torch.Tensor, n_total: int, world: int, rank: int, a
     return torch.cat([out[r * mx: r * mx + (e - b)] for r, (b, e) in enumerate(sizes)], 0)
 
 
+def barrier(group=None) -> None:
+    """Barrier that names this rank's own GPU under RCCL (without ``device_ids`` torch has to guess the device of a
+    communicator that has not been used yet)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    if dist.get_backend(group) == "nccl":
+        dist.barrier(group=group, device_ids=[torch.cuda.current_device()])
+    else:
+        dist.barrier(group=group)
+
+
 def barrier_max(seconds: float, device) -> float:
     """Max over ranks of a local duration (bench timing contract)."""
     if not (dist.is_available() and dist.is_initialized()):

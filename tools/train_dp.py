@@ -70,7 +70,7 @@ def main(argv=None):
                           "loss_rank0": [round(l, 5) for l in losses], "parameters_identical_across_ranks": bool(same),
                           "bucket_floats": bucket.numel}), flush=True)
     if world > 1:
-        dist.barrier(); dist.destroy_process_group()
+        mdist.barrier(); dist.destroy_process_group()
     assert same, "ranks diverged"
     return same
 
