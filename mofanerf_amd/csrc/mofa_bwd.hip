@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_composite_backward(
             float sg = v.w;
             if (noise) sg = sg + noise[ray * (long long)S + s];
             sig[t] = sg;                                   // pre-ReLU (sign decides the gate)
-            alpha[t] = 1.0f - expf(-fmaxf(sg, 0.f) * (dlt[t] * dnorm));
+            alpha[t] = 1.0f - expf(-relu_np(sg) * (dlt[t] * dnorm));
             cr[t] = 1.0f / (1.0f + expf(-v.x)), cg[t] = 1.0f / (1.0f + expf(-v.y)), cb[t] = 1.0f / (1.0f + expf(-v.z));
             run = run * ((1.0f - alpha[t]) + 1e-10f);
         } else {
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_composite_backward(
             const float dist = dlt[t] * dnorm;
             const float keep = 1.0f - alpha[t];             // exp(-sigma dist)
             const float dsig = sig[t] > 0.f ? dalpha * dist * keep : 0.f;
-            const float ddist = dalpha * fmaxf(sig[t], 0.f) * keep;
+            const float ddist = dalpha * relu_np(sig[t]) * keep;
             dn_acc += ddist * dlt[t];
             f32x4 o;
             o.x = w[t] * gr * cr[t] * (1.0f - cr[t]);

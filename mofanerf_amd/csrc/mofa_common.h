@@ -22,6 +22,10 @@ __host__ __device__ inline int64_t panel_index(int64_t rows, int64_t row, int k)
            (k & 3);
 }
 
+// ReLU with torch's NaN behaviour (F.relu(nan) = nan; fmaxf(nan, 0) would be 0): a NaN that enters the network - bad
+// input, or an fp16 overflow in the opt-in split mode - must reach the image exactly as it does in the reference.
+__device__ __forceinline__ float relu_np(float v) { return v < 0.f ? 0.f : v; }
+
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
                 v.z = acc[i][j][4 * q + 2] + bv[i][q].z;
                 v.w = acc[i][j][4 * q + 3] + bv[i][q].w;
                 if (a.relu) {
-                    v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                    v.x = relu_np(v.x), v.y = relu_np(v.y), v.z = relu_np(v.z), v.w = relu_np(v.w);
                 }
                 if constexpr (HH) store_quad_hh(a.y, a.m_padded, n, m, msw, v);
                 else *(f32x4*)(a.y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
@@ -613,10 +613,10 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
                         for (int q = 0; q < 4; ++q) {
                             const int n = wn * 64 + 32 * i + 8 * q + 4 * g;
                             f32x4 v;
-                            v.x = fmaxf(acc[i][j][4 * q + 0] + bv[i][q].x, 0.f);
-                            v.y = fmaxf(acc[i][j][4 * q + 1] + bv[i][q].y, 0.f);
-                            v.z = fmaxf(acc[i][j][4 * q + 2] + bv[i][q].z, 0.f);
-                            v.w = fmaxf(acc[i][j][4 * q + 3] + bv[i][q].w, 0.f);
+                            v.x = relu_np(acc[i][j][4 * q + 0] + bv[i][q].x);
+                            v.y = relu_np(acc[i][j][4 * q + 1] + bv[i][q].y);
+                            v.z = relu_np(acc[i][j][4 * q + 2] + bv[i][q].z);
+                            v.w = relu_np(acc[i][j][4 * q + 3] + bv[i][q].w);
                             *(f32x4*)(y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
                         }
                     }
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_split(const SplitArgs sa) {
         __syncthreads();
     }
 
-    // epilogue identical to k_layer's forward epilogue
+    // epilogue: k_layer's forward epilogue (bias + ReLU + panel store), see the F16 / HH notes inline
     f32x4 bv[NI][4];
     int boff = n0 + wn * 64 + 4 * g;
     asm volatile("" : "+v"(boff));
@@ -879,7 +879,9 @@ __global__ __launch_bounds__(256, 2) void k_layer_split(const SplitArgs sa) {
                 v.z = acc[i][j][4 * q + 2] + bv[i][q].z;
                 v.w = acc[i][j][4 * q + 3] + bv[i][q].w;
                 if (a.relu) {
-                    v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                    // relu_np propagates NaN: an operand beyond the fp16 range splits into (+Inf, -Inf), the sum of its
+                    // products is NaN, and that stays visible down to the image (tests/test_gpu_edge.py)
+                    v.x = relu_np(v.x), v.y = relu_np(v.y), v.z = relu_np(v.z), v.w = relu_np(v.w);
                 }
                 if constexpr (HH) store_quad_hh(a.y, a.m_padded, n, m, msw, v);
                 else *(f32x4*)(a.y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
@@ -1041,7 +1043,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_split2(const LayerArgs a) {
                 v.z = acc[i][j][4 * q + 2] + bv[i][q].z;
                 v.w = acc[i][j][4 * q + 3] + bv[i][q].w;
                 if (a.relu) {
-                    v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                    v.x = relu_np(v.x), v.y = relu_np(v.y), v.z = relu_np(v.z), v.w = relu_np(v.w);
                 }
                 *(f32x4*)(a.y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
             }

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
             dist = dist * dnorm;
             float sig = v.w;
             if (noise) sig = sig + noise[ray * (long long)S + s];
-            sig = fmaxf(sig, 0.f);
+            sig = relu_np(sig);
             alpha[t] = 1.0f - expf(-sig * dist);
             cr[t] = 1.0f / (1.0f + expf(-v.x));
             cg[t] = 1.0f / (1.0f + expf(-v.y));

@@ -325,6 +325,9 @@ class Renderer(torch.nn.Module):
         fine = kwargs.get("network_fine")
         self._folded_fine = self._fold_codes(fine, tex_code).clone() if fine is not None else None
         all_ret = self.batchify_rays(chunk, **kwargs)
+        if os.environ.get("MOFA_GEMM") == "fp16x3" and not bool(torch.isfinite(all_ret["rgb_map"]).all()):
+            # the opt-in fp16 split assumes |activation| < 65504; beyond it the pieces overflow to Inf and the result is NaN
+            raise lib.MofaError("MOFA_GEMM=fp16x3: an activation left the fp16 range (non-finite RGB); use fp32 or bf16x6")
         for k in all_ret:
             all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
         ret_list = [all_ret[k] for k in _OUT_KEYS]

@@ -9,7 +9,7 @@ import torch
 
 from conftest import nan_equal_close
 from harness import classify_samples, make_oracle, make_product, to_np
-from mofanerf_amd import factory, lib, synth
+from mofanerf_amd import factory, lib, rays, synth
 from oracle import mofa_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -208,3 +208,51 @@ def test_bulk_render_tool_and_ray_helpers(tmp_path):
     assert torch.allclose(r[1].detach().cpu(), rd_ref[rows.cpu(), cols.cpu()], atol=1e-6)
     r[1].sum().backward()
     assert pose.grad is not None and float(pose.grad.abs().sum()) > 0
+
+
+def test_opt_in_fp16x3_range_contract_is_loud(monkeypatch):
+    """The opt-in fp16x3 mode assumes |activation| < 65504.  Outside it the result must be visibly broken (non-finite RGB ->
+    MofaError), never a plausible wrong image; the default fp32 path and bf16x6 render the same weights fine."""
+    render, kw, _ = make_product((8, 128, 10, 128), 0, 100000, DEV)
+    fine = kw["network_fine"]
+    with torch.no_grad():
+        fine.xyzEncode.linears1.Linear0.weight.mul_(3.0e5)          # first-layer outputs ~1e6: beyond fp16, fine for fp32
+        fine.xyzEncode.linears1.Linear1.weight.mul_(1.0 / 3.0e5)
+    bm, tex, exp = synth.codes(0)
+    K = synth.intrinsics(8, 8)
+    pose = rays.pose_spherical(0.0, 0.0, 16.0)[:3, :4].to(DEV)
+    call = lambda: render.render_fitting(8, 8, K, chunk=4096, c2w=pose, shapeCodes=bm.to(DEV), uvCodes=tex.to(DEV), expType=20,
+                                         expCodes=exp.to(DEV), **kw)
+    with torch.no_grad():
+        monkeypatch.setenv("MOFA_GEMM", "fp32")
+        ref = call()[0]
+        assert torch.isfinite(ref).all()
+        monkeypatch.setenv("MOFA_GEMM", "bf16x6")
+        assert torch.isfinite(call()[0]).all()
+        monkeypatch.setenv("MOFA_GEMM", "fp16x3")
+        with pytest.raises(lib.MofaError, match="fp16 range"):
+            call()
+
+
+def test_nan_input_propagates_like_the_reference():
+    """A NaN ray (bad pose / bad data) yields NaN outputs for that ray in the reference (torch's relu, sigmoid, cumprod all
+    propagate NaN); the HIP path must not turn it into a plausible pixel, and must leave the other rays untouched."""
+    render, kw, _ = make_product(ARCH, 0, 4096, DEV)
+    K, ro, rd = _rays(4)
+    ro = ro.clone()
+    ro[5, 1] = float("nan")
+    bm, tex, exp = _codes()
+    with torch.no_grad():
+        rgb, disp, acc, ex = render.render_fitting(4, 4, K, chunk=16, rays=torch.stack([ro, rd], 0).to(DEV), shapeCodes=bm,
+                                                   uvCodes=tex, expType=20, expCodes=exp, **kw)
+    o = make_oracle(ARCH, 0, 4096)
+    with torch.no_grad():
+        r_rgb, r_disp, r_acc, r_ex = o.render(ro, rd, 16, synth.codes(0)[0], 20, 8.0, 26.0, tex_code=synth.codes(0)[1],
+                                              exp_codes=synth.codes(0)[2], N_samples=64, N_importance=64)
+    assert torch.isnan(r_rgb[5]).all() and torch.isnan(r_ex["rgb0"][5]).all()       # what the reference does
+    for got, want in ((ex["rgb0"], r_ex["rgb0"]), (ex["acc0"], r_ex["acc0"])):
+        nan_equal_close(got.cpu().numpy(), want.numpy(), 1e-4)                      # same NaN pattern, same finite values
+    for got, want in ((rgb, r_rgb), (acc, r_acc)):
+        g, w = got.cpu().numpy(), want.numpy()
+        assert (np.isnan(g) == np.isnan(w)).all()
+    assert torch.isnan(rgb[5]).all() and torch.isnan(acc[5]) and torch.isfinite(rgb[:5]).all() and torch.isfinite(rgb[6:]).all()
