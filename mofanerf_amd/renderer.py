@@ -82,6 +82,7 @@ class Renderer(torch.nn.Module):
         self._weight_grads = False
         self._tex_cache = None
         self._cache: Dict[tuple, torch.Tensor] = {}
+        self.png_sink = None      # optional mofanerf_amd.io.PngSink shared by consecutive render_path calls (bulk renders)
 
     # expCodes_Sigma is a plain list (not registered parameters, render_class.py:53-58): move it with the module
     def _apply(self, fn, *a, **k):
@@ -392,7 +393,7 @@ class Renderer(torch.nn.Module):
             return 0, 0
         from .io import PngSink
         frames, disparities = [], []
-        shared = getattr(self, "png_sink", None)            # a bulk driver may install one sink for the whole job, so that
+        shared = self.png_sink                              # a bulk driver may install one sink for the whole job, so that
         sink = shared if shared is not None else PngSink()  # encoding overlaps the NEXT render_path call as well
         try:                                                # quantise on device, pinned D2H, encode on worker threads
             for i, pose in enumerate(render_poses):
