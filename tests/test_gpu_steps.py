@@ -116,3 +116,41 @@ def test_bench_two_rank_flow_emits_one_contract_json_line():
         assert k in j, k
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["unit"] == "rays/s" and "cpu_baseline" not in j
     assert j["config"]["rays_per_step"] == 64 * 64 and j["dtype"] == "f32"
+
+
+def test_backward_is_deterministic():
+    """Two identical forward+backward passes (perturb=0) give bit-identical gradients for everything the HIP path computes
+    (both networks; the codes and StyleModule behind them): the weight-gradient GEMM sums its split-M partials in a fixed
+    order and nothing on the path uses atomics.  The texture encoder's convolutions run on MIOpen, whose backward-weights
+    kernels are not run-to-run deterministic, so its gradients are only required to be close."""
+    render, _, kw_train = make_product((8, 64, 10, 128), 0, 4096, DEV, with_tex=True)
+    render.train()
+    kw = dict(kw_train, perturb=0.0)
+    params = list(kw["network_fn"].parameters()) + list(kw["network_fine"].parameters()) + list(render.grad_parameter())
+    K, rays = _rays(16, 80, angle=20.0, seed=3)
+    rng = np.random.default_rng(4)
+    uv = torch.from_numpy(rng.uniform(0, 1, (512, 512, 3)).astype(np.float32)).to(DEV)
+    target = torch.from_numpy(rng.uniform(0, 1, (80, 3)).astype(np.float32)).to(DEV)
+    bm = synth.codes(0)[0].to(DEV).expand(80, -1)
+    grads = []
+    for _ in range(2):
+        for p in params:
+            p.grad = None
+        render._tex_cache = None
+        rgb, _, _, ex = render.render(16, 16, K, chunk=80, rays=rays, shapeCodes=bm, uvMap=uv, expType=3, **kw)
+        loss = ((rgb - target) ** 2).mean() + ((ex["rgb0"] - target) ** 2).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append([None if p.grad is None else p.grad.detach().clone() for p in params])
+    n_net = len(list(kw["network_fn"].parameters())) + len(list(kw["network_fine"].parameters()))
+    n_set = 0
+    for i, (a, b) in enumerate(zip(*grads)):
+        assert (a is None) == (b is None)
+        if a is None:
+            continue
+        if i < n_net:
+            assert torch.equal(a, b), f"network parameter {i}"
+            n_set += 1
+        else:
+            assert torch.allclose(a, b, rtol=1e-3, atol=1e-6 + 1e-4 * float(a.abs().max())), f"encoder-side parameter {i}"
+    assert n_set == n_net
