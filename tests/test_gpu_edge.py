@@ -165,6 +165,30 @@ def test_render_path_writes_png_and_resumes(tmp_path):
     assert render._tex_cache is not None
 
 
+def test_render_path_multi_pose_render_factor_and_shared_sink(tmp_path):
+    """Several poses, numbered outputs, `render_factor` (render_class.py:205-209: H, W, focal divided, K untouched), and one
+    asynchronous sink shared across calls: the files hold exactly to8b of the returned frames."""
+    from PIL import Image
+    from mofanerf_amd.io import PngSink
+    render, kw, _ = make_product(ARCH, 0, 4096, DEV, with_tex=True)
+    rng = np.random.default_rng(1)
+    uv = torch.from_numpy(rng.uniform(0, 1, (1, 512, 512, 3)).astype(np.float32)).to(DEV).expand(3, -1, -1, -1)
+    poses = torch.stack([orc.pose_spherical(a, 0.0, 16.0) for a in (-30.0, 0.0, 30.0)], 0)
+    K = synth.intrinsics(16, 16)
+    bm = synth.codes(0)[0].to(DEV).expand(3, -1)
+    render.png_sink = PngSink(workers=2)
+    with torch.no_grad():
+        rgbs, disps = render.render_path(poses, [32, 32, 2 * float(K[0][0])], K, 4096, kw, uvMap=uv,
+                                         expType=torch.tensor([1, 5, 9]), savedir=str(tmp_path), shapeCodes=bm, render_factor=2)
+    render.png_sink.close()
+    render.png_sink = None
+    assert rgbs.shape == (3, 16, 16, 3) and disps.shape == (3, 16, 16)
+    for i in range(3):
+        got = np.asarray(Image.open(tmp_path / f"{i:03d}.png").convert("RGB"))
+        assert np.array_equal(got, (255 * np.clip(rgbs[i], 0, 1)).astype(np.uint8))
+    assert not np.array_equal(rgbs[0], rgbs[2])
+
+
 def test_unsupported_flags_fail_loudly():
     render, kw, _ = make_product(ARCH, 0, 4096, DEV)
     K, ro, rd = _rays(8)
