@@ -94,16 +94,19 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
                      const float* pts, const float* viewdirs, int64_t n_rays, int32_t S, float* workspace,
                      float* raw_out, float* tape, const float* view_bias_rows, const uint16_t* packed_split,
                      int32_t split_pieces, void* stream);
-/* packed_split / split_pieces: NULL / 0 for the shipped exact-fp32 path.  OPT-IN (MOFA_GEMM=bf16x3|bf16x6): weights
- * split_pieces = 2 (bf16x3), 3 (bf16x6) or -2 (fp16x3: two fp16 pieces, needs |values| < 65504) makes layers whose width is a multiple of 128 run the split-product kernel (emulation of the fp32
- * products on the bf16 matrix pipe, fp32 accumulation); packed_split may stay NULL (operands are split in registers from the
- * ordinary fp32 panels) or point to weights pre-split into bf16 planes by mofa_net_pack_split (kernel v1). */
+/* packed_split / split_pieces: NULL / 0 for the shipped exact-fp32 path.  OPT-IN experiment (MOFA_GEMM, default off; DESIGN.md
+ * 3.6): split_pieces = 2 (bf16x3), 3 (bf16x6) or -2 (fp16x3) makes every layer whose width is a multiple of 128 run the
+ * split-product kernel - fp32 products emulated by partial products of 16-bit pieces on the 16-bit matrix pipe, fp32
+ * accumulation.  bf16 modes: packed_split may stay NULL (both operands split in registers from the ordinary fp32 panels, kernel
+ * v2) or point to weights pre-split into bf16 planes by mofa_net_pack_split (kernel v1).  fp16x3 needs packed_split, assumes
+ * |activation| < 65504 (a violation yields NaN in raw_out, never a plausible value) and, without a tape and from width 512 up,
+ * keeps the activations between layers as pre-split fp16 piece panels (internal layout; raw_out is unaffected). */
 size_t mofa_net_packed_split_elems(MofaNetShape s, int32_t pieces);   /* uint16 elements */
 int mofa_net_pack_split(MofaNetShape s, const float* const* weights, uint16_t* dst, int32_t pieces, void* stream);
 int mofa_pack_split(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, uint16_t* dst,
                     int32_t rows_padded, int32_t panel0, int32_t k_padded, int32_t pieces, void* stream);
 /* w_packed (the ordinary fp32 panels) selects v2: both operands split in registers, 3-stage LDS ring; w_split (bf16 planes from
- * mofa_pack_split) selects v1.  At least one of them must be given. */
+ * mofa_pack_split) selects v1 (the only choice for pieces = -2).  At least one of them must be given. */
 int mofa_layer_forward_split(const float* x1, int32_t k1, const float* x2, int32_t k2, const uint16_t* w_split,
                              const float* w_packed, int32_t pieces, const float* bias, int32_t bias_row_div,
                              int64_t bias_rows, float* y, int64_t m_padded, int32_t n_padded, int32_t relu, void* stream);
