@@ -1,6 +1,8 @@
 """End-to-end GPU parity of the drop-in renderer (render_fitting / render / run_network) against the committed golden
 fixtures (outputs of the reference itself) and the CPU oracle.  Tolerance: the north star's fp32 budget of
 1e-4 max-abs on RGB / acc; disp (= 1/depth-like, up to 0.125) relative 1e-4 and NaN-pattern-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -163,6 +165,32 @@ def test_run_network_api():
         raw = kw["network_query_fn"](pts.to(DEV), vd.to(DEV), kw["network_fine"])
     ref = o.run_network(pts, vd, o.fine, bm, tex, 3)
     nan_equal_close(raw.cpu().numpy(), ref.numpy(), 2e-5, 1e-5)
+
+
+def test_integration_md_ctypes_stub_runs_as_written():
+    """The reference-side binding printed in INTEGRATION.md (section 2) is executed verbatim (only the library path is
+    substituted) and must reproduce run_network bit for bit: the documented C-ABI usage is live documentation."""
+    import re
+    from mofanerf_amd import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(# models/hip_backend\.py.*?)```", text, re.S).group(1)
+    assert 'C.CDLL("libmofanerf_hip.so")' in code
+    ns = {}
+    exec(code.replace('C.CDLL("libmofanerf_hip.so")', f'C.CDLL({build.OUT!r})'), ns)
+    render, kw, _ = make_product((8, 64, 10, 128), 0, 100000, DEV)
+    rng = np.random.default_rng(9)
+    pts = T(rng.uniform(-8, 8, (21, 40, 3)).astype(np.float32)).to(DEV)
+    vd = torch.nn.functional.normalize(T(rng.normal(size=(21, 3)).astype(np.float32)), dim=-1).to(DEV)
+    bm, tex, _ = [t.to(DEV) for t in synth.codes(0)]
+    render.shapeCodes, render.expType, render.decoding_texCodes = bm, 3, tex
+    with torch.no_grad():
+        want = kw["network_query_fn"](pts, vd, kw["network_fine"])
+        scale, bias = render.idSpecificMod(bm[:1])
+        e = (scale * render.expCodes_Sigma[3] + bias).reshape(-1).contiguous()
+        got = ns["hip_run_network"](kw["network_fine"], pts, vd, e, bm.reshape(-1)[:50].contiguous(), tex.reshape(-1).contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
 
 
 def test_chunk_and_netchunk_invariance_shipped_sizes():
