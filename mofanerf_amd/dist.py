@@ -14,6 +14,11 @@ from typing import List, Tuple
 import torch
 import torch.distributed as dist
 
+# The host driver of these nodes only supports dmabuf IPC: without this RCCL's cross-process buffer registration fails with
+# "hipIpcGetMemHandle: invalid argument".  It must be in the environment before the HIP runtime initialises (lazy in torch), so
+# it is set when this module is imported; an explicit setting of the caller wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 
 def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     """Initialise the default process group from torchrun's env; returns (rank, world, local_rank)."""
