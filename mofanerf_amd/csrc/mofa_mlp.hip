@@ -311,6 +311,32 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
     }
 }
 
+// ---- measurement aid: what the fp32 matrix pipe sustains with NO memory traffic, barriers or epilogue -----------------------
+// 8 independent 32x32 accumulators per wave (the layer kernel's register blocking), iters x 64 MFMAs each.
+// tools/microbench_layer.py --peak turns the time into TFLOP/s: 156 = 99 % of 157.3, with one OR two waves per SIMD.
+__global__ __launch_bounds__(256, 2) void k_mfma_peak_probe(float* __restrict__ out, int iters) {
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a = (float)threadIdx.x * 1e-3f, b = (float)blockIdx.x * 1e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+            asm volatile("" : "+v"(a), "+v"(b));
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 123.456f) out[0] = s;   // keeps the accumulators alive
+}
+
 // ---- heads: sigma = sigmaCodes . w + b (model.py:130), rgb = v . W3 + b3 (model.py:134) ---------
 __global__ __launch_bounds__(256) void k_head(const float* __restrict__ x, int kp, long long m_padded,
                                               const float* __restrict__ w, const float* __restrict__ b, int n_out,
@@ -1380,6 +1406,12 @@ int mofa_internal_head_forward_hh(const float* x, int32_t k_padded, int64_t m_pa
     hipLaunchKernelGGL(k_head, dim3(blocks_for(n_points)), dim3(256), 0, (hipStream_t)stream, x, k_padded / 16,
                        (long long)m_padded, w_dense, b, n_out, raw, raw_off, (long long)n_points, 1);
     return check_launch("k_head(hh)");
+}
+
+/* measurement aid (tools/microbench_layer.py --peak): `blocks` workgroups of 4 waves running iters x 64 fp32 MFMAs each */
+int mofa_internal_mfma_peak_probe(float* out, int32_t blocks, int32_t iters, void* stream) {
+    hipLaunchKernelGGL(k_mfma_peak_probe, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
+    return check_launch("k_mfma_peak_probe");
 }
 
 int mofa_internal_fused_forward(const float* arena, float* arena_w, const float* packed, const float* folded,

@@ -92,6 +92,30 @@ def run(M, K, N, k2=0, iters=10):
     return ms, 2.0 * M * (K + k2) * N / (ms * 1e-3) / 1e12
 
 
+if __name__ == "__main__" and "--peak" in sys.argv:
+    import ctypes as C
+    f = L.mofa_internal_mfma_peak_probe
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    out = torch.zeros(16, device=dev)
+    iters = 4096
+    for blocks, label in ((512, "2 waves/SIMD (512 workgroups = one round)"), (256, "1 wave/SIMD"), (6144, "2 waves/SIMD, 12 rounds of workgroups")):
+        it = iters if blocks <= 512 else iters // 12
+        for _ in range(2):
+            lib.check(f(lib.ptr(out), blocks, it, lib.stream()), "probe")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            lib.check(f(lib.ptr(out), blocks, it, lib.stream()), "probe")
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        flops = blocks * 4 * it * 64 * 4096.0
+        print(f"pure fp32-MFMA loop, {label}: {ms:7.3f} ms  {flops / (ms * 1e-3) / 1e12:7.2f} TFLOP/s "
+              f"({flops / (ms * 1e-3) / 1e12 / 157.3 * 100:5.1f}% of 157.3)", flush=True)
+    sys.exit(0)
+
 if __name__ == "__main__" and "--split-hh" in sys.argv:
     for (M, K, N) in ((196608, 1024, 1024), (196608, 256, 256)):
         ms, tf = run_split_hh(M, K, N)
