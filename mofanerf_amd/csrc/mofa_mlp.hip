@@ -565,8 +565,11 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
             const bool l0 = l.x1_off < 0;
             const int KT = l.k1p + l.k2p;
             const int np = l.n_padded;
-            const bool active = wn * 64 < np;          // wave-uniform: this wave's feature rows exist in this layer
             const float* wbase = a.packed + l.w_off;
+            // feature blocks of 256 (one for widths <= 256; a 1024-wide layer walks four, re-streaming its X half tile from L2)
+            for (int nb = 0; nb * BNMAX < np; ++nb) {
+            const int nbase = nb * BNMAX;
+            const bool active = nbase + wn * 64 < np;   // wave-uniform: this wave's feature rows exist in this layer
 
             auto stage_issue = [&](int buf, int kt) {
                 float* xs = smem + buf * STAGE;
@@ -585,10 +588,10 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
 #pragma unroll
                     for (int r = 0; r < 2; ++r) glds16(src + (r * 256 + tid) * 4, xs + (r * 256 + wn * 64) * 4);
                 }
-                const float* wsrc = wbase + (long long)kt * np * 16;
+                const float* wsrc = wbase + ((long long)kt * np + nbase) * 16;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if ((r * 256 + wn * 64) * 4 < np * 16)   // wave-uniform guard for layers narrower than 256
+                    if ((r * 256 + wn * 64) * 4 < (np - nbase) * 16)   // wave-uniform guard for (block remainders of) layers narrower than 256
                         glds16(wsrc + (r * 256 + tid) * 4, ws + (r * 256 + wn * 64) * 4);
             };
 
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
             if (active) {
                 float* y = a.arena_w + l.y_off;
                 f32x4 bv[NI][4];
-                int boff = wn * 64 + 4 * g;
+                int boff = nbase + wn * 64 + 4 * g;
                 asm volatile("" : "+v"(boff));
                 if (!l.bias_row_div) {
 #pragma unroll
@@ -637,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
                     for (int i = 0; i < NI; ++i) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const int n = wn * 64 + 32 * i + 8 * q + 4 * g;
+                            const int n = nbase + wn * 64 + 32 * i + 8 * q + 4 * g;
                             f32x4 v;
                             v.x = relu_np(acc[i][j][4 * q + 0] + bv[i][q].x);
                             v.y = relu_np(acc[i][j][4 * q + 1] + bv[i][q].y);
@@ -648,6 +651,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
                     }
                 }
             }
+            }   // feature blocks
             // this workgroup's stores of layer li feed its own loads of layer li+1
             __threadfence_block();
             __syncthreads();
@@ -1428,8 +1432,7 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
     a.z_row_stride = z_row_stride, a.n_points = n_points, a.m_padded = m_padded, a.bias_rows = bias_rows;
     a.S = S > 0 ? S : 1, a.n_layers = n_layers, a.m_tiles = (int)(m_padded / kRowTile);
     for (int i = 0; i < n_layers; ++i) {
-        MOFA_REQUIRE(n_padded[i] > 0 && n_padded[i] <= 256 && n_padded[i] % 64 == 0, "fused_forward: layer %d has n_padded=%d", i,
-                     n_padded[i]);
+        MOFA_REQUIRE(n_padded[i] > 0 && n_padded[i] % 64 == 0, "fused_forward: layer %d has n_padded=%d", i, n_padded[i]);
         a.L[i] = FusedLayer{x1_off[i], x2_off[i], y_off[i], w_off[i], bias_off[i], k1p[i], k2p[i], n_padded[i], bias_row_div[i]};
     }
     hipStream_t st = (hipStream_t)stream;

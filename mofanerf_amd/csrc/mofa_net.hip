@@ -373,7 +373,7 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     const char* fused_env = getenv("MOFA_FUSED");
     // the opt-in split-product modes run 128-multiple widths per layer (the persistent kernel is exact-fp32 only)
     const bool split_here = split_pieces != 0 && packed_split && p.Wp % 128 == 0;
-    const bool fused = p.Wp <= 256 && (fused_env ? fused_env[0] == '1' : (Mp / kRowTile >= 128 && !split_here));
+    const bool fused = fused_env ? fused_env[0] == '1' : (p.Wp <= 256 && Mp / kRowTile >= 128 && !split_here);
     // fp16x3 with pre-split activation panels: every MFMA layer after the first consumes and produces fp16 piece panels
     // (the split then costs one pass in the producer's epilogue instead of one per consuming N-tile).  Inference only.
     // Measured (M=196608): +9 % per layer at K=N=1024, -9 % at 256 (the conversion epilogue is amortised over K), so the
