@@ -121,19 +121,24 @@ class HipNet:
                                         lib.ptr(t), lib.ptr(self._folded), lib.stream()), "mofa_net_fold")
         return self._folded
 
-    def workspace(self, n_points: int, n_rays: int, device) -> torch.Tensor:
+    def workspace(self, n_points: int, n_rays: int, device, slot: int = 0) -> torch.Tensor:
+        """Activation buffers of one sub-batch.  ``slot`` > 0: an independent buffer for a sub-batch that runs concurrently on
+        another stream."""
         n = self._L.mofa_net_workspace_floats(self.shape, n_points, n_rays)
-        if self._ws is None or self._ws.numel() < n or self._ws.device != device:
-            self._ws = torch.empty(n, dtype=torch.float32, device=device)
-        return self._ws
+        if self._ws is None:
+            self._ws = {}
+        ws = self._ws.get(slot)
+        if ws is None or ws.numel() < n or ws.device != device:
+            ws = self._ws[slot] = torch.empty(n, dtype=torch.float32, device=device)
+        return ws
 
     # -- forward -----------------------------------------------------------------------------------
     def forward_rays(self, rays_o, rays_d, z, z_row_stride: int, viewdirs, S: int, raw_out: torch.Tensor,
-                     folded: Optional[torch.Tensor] = None):
+                     folded: Optional[torch.Tensor] = None, slot: int = 0):
         """raw_out[R,S,4] = NeRF(PE(o + d z), codes, PE(viewdirs)) for R rays x S samples."""
         R = viewdirs.shape[0]
         view = self._linears[-3]
-        ws = self.workspace(R * S, R, viewdirs.device)
+        ws = self.workspace(R * S, R, viewdirs.device, slot)
         sp, pieces = self.split()
         lib.check(self._L.mofa_net_forward(self.shape, lib.ptr(self.packed()),
                                            lib.ptr(folded if folded is not None else self._folded),

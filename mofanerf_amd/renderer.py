@@ -82,7 +82,15 @@ class Renderer(torch.nn.Module):
         self._weight_grads = False
         self._tex_cache = None
         self._cache: Dict[tuple, torch.Tensor] = {}
+        self.n_streams = int(os.environ.get("MOFA_STREAMS", "1"))   # concurrent sub-batches of the inference path (render_rays)
+        self._streams = {}
         self.png_sink = None      # optional mofanerf_amd.io.PngSink shared by consecutive render_path calls (bulk renders)
+
+    def _side_streams(self, n, dev):
+        key = (str(dev), n)
+        if key not in self._streams:
+            self._streams[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        return self._streams[key]
 
     # expCodes_Sigma is a plain list (not registered parameters, render_class.py:53-58): move it with the module
     def _apply(self, fn, *a, **k):
@@ -239,9 +247,27 @@ class Renderer(torch.nn.Module):
                          for i in range(0, R, rays_per)]
                 return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
             raw = torch.empty(R, n_s, 4, dtype=torch.float32, device=dev)
-            for i in range(0, R, rays_per):
+            starts = list(range(0, R, rays_per))
+            n_str = min(self.n_streams, len(starts))
+            if n_str <= 1:
+                for i in starts:
+                    j = min(R, i + rays_per)
+                    h.forward_rays(rays_o[i:j], rays_d[i:j], zv[i:j] if zs else zv, zs, vd[i:j], n_s, raw[i:j], folded)
+                return raw
+            # Independent sub-batches round-robin over a few streams: kernels of different streams are not in step with each
+            # other, so one stream's launch boundaries (tail, write burst, first fetches) are filled by the others' workgroups.
+            h.packed(), h.split()                                   # (re)pack on the main stream, before the side streams fork
+            main = torch.cuda.current_stream(dev)
+            side = self._side_streams(n_str, dev)
+            for s_ in side:
+                s_.wait_stream(main)
+            for k, i in enumerate(starts):
                 j = min(R, i + rays_per)
-                h.forward_rays(rays_o[i:j], rays_d[i:j], zv[i:j] if zs else zv, zs, vd[i:j], n_s, raw[i:j], folded)
+                with torch.cuda.stream(side[k % n_str]):
+                    h.forward_rays(rays_o[i:j], rays_d[i:j], zv[i:j] if zs else zv, zs, vd[i:j], n_s, raw[i:j], folded,
+                                   slot=k % n_str)
+            for s_ in side:
+                main.wait_stream(s_)
             return raw
 
         raw = network(network_fn, self._folded_coarse, z, z_stride, S)

@@ -199,8 +199,9 @@ def test_chunk_and_netchunk_invariance_shipped_sizes():
     arch = (8, 256, 10, 1024)
     K = synth.intrinsics(32, 32)
     outs = []
-    for chunk, netchunk in ((300, 196608), (128, 8192), (77, 5000)):
+    for chunk, netchunk, n_streams in ((300, 196608, 1), (128, 8192, 1), (77, 5000, 1), (300, 4096, 3)):
         render, kw, _ = make_product(arch, 0, netchunk, DEV)
+        render.n_streams = n_streams            # > 1: independent sub-batches run concurrently on side streams (MOFA_STREAMS)
         bm, tex, exp = synth.codes(0)
         from oracle import mofa_oracle as orc
         ro, rd = orc.get_rays(32, 32, K, orc.pose_spherical(-60.0, 0.0, 16.0)[:3, :4])
