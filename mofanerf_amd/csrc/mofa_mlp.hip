@@ -314,27 +314,51 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
 // ---- measurement aid: what the fp32 matrix pipe sustains with NO memory traffic, barriers or epilogue -----------------------
 // 8 independent 32x32 accumulators per wave (the layer kernel's register blocking), iters x 64 MFMAs each.
 // tools/microbench_layer.py --peak turns the time into TFLOP/s: 156 = 99 % of 157.3, with one OR two waves per SIMD.
-__global__ __launch_bounds__(256, 2) void k_mfma_peak_probe(float* __restrict__ out, int iters) {
+__global__ __launch_bounds__(256, 2) void k_mfma_peak_probe(float* __restrict__ out, int iters, int random_operands) {
     f32x16 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    float a = (float)threadIdx.x * 1e-3f, b = (float)blockIdx.x * 1e-3f;
+    // random_operands: every lane gets its own pseudo-random operand values (|v| ~ 1e-3 .. 1) and their mantissa bits are
+    // re-scrambled with integer ops once per 64 MFMAs, so that the multiplier inputs toggle like real data instead of sitting
+    // at two constants - the question being whether the pipe's sustained rate depends on the data
+    unsigned h = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u + 12345u);
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h = h * 1664525u + 1013904223u;
+        a[e] = random_operands ? __uint_as_float(0x3A000000u | (h & 0x05FFFFFFu) | ((h >> 3) & 0x80000000u)) : (float)threadIdx.x * 1e-3f;
+        h = h * 1664525u + 1013904223u;
+        b[e] = random_operands ? __uint_as_float(0x3A000000u | (h & 0x05FFFFFFu) | ((h >> 5) & 0x80000000u)) : (float)blockIdx.x * 1e-3f;
+    }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
-            asm volatile("" : "+v"(a), "+v"(b));
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[(e + i) & 7], acc[i], 0, 0, 0);
+        }
+        if (random_operands) {
+            // random_operands == 2: the control - identical instruction stream, but the scramble keeps only bits that are
+            // already set (mask 0), so the operands stay what they were
+            const unsigned keep = random_operands == 2 ? 0u : 0x007FFFFFu;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                h = h * 1664525u + 1013904223u;
+                a[e] = __uint_as_float((__float_as_uint(a[e]) & ~keep) | (h & keep));
+                b[e] = __uint_as_float((__float_as_uint(b[e]) & ~keep) | (((h >> 7) | (h << 3)) & keep));
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(a[e]), "+v"(b[e]));
         }
     }
-    float s = 0.f;
+    float s_ = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s += acc[i][r];
-    if (s == 123.456f) out[0] = s;   // keeps the accumulators alive
+        for (int r = 0; r < 16; ++r) s_ += acc[i][r];
+    if (s_ == 123.456f) out[0] = s_;   // keeps the accumulators alive
 }
 
 // ---- heads: sigma = sigmaCodes . w + b (model.py:130), rgb = v . W3 + b3 (model.py:134) ---------
@@ -1413,8 +1437,8 @@ int mofa_internal_head_forward_hh(const float* x, int32_t k_padded, int64_t m_pa
 }
 
 /* measurement aid (tools/microbench_layer.py --peak): `blocks` workgroups of 4 waves running iters x 64 fp32 MFMAs each */
-int mofa_internal_mfma_peak_probe(float* out, int32_t blocks, int32_t iters, void* stream) {
-    hipLaunchKernelGGL(k_mfma_peak_probe, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
+int mofa_internal_mfma_peak_probe(float* out, int32_t blocks, int32_t iters, int32_t random_operands, void* stream) {
+    hipLaunchKernelGGL(k_mfma_peak_probe, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, iters, random_operands);
     return check_launch("k_mfma_peak_probe");
 }
 

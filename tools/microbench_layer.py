@@ -96,18 +96,22 @@ if __name__ == "__main__" and "--peak" in sys.argv:
     import ctypes as C
     f = L.mofa_internal_mfma_peak_probe
     f.restype = C.c_int
-    f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     out = torch.zeros(16, device=dev)
     iters = 4096
-    for blocks, label in ((512, "2 waves/SIMD (512 workgroups = one round)"), (256, "1 wave/SIMD"), (6144, "2 waves/SIMD, 12 rounds of workgroups")):
+    for blocks, rnd, label in ((512, 0, "constant operands, 2 waves/SIMD (512 workgroups = one round)"), (256, 0, "constant operands, 1 wave/SIMD"),
+                               (6144, 0, "constant operands, 2 waves/SIMD, 12 rounds of workgroups"),
+                               (512, 1, "RANDOM operands re-scrambled every 64 MFMAs, 2 waves/SIMD"), (256, 1, "RANDOM operands, 1 wave/SIMD"),
+                               (512, 2, "control: same instruction stream, operands unchanged, 2 waves/SIMD"),
+                               (256, 2, "control: same instruction stream, operands unchanged, 1 wave/SIMD")):
         it = iters if blocks <= 512 else iters // 12
         for _ in range(2):
-            lib.check(f(lib.ptr(out), blocks, it, lib.stream()), "probe")
+            lib.check(f(lib.ptr(out), blocks, it, rnd, lib.stream()), "probe")
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            lib.check(f(lib.ptr(out), blocks, it, lib.stream()), "probe")
+            lib.check(f(lib.ptr(out), blocks, it, rnd, lib.stream()), "probe")
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
