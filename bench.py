@@ -1,28 +1,36 @@
 #!/usr/bin/env python3
 """Benchmark of the MoFaNeRF ray-marching hot path on MI355X.
 
-One "step" = one 512x512 novel view (262,144 rays; 64 coarse + 128 fine network samples per ray) through
-the shipped network sizes (coarse 256x8, fine 1024x10; tools/config_parser.py:17-24) with
-chunk = netchunk = 196608 (configs/exp_mofanerf.txt:9-10) — BASELINE.json configs[1].  Weights are the seeded
+Default (`--mode render`, the headline = BASELINE.json configs[1]): one "step" = one 512x512 novel view (262,144 rays;
+64 coarse + 128 fine network samples per ray) through the shipped network sizes (coarse 256x8, fine 1024x10;
+tools/config_parser.py:17-24) with chunk = netchunk = 196608 (configs/exp_mofanerf.txt:9-10).  Weights are the seeded
 synthetic recipe (no checkpoint is downloadable), inputs are resident in HBM before the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode render|fit|train]
 
-N > 1: the frame's rows are split into N contiguous blocks (one process per GPU), each rank runs the whole
-coarse->fine pipeline on its block, and one RCCL all-gather of the [rays/N, 5] tiles reassembles the frame on
-every rank inside the timed region (strong scaling: total work fixed).
+`--gpus N` with N > 1 and no torchrun environment: bench.py re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` (one process per
+GPU, RCCL), so `python bench.py --gpus 8` alone produces the line; launched under torchrun it uses the environment it finds.
 
-Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel (the BN=128 fp32-MFMA layer kernel): algorithmic
-FLOPs of its launches / their summed duration measured with HIP events on the launch stream, against the fp32
-MFMA peak of 157.3 TFLOP/s.  `cpu_baseline` times the CPU oracle on a bounded sample of the same frame (rank 0,
-N = 1 only).
+  render  N > 1: the frame's rows are split into N contiguous blocks, each rank runs the whole coarse->fine pipeline on its
+          block, ONE RCCL all-gather of the [rays/N, 5] tiles reassembles the frame on every rank inside the timed region
+          (scaling "strong": total work fixed).
+  fit     BASELINE configs[2]: run_fit.py's photometric step, N_rand = 1024 rays, forward + backward to codes / light
+          (no weight gradients); N > 1 = independent replicas (too small to shard), scaling "weak".
+  train   BASELINE configs[4]: run_train.py's step, N_rand = 4096 rays per GPU, texture encoder, forward + backward incl.
+          weight gradients, ONE RCCL all-reduce of the flat gradient bucket, Adam; scaling "weak".
+
+Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel of the mode (render/fit: the BN=128 fp32-MFMA layer kernel;
+train: whichever of forward / backward-data / weight-gradient kernels has the largest summed time): algorithmic FLOPs of its
+launches / their summed duration measured with HIP events on the launch stream, against the fp32 MFMA peak of 157.3 TFLOP/s.
+`cpu_baseline` times the CPU oracle on a bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,12 +40,16 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from mofanerf_amd import dist as mdist, factory, lib, schema, synth  # noqa: E402
+from mofanerf_amd import dist as mdist, factory, lib, schema, steps as msteps, synth  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 H = W = 512
 ARCH = (8, 256, 10, 1024)
 N_SAMPLES, N_IMPORTANCE = 64, 64
+KERNELS = ["mofa::k_layer<128,false,true> (fp32 MFMA Linear+bias+ReLU)",
+           "mofa::k_mlp_fused (persistent fp32-MFMA network kernel, widths <= 256)",
+           "mofa::k_layer<128,false,true,BWD> (fp32 MFMA backward-data GEMM + ReLU mask)",
+           "mofa::k_wgrad<128,256> (fp32 MFMA weight-gradient GEMM, contraction over points)"]
 
 
 def pose_spherical(phi_deg, theta_deg, radius):
@@ -55,7 +67,7 @@ def flops_per_ray(folded=True):
                 (N_SAMPLES + N_IMPORTANCE) * schema.mac_per_point(Df, Wf, folded))
 
 
-def build_product(device, seed=0):
+def build_product(device, seed=0, with_tex=False):
     Dc, Wc, Df, Wf = ARCH
     args = factory.default_args(netdepth=Dc, netwidth=Wc, netdepth_fine=Df, netwidth_fine=Wf, no_reload=True,
                                 device=device, basedir="/nonexistent", N_samples=N_SAMPLES, N_importance=N_IMPORTANCE)
@@ -63,15 +75,17 @@ def build_product(device, seed=0):
     kw["network_fn"].load_state_dict(synth.nerf_state(Dc, Wc, seed, "coarse"))
     kw["network_fine"].load_state_dict(synth.nerf_state(Df, Wf, seed, "fine"))
     render.idSpecificMod.load_state_dict(synth.style_state(seed))
+    if with_tex:
+        render.texEncoder.load_state_dict(synth.tex_encoder_state(seed))
     for dst, src in zip(render.expCodes_Sigma, synth.exp_sigma(seed)):
         dst.data[:] = src.to(dst.device)
     kw.update(near=8.0, far=26.0)
     return render.eval(), kw, args
 
 
-def cpu_baseline(n_rays, seed=0):
+def cpu_baseline(n_rays, seed=0, backward=False):
     """Time the CPU oracle (restatement of the reference, proven equal to it by tests/test_oracle_golden.py) on the
-    first `n_rays` rays of the centre rows of the same frame."""
+    first `n_rays` rays of the centre rows of the same frame (`backward`: forward + autograd backward to the codes)."""
     from oracle import mofa_oracle as orc
     Dc, Wc, Df, Wf = ARCH
     cores = os.cpu_count() or 1
@@ -84,36 +98,58 @@ def cpu_baseline(n_rays, seed=0):
 
     def run(n, chunk=4096):
         t0 = time.perf_counter()
-        o.render(ro[:n], rd[:n], chunk, bm, 20, 8.0, 26.0, tex_code=tex, exp_codes=exp, N_samples=N_SAMPLES,
-                 N_importance=N_IMPORTANCE)
+        if backward:
+            cs = [t.clone().requires_grad_(True) for t in (bm, tex, exp)]
+            rgb, _, _, _ = o.render(ro[:n], rd[:n], chunk, cs[0], 20, 8.0, 26.0, tex_code=cs[1], exp_codes=cs[2],
+                                    N_samples=N_SAMPLES, N_importance=N_IMPORTANCE)
+            rgb.abs().mean().backward()
+        else:
+            with torch.no_grad():
+                o.render(ro[:n], rd[:n], chunk, bm, 20, 8.0, 26.0, tex_code=tex, exp_codes=exp, N_samples=N_SAMPLES,
+                         N_importance=N_IMPORTANCE)
         return time.perf_counter() - t0
 
-    with torch.no_grad():
-        # torch's intra-op pool oversubscribes badly on a 2-socket host (measured: 256 threads are 25x slower than 16),
-        # so the thread count is calibrated on a 64-ray slice and the fastest setting is used for the timed sample.
-        best, best_t = 1, float("inf")
-        for th in sorted({t for t in (8, 16, 32, 64) if t <= cores} | {min(cores, 8)}):
-            torch.set_num_threads(th)
-            run(8)
-            t = run(min(64, n_rays))
-            if t < best_t:
-                best, best_t = th, t
-        torch.set_num_threads(best)
+    # torch's intra-op pool oversubscribes badly on a 2-socket host (measured: 256 threads are 25x slower than 16),
+    # so the thread count is calibrated on a 64-ray slice and the fastest setting is used for the timed sample.
+    best, best_t = 1, float("inf")
+    for th in sorted({t for t in (8, 16, 32, 64) if t <= cores} | {min(cores, 8)}):
+        torch.set_num_threads(th)
         run(8)
-        dt = run(n_rays)
+        t = run(min(64, n_rays))
+        if t < best_t:
+            best, best_t = th, t
+    torch.set_num_threads(best)
+    run(8)
+    dt = run(n_rays)
+    what = "forward + backward to the codes" if backward else "one forward pass, no_grad"
     return {"value": round(n_rays / dt, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_rays} rays (centre rows of the same 512x512 frame), same networks/codes, one pass, "
-                      f"{dt:.1f} s; torch CPU fp32 oracle, no_grad, anomaly detection off; threads = fastest of "
+            "sample": f"{n_rays} rays (centre rows of the same 512x512 frame), same networks/codes, {what}, "
+                      f"{dt:.1f} s; torch CPU fp32 oracle, anomaly detection off; threads = fastest of "
                       f"8/16/32/64 on a 64-ray calibration slice; host has {cores} logical CPUs"}
+
+
+def self_spawn(n):
+    """`python bench.py --gpus N` without a torchrun environment: re-execute under torch.distributed.run (one rank per GPU)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL buffer registration)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     global H, W, ARCH
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cpu-rays", type=int, default=1024, help="rays in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--mode", choices=["render", "fit", "train"], default="render",
+                    help="render = the headline (BASELINE configs[1]); fit / train = configs[2] / configs[4] (forward + backward)")
+    ap.add_argument("--cpu-rays", type=int, default=None, help="rays in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--arch", type=int, nargs=4, default=list(ARCH), metavar=("Dc", "Wc", "Df", "Wf"),
                     help="network sizes; default = shipped config (8 256 10 1024).  '8 256 8 256' is the labelled variant "
                          "BASELINE.md lists (fine net as small as the coarse one)")
@@ -121,43 +157,92 @@ def main():
                     help="fp32 (default, the headline: exact fp32 MFMA).  bf16x6 / bf16x3 = OPT-IN split-product emulation of "
                          "the fp32 products on the bf16 matrix pipe — a labelled experiment, not the headline")
     ap.add_argument("--size", type=int, default=512, help="image side (512 = the benchmark; smaller only for functional tests)")
+    ap.add_argument("--rays", type=int, default=None, help="fit / train: N_rand per GPU (default 1024 / 4096)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(a.gpus))
     H = W = a.size
     ARCH = tuple(a.arch)
     os.environ["MOFA_GEMM"] = a.gemm
+    d_steps, d_warm = {"render": (2, 1), "fit": (10, 3), "train": (4, 4)}[a.mode]   # train: MIOpen searches conv solvers first
+    a.steps = d_steps if a.steps is None else a.steps
+    a.warmup = d_warm if a.warmup is None else a.warmup
+    if a.cpu_rays is None:
+        a.cpu_rays = {"render": 1024, "fit": 256, "train": 0}[a.mode]
 
     rank, world, local = mdist.init_from_env()
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N>1)"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU fallback for the product path"
     local = local % torch.cuda.device_count()     # (several ranks may share a GPU only in the gloo functional test)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     L = lib.load()
 
-    render, kw, args = build_product(dev)
+    render, kw, args = build_product(dev, with_tex=(a.mode == "train"))
     bm, tex, exp = (t.to(dev) for t in synth.codes(0))
     K = synth.intrinsics(H, W)
     n_total = H * W
-    b, e = mdist.shard_range(n_total, rank, world, align=W)           # whole image rows per rank
-    angles = [0.0, -60.0, 60.0]                                         # run_fit.py's three novel views
+    comm_ms = []                                                       # per-step collective time on this rank (N > 1)
 
-    def frame_rays(angle):
+    def timed_comm(fn):
+        if world == 1:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        comm_ms.append((e0, e1))
+        return out
+
+    def all_rays(angle, b, n):
         c2w = pose_spherical(angle, 0.0, 16.0)[:3, :4].contiguous().to(dev)
-        n = e - b
         o, d, v = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(3))
         lib.check(L.mofa_get_rays(H, W, float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]), lib.ptr(c2w), b, n,
                                   lib.ptr(o), lib.ptr(d), lib.ptr(v), lib.stream()), "mofa_get_rays")
-        return torch.stack([o, d], 0)
+        return o, d
 
-    rays = {ang: frame_rays(ang) for ang in angles}                     # inputs resident in HBM before timing
+    if a.mode == "render":
+        b, e = mdist.shard_range(n_total, rank, world, align=W)           # whole image rows per rank
+        angles = [0.0, -60.0, 60.0]                                         # run_fit.py's three novel views
+        rays = {ang: torch.stack(all_rays(ang, b, e - b), 0) for ang in angles}   # inputs resident in HBM before timing
+        frame_buf = [None]
+        units_per_step, scaling = n_total, "strong"
 
-    def step(i):
-        r = rays[angles[i % len(angles)]]
-        with torch.no_grad():                                           # render-only, as run_fit.py's novel-view loop
-            rgb, disp, acc, _ = render.render_fitting(H, W, K, chunk=args.chunk, rays=r, shapeCodes=bm, uvCodes=tex,
-                                                      expType=20, expCodes=exp, **kw)
-        tile = torch.cat([rgb, disp[:, None], acc[:, None]], -1)        # [rays/N, 5]
-        return mdist.all_gather_tiles(tile, n_total, world, rank, align=W)
+        def step(i):
+            r = rays[angles[i % len(angles)]]
+            with torch.no_grad():                                           # render-only, as run_fit.py's novel-view loop
+                rgb, disp, acc, _ = render.render_fitting(H, W, K, chunk=args.chunk, rays=r, shapeCodes=bm, uvCodes=tex,
+                                                          expType=20, expCodes=exp, **kw)
+            tile = torch.cat([rgb, disp[:, None], acc[:, None]], -1)        # [rays/N, 5]
+            frame_buf[0] = timed_comm(lambda: mdist.all_gather_tiles(tile, n_total, world, rank, align=W, out=frame_buf[0]))
+            return frame_buf[0]
+    else:
+        n = a.rays or (1024 if a.mode == "fit" else 4096)
+        o, d = all_rays(15.0 + rank, 0, n_total)
+        idx = torch.from_numpy(np.random.default_rng(rank).choice(n_total, n, replace=False)).to(dev)
+        rays_b = torch.stack([o[idx], d[idx]], 0)
+        target = torch.rand(n, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
+        units_per_step, scaling = n * world, "weak"
+        if a.mode == "fit":
+            cs = [t.clone().requires_grad_(True) for t in (bm, tex, exp)]
+            light = torch.ones(1, device=dev, requires_grad=True)
+            opts = [torch.optim.Adam(cs, lr=1e-3), torch.optim.Adam([light], lr=1e-3)]
+
+            def step(i):
+                return msteps.fit_step(render, dict(kw), opts, H, W, K, rays_b, target, cs[0], cs[1], cs[2], light, chunk=n)[0]
+        else:
+            kwt = dict(kw); kwt["perturb"] = 1.0
+            render.train()
+            params = list(kw["network_fn"].parameters()) + list(kw["network_fine"].parameters()) + list(render.grad_parameter())
+            opt = torch.optim.Adam(params, lr=5e-5)
+            bucket = mdist.GradBucket(params)
+            sync0 = bucket.sync
+            bucket.sync = lambda: timed_comm(sync0)
+            uv = torch.rand(512, 512, 3, device=dev)
+            bm_n = bm.expand(n, -1)
+
+            def step(i):
+                return msteps.train_step(render, kwt, opt, bucket, H, W, K, rays_b, target, bm_n, uv, 3, chunk=n)
 
     def sync():
         if world > 1:
@@ -167,61 +252,83 @@ def main():
     for i in range(a.warmup):
         step(i)
     sync()
+    comm_ms.clear()
     lib.check(L.mofa_prof_begin(), "mofa_prof_begin")
     t0 = time.perf_counter()
     for i in range(a.steps):
-        frame = step(a.warmup + i)
+        last = step(a.warmup + i)
     sync()
     dt = time.perf_counter() - t0
-    ms2, launches2, pflops2 = (ctypes.c_double * 2)(), (ctypes.c_int64 * 2)(), (ctypes.c_double * 2)()
-    lib.check(L.mofa_prof_end(ms2, launches2, pflops2), "mofa_prof_end")
+    NK = lib.PROF_KINDS
+    ms, launches, pflops = (ctypes.c_double * NK)(), (ctypes.c_int64 * NK)(), (ctypes.c_double * NK)()
+    lib.check(L.mofa_prof_end(ms, launches, pflops), "mofa_prof_end")
     dt = mdist.barrier_max(dt, dev)
-    assert frame.shape == (n_total, 5) and bool(torch.isfinite(frame[:, :3]).all())
+    comm = sum(e0.elapsed_time(e1) for e0, e1 in comm_ms) / max(1, len(comm_ms)) if comm_ms else 0.0
+    if a.mode == "render":
+        assert last.shape == (n_total, 5) and bool(torch.isfinite(last[:, :3]).all())
+    else:
+        assert bool(torch.isfinite(last).all())
 
     if rank == 0:
-        rays_per_s = n_total * a.steps / dt
-        # dominant kernel = the one with the larger summed time: [0] per-layer MFMA kernel, [1] persistent network kernel.
-        # Its algorithmic FLOPs are 2*M*K*N of its launches; at the benchmark sizes nothing is padded (K, N multiples of 64,
-        # M a multiple of 256), except layer 0's K = 63 -> 64 inside the persistent kernel (0.1 %).
-        dom = 0 if ms2[0] >= ms2[1] else 1
-        kname = ["mofa::k_layer<128,false,true> (fp32 MFMA Linear+bias+ReLU)" if a.gemm == "fp32" else
-                 f"mofa::k_layer_split<128,{3 if a.gemm == 'bf16x6' else 2}> ({a.gemm} split products on the 16-bit matrix pipe; peak quoted = fp32 MFMA)",
-                 "mofa::k_mlp_fused (persistent fp32-MFMA network kernel, widths <= 256)"][dom]
-        ms_dom, launches_dom, alg_flops = ms2[dom], launches2[dom], pflops2[dom]
-        achieved = alg_flops / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
+        units_per_s = units_per_step * a.steps / dt
+        # dominant kernel = the MFMA kernel kind with the largest summed time.  Its algorithmic FLOPs are 2*M*K*N of its
+        # launches; at the benchmark sizes nothing is padded (K, N multiples of 64, M a multiple of 256), except layer 0's
+        # K = 63 -> 64 inside the persistent kernel (0.1 %).
+        dom = max(range(NK), key=lambda k: ms[k])
+        kname = KERNELS[dom]
+        if a.gemm != "fp32" and dom == 0:
+            kname = (f"mofa::k_layer_split<128,{3 if a.gemm == 'bf16x6' else 2}> ({a.gemm} split products on the 16-bit matrix "
+                     "pipe; peak quoted = fp32 MFMA)")
+        achieved = pflops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         traffic, tinfo = None, {}
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")       # PMC-derived bytes/launch (separate --pmc passes)
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and dom == 0 and a.mode == "render" and ARCH == (8, 256, 10, 1024):
             tj = json.load(open(tpath))
             traffic = tj.get("bytes_per_launch")
             tinfo = {"traffic_shape": tj.get("shape"), "traffic_algorithmic_bytes_same_shape": tj.get("algorithmic_bytes_per_launch"),
-                     "mfma_busy_fraction_pmc": tj.get("mfma_busy_fraction")}
+                     "mfma_busy_fraction_pmc": tj.get("mfma_busy_fraction"),
+                     "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc passes on the single-layer driver, not this run)"}
+        others = [{"kernel": KERNELS[k].split(" ")[0], "launches": int(launches[k]), "total_ms": round(ms[k], 2),
+                   "tflops": round(pflops[k] / (ms[k] * 1e-3) / 1e12, 2)} for k in range(NK) if k != dom and ms[k] > 0]
+        fwd = flops_per_ray(True)
+        work = {"render": fwd, "fit": 2 * fwd, "train": 3 * fwd}[a.mode]    # + backward-data (+ weight gradients)
+        metric = {"render": "rendered rays/sec (64c+128f samples) at 512^2 novel-view",
+                  "fit": "fitted rays/sec (run_fit.py photometric step: forward + backward to codes/pose/light, N_rand=1024)",
+                  "train": "trained rays/sec (run_train.py step: forward + backward + weight gradients + Adam, N_rand=4096/GPU)"}[a.mode]
+        workload = {"render": f"{H}x{W} novel view", "fit": f"{units_per_step // world} rays/GPU of a {H}x{W} view, L1 loss",
+                    "train": f"{units_per_step // world} rays/GPU of a {H}x{W} view, MSE(rgb)+MSE(rgb0), texture encoder, Adam"}[a.mode]
+        par = {"render": f"ray-rows x{world} + all-gather", "fit": f"{world} independent replicas",
+               "train": f"data-parallel x{world} + gradient all-reduce"}[a.mode]
         out = {
-            "metric": "rendered rays/sec (64c+128f samples) at 512^2 novel-view", "value": round(rays_per_s, 1),
+            "metric": metric, "value": round(units_per_s, 1),
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32" if a.gemm == "fp32" else f"f32 emulated by {a.gemm} split products (16-bit MFMA, fp32 accumulation) - OPT-IN EXPERIMENT",
             "data": "synthetic",
-            "config": {"workload": f"{H}x{W} novel view, 64 coarse + 128 fine samples/ray, coarse {ARCH[1]}x{ARCH[0]} + fine {ARCH[3]}x{ARCH[2]}, "
-                                   "chunk=netchunk=196608, seeded Xavier weights (BASELINE.json configs[1])",
-                       "rays_per_step": n_total, "parallelism": f"ray-rows x{world} + all-gather",
-                       "gflop_per_ray_folded": round(flops_per_ray(True) / 1e9, 4),
-                       "gflop_per_ray_nominal": round(flops_per_ray(False) / 1e9, 4)},
-            "whole_path_tflops": round(flops_per_ray(True) * rays_per_s / 1e12, 2),
+            "config": {"workload": f"{workload}, 64 coarse + 128 fine samples/ray, coarse {ARCH[1]}x{ARCH[0]} + fine {ARCH[3]}x{ARCH[2]}, "
+                                   f"chunk=netchunk=196608, seeded Xavier weights (BASELINE.json configs[{ {'render': 1, 'fit': 2, 'train': 4}[a.mode] }])",
+                       "mode": a.mode, "rays_per_step": units_per_step, "rays_per_rank_per_step": units_per_step // world,
+                       "parallelism": par,
+                       "gflop_per_ray_folded": round(work / 1e9, 4),
+                       "gflop_per_ray_nominal": round(work / fwd * flops_per_ray(False) / 1e9, 4)},
+            "whole_path_tflops": round(work * units_per_s / 1e12, 2),
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic if dom == 0 else None,
-                         "launches": int(launches_dom), "avg_launch_ms": round(ms_dom / max(1, launches_dom), 4),
-                         "algorithmic_gflop_per_launch": round(alg_flops / max(1, launches_dom) / 1e9, 3),
-                         "share_of_timed_region": round(ms_dom * 1e-3 / dt, 4),
-                         "other_network_kernel": {"kernel": ["k_layer<128,false,true>", "k_mlp_fused"][1 - dom],
-                                                  "launches": int(launches2[1 - dom]), "total_ms": round(ms2[1 - dom], 2),
-                                                  "tflops": round(pflops2[1 - dom] / (ms2[1 - dom] * 1e-3) / 1e12, 2) if ms2[1 - dom] > 0 else None},
-                         **(tinfo if dom == 0 else {})},
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "launches": int(launches[dom]), "avg_launch_ms": round(ms[dom] / max(1, launches[dom]), 4),
+                         "algorithmic_gflop_per_launch": round(pflops[dom] / max(1, launches[dom]) / 1e9, 3),
+                         "share_of_timed_region": round(ms[dom] * 1e-3 / dt, 4),
+                         "other_mfma_kernels": others, **tinfo},
         }
+        if world > 1:
+            out["rccl_ranks"] = world
+            out["backend"] = torch.distributed.get_backend()
+            out["collective"] = {"what": {"render": "all_gather_into_tensor of the [rays/N,5] fp32 tiles, written straight into the frame",
+                                          "fit": "none (replicas)", "train": "all_reduce of the flat fp32 gradient bucket"}[a.mode],
+                                 "avg_ms_per_step_rank0": round(comm, 4)}
         if world == 1 and a.cpu_rays > 0:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_rays)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_rays, backward=(a.mode == "fit"))
         print(json.dumps(out), flush=True)
     if world > 1:
         mdist.barrier()

@@ -44,7 +44,14 @@ extern "C" {
 #define MOFA_ROW_TILE 256 /* activation rows are padded to this */
 
 int mofa_abi_version(void);
-const char* mofa_last_error(void);
+const char* mofa_last_error(void);   /* thread-local text of the calling thread's last failure */
+
+/* Library-wide state is limited to what is listed here; everything else is in caller-owned buffers.
+ *   - measurement / A-B knobs (MOFA_STAGE, MOFA_FUSED, MOFA_PERSIST, MOFA_DEPHASE, MOFA_BN64, MOFA_SPLIT_V, MOFA_SPLIT_HH):
+ *     read from the environment ONCE when the library is loaded into an immutable snapshot; no launch path calls getenv.
+ *     mofa_config_reload() re-reads them (tests and A/B tools that change a knob inside one process call it explicitly).
+ *   - per-device caches (CU count, a one-time function attribute) and the per-device measurement session below. */
+int mofa_config_reload(void);
 
 /* ---- network description -------------------------------------------------------------------
  * NeRF(D, W, use_viewdirs=True, skips=[4]) of models/model.py:80-137.  `weights`/`biases` are the
@@ -179,10 +186,14 @@ int mofa_view_bias(const float* viewdirs, int64_t n_rays, const float* w, int32_
 int mofa_positional_encode(const float* x, int64_t n, int32_t n_freqs, float* out, void* stream);
 
 /* ---- measurement hook ------------------------------------------------------------------------
- * Between mofa_prof_begin() and mofa_prof_end() every launch of the two MFMA network kernels — [0] the per-layer kernel
- * k_layer<128,false,*> and [1] the persistent whole-network kernel k_mlp_fused (widths <= 256) — is bracketed by
- * hipEventRecord on its own stream.  mofa_prof_end() synchronises those events (host blocks) and fills three arrays of
- * length 2: summed kernel time, launch count, padded FLOPs executed.  Used by bench.py only. */
+ * A measurement session of the CALLING THREAD'S CURRENT DEVICE (state is per device, mutex-guarded; with no session
+ * open the launch paths read one atomic flag).  Between mofa_prof_begin() and mofa_prof_end() every launch of the MFMA
+ * kernels — [0] the per-layer forward kernel k_layer<128,false,*> / k_layer_persist<128>, [1] the persistent
+ * whole-network kernel k_mlp_fused (widths <= 256), [2] the backward-data kernel k_layer<128,..,BWD>, [3] the
+ * weight-gradient kernel k_wgrad — is bracketed by hipEventRecord on its own stream.  mofa_prof_end() synchronises those
+ * events (host blocks) and fills three arrays of length MOFA_PROF_KINDS: summed kernel time, launch count, FLOPs
+ * executed (2*M*K*N of the padded shapes).  Used by bench.py only. */
+#define MOFA_PROF_KINDS 4
 int mofa_prof_begin(void);
 int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops);
 
@@ -204,6 +215,12 @@ int mofa_composite_forward(const float* raw, const float* z, int64_t z_row_strid
 int mofa_sample_pdf_merge(const float* z, int64_t z_row_stride, const float* weights, const float* u,
                           int64_t u_row_stride, int64_t n_rays, int32_t S, int32_t Ni, float* z_samples,
                           float* z_fine, float* z_std, void* stream);
+
+/* sample_pdf(bins, weights, N_samples, det / u) exactly as tools/run_nerf_helpers.py:203-247 takes it: bins [n_rays, n_bins]
+ * (row stride given; 0 = one shared row), weights [n_rays, n_bins-1], u as above -> samples [n_rays, Ni].  Same kernel as
+ * mofa_sample_pdf_merge without the mid-point / merge stages; this is the form the reference's own KATs are stated in. */
+int mofa_sample_pdf(const float* bins, int64_t bins_row_stride, const float* weights, const float* u, int64_t u_row_stride,
+                    int64_t n_rays, int32_t n_bins, int32_t Ni, float* samples, void* stream);
 
 #ifdef __cplusplus
 }

@@ -29,9 +29,11 @@ def _ru(v: int, m: int) -> int:
     return (v + m - 1) // m * m
 
 
-def fold_torch(h: HipNet, exp_code: torch.Tensor, shape_code: torch.Tensor, tex_code: torch.Tensor) -> torch.Tensor:
+def fold_torch(h: HipNet, exp_code: torch.Tensor, shape_code: torch.Tensor, tex_code: torch.Tensor,
+               detach_params: bool = False) -> torch.Tensor:
     """Differentiable twin of ``mofa_net_fold``: same blob layout (one ``n_padded`` slice per layer in state-dict order,
-    the view layer skipped, heads padded to 4)."""
+    the view layer skipped, heads padded to 4).  ``detach_params``: gradients flow to the codes only (fitting without
+    weight gradients) — no network parameter receives a ``.grad``."""
     D = h.net.D
     lin = h._linears
     bim0, bim_skip, uv0, uv_skip, view = 4, 9, 4 + D, 9 + D, 4 + 2 * D
@@ -40,26 +42,27 @@ def fold_torch(h: HipNet, exp_code: torch.Tensor, shape_code: torch.Tensor, tex_
     for li, l in enumerate(lin):
         if li == view:
             continue
-        b = l.bias
+        b, w = (l.bias.detach(), l.weight.detach()) if detach_params else (l.bias, l.weight)
         if li == 0:
-            b = b + l.weight[:, schema.PE_POINTS:schema.PE_POINTS + schema.CH_EXP] @ e
+            b = b + w[:, schema.PE_POINTS:schema.PE_POINTS + schema.CH_EXP] @ e
         elif li in (bim0, bim_skip):
-            b = b + l.weight[:, :schema.CH_SHAPE] @ s
+            b = b + w[:, :schema.CH_SHAPE] @ s
         elif li in (uv0, uv_skip):
-            b = b + l.weight[:, :schema.CH_TEX] @ t
+            b = b + w[:, :schema.CH_TEX] @ t
         parts.append(_pad_to(b, 4 if li > view else _ru(l.out_features, 64)))
     return torch.cat(parts)
 
 
-def view_bias_torch(h: HipNet, viewdirs: torch.Tensor) -> torch.Tensor:
+def view_bias_torch(h: HipNet, viewdirs: torch.Tensor, detach_params: bool = False) -> torch.Tensor:
     """Differentiable twin of ``mofa_view_bias``: ``[R, roundup(W/2, 64)]``."""
     l = h._linears[-3]
+    w, b = (l.weight.detach(), l.bias.detach()) if detach_params else (l.weight, l.bias)
     feats = [viewdirs]
     for i in range(4):                                  # multires_views = 4
         f = float(2 ** i)
         feats += [torch.sin(viewdirs * f), torch.cos(viewdirs * f)]
     pe = torch.cat(feats, -1)
-    return _pad_to(pe @ l.weight[:, :schema.PE_VIEWS].t() + l.bias, _ru(l.out_features, 64))
+    return _pad_to(pe @ w[:, :schema.PE_VIEWS].t() + b, _ru(l.out_features, 64))
 
 
 class NetFn(torch.autograd.Function):

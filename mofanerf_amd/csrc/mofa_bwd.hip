@@ -4,6 +4,11 @@
 // Built with -ffp-contract=off like the forward.
 #include "mofa_common.h"
 
+extern "C" {
+int mofa_internal_prof_open(void* stream, int kind);
+void mofa_internal_prof_close(void* stream, int kind, double flops);
+}
+
 namespace mofa {
 namespace {
 
@@ -567,8 +572,11 @@ int launch_wgrad(const float* g, const float* x, long long m_padded, long long n
     constexpr int PSTR = WgCfg<TN, TK>::MC * 16 + 16;
     const size_t lds = 2 * (size_t)(TN / 16 + TK / 16) * PSTR * sizeof(float);
     const dim3 grid((n_padded / TN) * (k_padded / TK), splits);
+    const int prof = mofa_internal_prof_open(st, 3);       // measurement session open? (bench.py --mode train)
+    if (prof < 0) return MOFA_EHIP;
     hipLaunchKernelGGL((k_wgrad<TN, TK>), grid, dim3(256), lds, st, g, x, m_padded, n_points, n_padded, k_padded,
                        chunks_per_split, partial, bias_partial);
+    if (prof) mofa_internal_prof_close(st, 3, 2.0 * (double)n_points * (double)n_padded * (double)k_padded);
     return check_launch("k_wgrad");
 }
 

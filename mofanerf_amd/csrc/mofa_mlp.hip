@@ -19,6 +19,8 @@
 // slab stays resident in the 256 MiB Infinity Cache.
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -308,6 +310,124 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
                 else *(f32x4*)(a.y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
             }
         }
+    }
+}
+
+// ---- persistent twin of k_layer<128,false,true> (MOFA_PERSIST=1; A/B arm) ------------------------------
+// Same tile, same panels, same K loop, same epilogue, bit-identical results.  What changes is the SCHEDULE: the grid is
+// 2 workgroups per CU and every workgroup WALKS its share of the tiles instead of exiting after one, so that
+//   (a) the 5-7 us a freed slot waits for the dispatcher's next workgroup disappears (12 rounds per 196,608-point launch),
+//   (b) the next tile's first operand panel is requested BEFORE the epilogue's 32 stores per lane are issued, so its
+//       ~2.6 us first-fetch latency overlaps the store burst instead of following it,
+//   (c) optionally (MOFA_DEPHASE=1) the 8 feature-tile workgroups of one point tile start late together by a
+//       group-specific fraction of a tile time, so that the chip's workgroups are no longer all in their epilogue at once.
+// XCD-aware walk: block b runs on XCD b % 8; XCD x owns the contiguous logical tile range [x*per, (x+1)*per) and its
+// G/8 workgroups sweep it side by side, so the 8 feature tiles of a point tile are in flight together in ONE L2.
+__global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer_persist(const LayerArgs a, int per_xcd_tiles, int dephase) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BN = 128, BM = kRowTile, NI = 2, NJ = 4;
+    constexpr int STAGE = (BM + BN) * 16, XR = BM / 64, WR = BN / 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    const int KT = a.k1p + a.k2p;
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
+    const int lr = lane & 31, g = lane >> 5;
+
+    auto tile_of = [&](int it, long long& m0, int& n0) -> bool {
+        const int local = w + it * wg_per_xcd;
+        const int logical = xcd * per_xcd_tiles + local;
+        if (local >= per_xcd_tiles || logical >= a.total_tiles) return false;
+        const int mt = logical / a.n_tiles;
+        m0 = (long long)mt * BM, n0 = (logical - mt * a.n_tiles) * BN;
+        return true;
+    };
+    auto stage_issue = [&](int buf, int kt, long long m0, int n0) {
+        float* xs = smem + buf * STAGE;
+        float* ws = xs + BM * 16;
+        const float* base = kt < a.k1p ? a.x1 : a.x2;
+        const int kk = kt < a.k1p ? kt : kt - a.k1p;
+        const float* src = base + ((long long)kk * a.m_padded + m0) * 16;
+#pragma unroll
+        for (int r = 0; r < XR; ++r) glds16(src + (r * 256 + tid) * 4, xs + (r * 256 + wave * 64) * 4);
+        const float* wsrc = a.w + ((long long)kt * a.n_padded + n0) * 16;
+#pragma unroll
+        for (int r = 0; r < WR; ++r) glds16(wsrc + (r * 256 + tid) * 4, ws + (r * 256 + wave * 64) * 4);
+    };
+
+    long long m0 = 0;
+    int n0 = 0;
+    if (!tile_of(0, m0, n0)) return;
+    if (dephase) {
+        // the workgroups of one point tile (consecutive w) share a phase; 64 groups chip-wide -> phases k/64 of a tile time
+        const int grp = (w / a.n_tiles) * 8 + xcd;
+        const int units = ((grp * 37) & 63) * KT / 64;          // one unit = s_sleep 127 = 8128 cycles ~ one K panel of a shared SIMD
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    stage_issue(0, 0, m0, n0);
+    for (int it = 0;; ++it) {
+        f32x16 acc[NI][NJ];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        __syncthreads();                       // panel 0 of this tile has landed (requested before the previous epilogue)
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < KT) stage_issue(cur ^ 1, kt + 1, m0, n0);
+            const float* xs = smem + cur * STAGE;
+            mma_panel<NI, NJ>(xs, xs + BM * 16, wm * (32 * NJ), wn * 64, lane, acc);
+            __syncthreads();
+        }
+        // request the NEXT tile's first panel before this tile's stores (no wave reads LDS any more: the loop ended on a barrier)
+        long long m1 = 0;
+        int n1 = 0;
+        const bool more = tile_of(it + 1, m1, n1);
+        if (more) stage_issue(0, 0, m1, n1);
+        // epilogue: bias + ReLU + panel store (k_layer's, verbatim)
+        f32x4 bv[NI][4];
+        int boff = n0 + wn * 64 + 4 * g;
+        asm volatile("" : "+v"(boff));
+        if (!a.bias_row_div) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(a.bias + boff + 32 * i + 8 * q);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const long long m = m0 + wm * (32 * NJ) + 32 * j + lr;
+            if (a.bias_row_div) {
+                long long brow = m / a.bias_row_div;
+                if (brow >= a.bias_rows) brow = a.bias_rows - 1;
+                const float* bias = a.bias + brow * a.n_padded + n0 + wn * 64 + 4 * g;
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(bias + 32 * i + 8 * q);
+            }
+            const int msw = (int)(m >> 2) & 3;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + 32 * i + 8 * q + 4 * g;
+                    f32x4 v;
+                    v.x = acc[i][j][4 * q + 0] + bv[i][q].x;
+                    v.y = acc[i][j][4 * q + 1] + bv[i][q].y;
+                    v.z = acc[i][j][4 * q + 2] + bv[i][q].z;
+                    v.w = acc[i][j][4 * q + 3] + bv[i][q].w;
+                    if (a.relu) {
+                        v.x = relu_np(v.x), v.y = relu_np(v.y), v.z = relu_np(v.z), v.w = relu_np(v.w);
+                    }
+                    *(f32x4*)(a.y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
+                }
+            }
+        }
+        if (!more) break;
+        m0 = m1, n0 = n1;
     }
 }
 
@@ -684,15 +804,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
 }
 
 int launch_fused(const FusedArgs& a, hipStream_t st) {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-               prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount
-                  : 256;
-    }
+    const int cus = compute_units(current_device());
     const int half_tiles = a.m_tiles * 2;
     const int grid = half_tiles < 2 * cus ? half_tiles : 2 * cus;      // two resident workgroups per CU
     const size_t lds = 2 * (size_t)(128 + 256) * 16 * sizeof(float);   // 48 KiB
@@ -1130,37 +1242,45 @@ __global__ __launch_bounds__(256) void k_pack_split(const float* __restrict__ w,
     }
 }
 
-inline int stage_mode() {  // MOFA_STAGE=reg selects the register-staged A/B arm; default is LDS-DMA
-    const char* e = getenv("MOFA_STAGE");
-    return (e && e[0] == 'r') ? 0 : 1;
-}
+inline int stage_mode() { return config().stage_glds; }  // MOFA_STAGE=reg selects the register-staged A/B arm
 
 // Optional per-launch timing of the dominant kernel (k_layer<128, false, *>) with HIP events recorded on the launch
 // stream; used by bench.py for the live roofline figure.  Off by default (no events, no overhead).
+// The measurement session is explicit state the HOST opens and closes (mofa_prof_begin/end); it is kept per device and
+// guarded by a mutex, so two devices or two host threads in one process do not share or corrupt it.  When no session is
+// open the launch paths only read one relaxed atomic.
+constexpr int kProfKinds = 4;   // 0: k_layer<128,false,*> (forward), 1: k_mlp_fused, 2: k_layer<BWD> (backward-data), 3: k_wgrad
 struct ProfState {
-    bool on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
-    std::vector<int> kind;     // 0: k_layer<128,false,*> launch, 1: k_mlp_fused launch
+    std::vector<int> kind;
     size_t used = 0;
-    double flops[2] = {0.0, 0.0};
+    double flops[kProfKinds] = {0.0, 0.0, 0.0, 0.0};
 };
-ProfState g_prof;
+ProfState g_prof[kMaxDevices];
+std::atomic<bool> g_prof_on[kMaxDevices];
+std::mutex g_prof_mu;
+
+inline bool prof_enabled() { return g_prof_on[current_device()].load(std::memory_order_relaxed); }
 
 inline int prof_open(hipStream_t st, int kind) {
-    if (g_prof.used == g_prof.ev.size()) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfState& P = g_prof[current_device()];
+    if (P.used == P.ev.size()) {
         hipEvent_t e0, e1;
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return check_launch("hipEventCreate");
-        g_prof.ev.emplace_back(e0, e1);
-        g_prof.kind.push_back(kind);
+        P.ev.emplace_back(e0, e1);
+        P.kind.push_back(kind);
     }
-    g_prof.kind[g_prof.used] = kind;
-    (void)hipEventRecord(g_prof.ev[g_prof.used].first, st);
+    P.kind[P.used] = kind;
+    (void)hipEventRecord(P.ev[P.used].first, st);
     return MOFA_OK;
 }
 inline void prof_close(hipStream_t st, int kind, double flops) {
-    (void)hipEventRecord(g_prof.ev[g_prof.used].second, st);
-    g_prof.used++;
-    g_prof.flops[kind] += flops;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfState& P = g_prof[current_device()];
+    (void)hipEventRecord(P.ev[P.used].second, st);
+    P.used++;
+    P.flops[kind] += flops;
 }
 
 template <int BN, bool L0, bool BWD = false>
@@ -1172,12 +1292,25 @@ int launch_layer(LayerArgs a, hipStream_t st) {
     a.total_tiles = (int)total;
     const unsigned grid = (unsigned)round_up(total, 8);
     const size_t lds = 2 * (size_t)(kRowTile + BN) * 16 * sizeof(float);
-    const bool prof = g_prof.on && BN == 128 && !L0 && !BWD;
-    if (prof && prof_open(st, 0) != MOFA_OK) return MOFA_EHIP;
+    const bool prof = BN == 128 && !L0 && prof_enabled();
+    const int pkind = BWD ? 2 : 0;
+    if (prof && prof_open(st, pkind) != MOFA_OK) return MOFA_EHIP;
     bool launched = false;
     if constexpr (L0 && BN == 128) {
         if (a.y_hh) {   // opt-in fp16x3 mode: the first layer feeds a split-product layer, so it writes piece panels
             hipLaunchKernelGGL((k_layer<BN, true, true, false, true>), dim3(grid), dim3(256), lds, st, a);
+            launched = true;
+        }
+    }
+    if constexpr (BN == 128 && !L0 && !BWD) {
+        // MOFA_PERSIST=1: the persistent twin (bit-identical; A/B arm until it is measured faster)
+        const Config& cfg = config();
+        if (!launched && cfg.persist == 1 && stage_mode()) {
+            const int cus = compute_units(current_device());
+            long long G = 2LL * cus / 8 * 8;                                  // two resident workgroups per CU, multiple of 8 XCDs
+            const int per_xcd_tiles = (int)((total + 7) / 8);
+            if (G > 8LL * per_xcd_tiles) G = 8LL * per_xcd_tiles;
+            hipLaunchKernelGGL(k_layer_persist, dim3((unsigned)G), dim3(256), lds, st, a, per_xcd_tiles, cfg.dephase);
             launched = true;
         }
     }
@@ -1188,7 +1321,7 @@ int launch_layer(LayerArgs a, hipStream_t st) {
         hipLaunchKernelGGL((k_layer<BN, L0, true>), dim3(grid), dim3(256), lds, st, a);
     else
         hipLaunchKernelGGL((k_layer<BN, L0, false>), dim3(grid), dim3(256), lds, st, a);
-    if (prof) prof_close(st, 0, 2.0 * (double)a.m_padded * (double)a.n_padded * 16.0 * (double)(a.k1p + a.k2p));
+    if (prof) prof_close(st, pkind, 2.0 * (double)a.m_padded * (double)a.n_padded * 16.0 * (double)(a.k1p + a.k2p));
     return check_launch(BWD ? "k_layer<BWD>" : (L0 ? "k_layer<L0>" : "k_layer"));
 }
 
@@ -1200,17 +1333,17 @@ int launch_layer_split(LayerArgs a, const unsigned short* ws, hipStream_t st) {
     MOFA_REQUIRE(total > 0 && total < (1ll << 30), "layer_split: tile count %lld out of range", total);
     a.total_tiles = (int)total;
     SplitArgs sa{a, ws};
-    const bool prof = g_prof.on;
+    const bool prof = prof_enabled();
     if (prof && prof_open(st, 0) != MOFA_OK) return MOFA_EHIP;
-    const char* ver = getenv("MOFA_SPLIT_V");
-    if (!F16 && a.w && !(ws && ver && ver[0] == '1')) {  // v2: fp32 weight panels split in registers, 3-stage ring (bf16 only)
+    if (!F16 && a.w && !(ws && config().split_v == 1)) {  // v2: fp32 weight panels split in registers, 3-stage ring (bf16 only)
         const size_t lds2 = 3 * (size_t)(kRowTile + BN) * 16 * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static std::atomic<bool> attr_set[kMaxDevices];     // the attribute is per device (per loaded code object)
+        const int dev = current_device();
+        if (!attr_set[dev].load(std::memory_order_acquire)) {
             if (hipFuncSetAttribute((const void*)k_layer_split2<BN, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) !=
                 hipSuccess)
                 return check_launch("hipFuncSetAttribute(k_layer_split2)");
-            attr_set = true;
+            attr_set[dev].store(true, std::memory_order_release);
         }
         hipLaunchKernelGGL((k_layer_split2<BN, P>), dim3((unsigned)round_up(total, 8)), dim3(256), lds2, st, a);
     } else {
@@ -1234,7 +1367,7 @@ int dispatch_layer(LayerArgs a, bool l0, hipStream_t st) {
     MOFA_REQUIRE(a.m_padded > 0 && a.m_padded % kRowTile == 0, "m_padded=%lld must be a positive multiple of %d",
                  a.m_padded, kRowTile);
     MOFA_REQUIRE(a.n_padded > 0 && a.n_padded % 64 == 0, "n_padded=%d must be a positive multiple of 64", a.n_padded);
-    static const bool force64 = getenv("MOFA_BN64") != nullptr;   // measurement knob (tools/microbench_layer.py)
+    const bool force64 = config().bn64 != 0;   // measurement knob (tools/microbench_layer.py)
     if (a.n_padded % 128 == 0 && !force64) return l0 ? launch_layer<128, true>(a, st) : launch_layer<128, false>(a, st);
     return l0 ? launch_layer<64, true>(a, st) : launch_layer<64, false>(a, st);
 }
@@ -1383,26 +1516,40 @@ int mofa_positional_encode(const float* x, int64_t n, int32_t n_freqs, float* ou
 }
 
 int mofa_prof_begin(void) {
-    g_prof.on = true, g_prof.used = 0, g_prof.flops[0] = g_prof.flops[1] = 0.0;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    const int dev = current_device();
+    ProfState& P = g_prof[dev];
+    P.used = 0;
+    for (int k = 0; k < kProfKinds; ++k) P.flops[k] = 0.0;
+    g_prof_on[dev].store(true, std::memory_order_relaxed);
     return MOFA_OK;
 }
 
-/* arrays of 2: [0] = the per-layer MFMA kernel k_layer<128,false,*>, [1] = the persistent kernel k_mlp_fused */
+/* arrays of MOFA_PROF_KINDS (4): [0] the per-layer forward MFMA kernel k_layer<128,false,*> (or its persistent twin),
+ * [1] the persistent network kernel k_mlp_fused, [2] the backward-data kernel k_layer<128,..,BWD>, [3] the weight-gradient
+ * kernel k_wgrad.  Session of the CURRENT device. */
 int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops) {
     MOFA_REQUIRE(total_ms && launches && padded_flops, "prof_end: null pointer");
-    g_prof.on = false;
-    total_ms[0] = total_ms[1] = 0.0, launches[0] = launches[1] = 0;
-    for (size_t i = 0; i < g_prof.used; ++i) {
-        if (hipEventSynchronize(g_prof.ev[i].second) != hipSuccess) return check_launch("hipEventSynchronize");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    const int dev = current_device();
+    ProfState& P = g_prof[dev];
+    g_prof_on[dev].store(false, std::memory_order_relaxed);
+    for (int k = 0; k < kProfKinds; ++k) total_ms[k] = 0.0, launches[k] = 0;
+    for (size_t i = 0; i < P.used; ++i) {
+        if (hipEventSynchronize(P.ev[i].second) != hipSuccess) return check_launch("hipEventSynchronize");
         float t = 0.f;
-        if (hipEventElapsedTime(&t, g_prof.ev[i].first, g_prof.ev[i].second) != hipSuccess)
+        if (hipEventElapsedTime(&t, P.ev[i].first, P.ev[i].second) != hipSuccess)
             return check_launch("hipEventElapsedTime");
-        total_ms[g_prof.kind[i]] += (double)t, launches[g_prof.kind[i]] += 1;
+        total_ms[P.kind[i]] += (double)t, launches[P.kind[i]] += 1;
     }
-    padded_flops[0] = g_prof.flops[0], padded_flops[1] = g_prof.flops[1];
-    g_prof.used = 0;
+    for (int k = 0; k < kProfKinds; ++k) padded_flops[k] = P.flops[k];
+    P.used = 0;
     return MOFA_OK;
 }
+
+/* internal (mofa_bwd.hip): bracket a k_wgrad launch with events when a measurement session is open */
+int mofa_internal_prof_open(void* stream, int kind) { return prof_enabled() ? (prof_open((hipStream_t)stream, kind) == MOFA_OK ? 1 : MOFA_EHIP) : 0; }
+void mofa_internal_prof_close(void* stream, int kind, double flops) { prof_close((hipStream_t)stream, kind, flops); }
 
 // internal (used by mofa_net.hip): run a list of MFMA layers of one network (all widths <= 256) as ONE persistent launch
 // ---- opt-in fp16x3 mode with pre-split ("hh") activation panels: internal to mofa_net_forward --------------------------
@@ -1460,7 +1607,7 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
         a.L[i] = FusedLayer{x1_off[i], x2_off[i], y_off[i], w_off[i], bias_off[i], k1p[i], k2p[i], n_padded[i], bias_row_div[i]};
     }
     hipStream_t st = (hipStream_t)stream;
-    if (!g_prof.on) return launch_fused(a, st);
+    if (!prof_enabled()) return launch_fused(a, st);
     double flops = 0.0;
     for (int i = 0; i < n_layers; ++i) flops += 2.0 * (double)m_padded * (double)n_padded[i] * 16.0 * (double)(k1p[i] + k2p[i]);
     if (prof_open(st, 1) != MOFA_OK) return MOFA_EHIP;

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <utility>
 #include <vector>
 
@@ -65,6 +66,42 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- configuration snapshot + per-device caches (no getenv / no device-0 assumptions on the launch paths) ----------------
+namespace {
+Config read_env() {
+    Config c;
+    auto tri = [](const char* name) { const char* e = getenv(name); return e ? (e[0] == '1' ? 1 : 0) : -1; };
+    const char* e;
+    if ((e = getenv("MOFA_STAGE")) && e[0] == 'r') c.stage_glds = 0;
+    if ((e = getenv("MOFA_SPLIT_V")) && e[0] == '1') c.split_v = 1;
+    c.bn64 = getenv("MOFA_BN64") != nullptr;
+    c.fused = tri("MOFA_FUSED"), c.split_hh = tri("MOFA_SPLIT_HH"), c.persist = tri("MOFA_PERSIST");
+    c.dephase = tri("MOFA_DEPHASE") == 1;
+    return c;
+}
+// two slots + an atomic index: readers never see a half-written snapshot, reload is rare and host-side only
+Config g_cfg[2] = {read_env(), Config{}};
+std::atomic<int> g_cfg_cur{0};
+std::atomic<int> g_cus[kMaxDevices];
+}  // namespace
+
+const Config& config() { return g_cfg[g_cfg_cur.load(std::memory_order_acquire)]; }
+
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev < kMaxDevices ? dev : kMaxDevices - 1;
+}
+
+int compute_units(int device) {
+    int v = g_cus[device].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    hipDeviceProp_t prop;
+    v = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    g_cus[device].store(v, std::memory_order_relaxed);
+    return v;
 }
 
 int check_launch(const char* what) {
@@ -184,6 +221,13 @@ using namespace mofa;
 extern "C" {
 
 int mofa_abi_version(void) { return MOFA_ABI_VERSION; }
+
+int mofa_config_reload(void) {
+    const int next = 1 - g_cfg_cur.load(std::memory_order_acquire);
+    g_cfg[next] = read_env();
+    g_cfg_cur.store(next, std::memory_order_release);
+    return MOFA_OK;
+}
 const char* mofa_last_error(void) { return g_err; }
 
 int mofa_net_num_layers(MofaNetShape s) { return shape_ok(s) ? 2 * s.D + 7 : MOFA_EINVAL; }
@@ -370,18 +414,17 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     }
     // ---- dispatch: one persistent launch for widths <= 256 (every layer of a point tile lives in one workgroup), else
     //      one launch per layer.  MOFA_FUSED=0/1 overrides the heuristic (tests / A-B).
-    const char* fused_env = getenv("MOFA_FUSED");
+    const Config& cfg = config();
     // the opt-in split-product modes run 128-multiple widths per layer (the persistent kernel is exact-fp32 only)
     const bool split_here = split_pieces != 0 && packed_split && p.Wp % 128 == 0;
-    const bool fused = fused_env ? fused_env[0] == '1' : (p.Wp <= 256 && Mp / kRowTile >= 128 && !split_here);
+    const bool fused = cfg.fused >= 0 ? cfg.fused == 1 : (p.Wp <= 256 && Mp / kRowTile >= 128 && !split_here);
     // fp16x3 with pre-split activation panels: every MFMA layer after the first consumes and produces fp16 piece panels
     // (the split then costs one pass in the producer's epilogue instead of one per consuming N-tile).  Inference only.
     // Measured (M=196608): +9 % per layer at K=N=1024, -9 % at 256 (the conversion epilogue is amortised over K), so the
     // default takes it from width 512 up; MOFA_SPLIT_HH=0/1 forces it off/on (A/B, tests).
     bool hh = split_pieces == -2 && split_here && !tape && !fused;
     if (hh) {
-        const char* e = getenv("MOFA_SPLIT_HH");
-        hh = e ? e[0] == '1' : p.Wp >= 512;
+        hh = cfg.split_hh >= 0 ? cfg.split_hh == 1 : p.Wp >= 512;
         for (const Step& st : steps) hh = hh && p.L[st.li].n_padded % 128 == 0;
     }
     if (fused) {

@@ -132,6 +132,9 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
 // cdf follows the CPU reference: cumsum accumulates in double and rounds every prefix to float.
 constexpr int kMaxS = 256, kMaxNi = 256;
 
+// BINS = true is the plain `sample_pdf(bins, weights, N)` entry (mofa_sample_pdf): `z` holds the B bin edges themselves
+// (S := B), `weights` the B-1 bin weights, and nothing is merged (z_fine / z_std may be NULL).
+template <bool BINS>
 __global__ __launch_bounds__(256) void k_sample_pdf_merge(const float* __restrict__ z, long long z_row_stride,
                                                           const float* __restrict__ weights,
                                                           const float* __restrict__ u, long long u_row_stride,
@@ -148,13 +151,13 @@ __global__ __launch_bounds__(256) void k_sample_pdf_merge(const float* __restric
     float* bins = s_bins[wv];
     float* cdf = s_cdf[wv];
     const float* zr = z + ray * z_row_stride;
-    const float* wr = weights + ray * (long long)S;
-    const int B = S - 1;   // len(bins) == len(cdf)
-    const int NW = S - 2;  // interior weights
+    const int B = BINS ? S : S - 1;   // len(bins) == len(cdf)
+    const int NW = B - 1;             // bin weights (the interior weights [1:-1] of the S coarse samples)
+    const float* wr = BINS ? weights + ray * (long long)NW - 1 : weights + ray * (long long)S;   // wr[i + 1] = weight of bin i
 
     for (int s = lane; s < S; s += 64) all[s] = zr[s];
     __builtin_amdgcn_wave_barrier();
-    for (int b = lane; b < B; b += 64) bins[b] = 0.5f * (all[b + 1] + all[b]);
+    for (int b = lane; b < B; b += 64) bins[b] = BINS ? all[b] : 0.5f * (all[b + 1] + all[b]);
 
     // pdf = (w + 1e-5) / sum(w + 1e-5); cdf = [0, cumsum(pdf)]
     double part = 0.0;
@@ -204,7 +207,8 @@ __global__ __launch_bounds__(256) void k_sample_pdf_merge(const float* __restric
         m2 += dlt * dlt;
     }
     m2 = wave_sum_d(m2);
-    if (lane == 0) z_std[ray] = (float)sqrt(m2 / (double)Ni);
+    if (lane == 0 && z_std) z_std[ray] = (float)sqrt(m2 / (double)Ni);
+    if (BINS || !z_fine) return;
 
     // merge by rank: position = #(smaller) + #(equal with a lower index)
     const int N = S + Ni;
@@ -260,10 +264,21 @@ int mofa_sample_pdf_merge(const float* z, int64_t z_row_stride, const float* wei
     MOFA_REQUIRE(z && weights && u && z_samples && z_fine && z_std, "sample_pdf_merge: null pointer");
     MOFA_REQUIRE(n_rays > 0 && S >= 4 && S <= kMaxS && Ni >= 1 && Ni <= kMaxNi,
                  "sample_pdf_merge: need 4 <= S <= %d, 1 <= Ni <= %d", kMaxS, kMaxNi);
-    hipLaunchKernelGGL(k_sample_pdf_merge, dim3(blocks_for(n_rays, kWavesPerBlock)), dim3(256), 0,
+    hipLaunchKernelGGL(k_sample_pdf_merge<false>, dim3(blocks_for(n_rays, kWavesPerBlock)), dim3(256), 0,
                        (hipStream_t)stream, z, (long long)z_row_stride, weights, u, (long long)u_row_stride,
                        (long long)n_rays, S, Ni, z_samples, z_fine, z_std);
     return check_launch("k_sample_pdf_merge");
+}
+
+int mofa_sample_pdf(const float* bins, int64_t bins_row_stride, const float* weights, const float* u, int64_t u_row_stride,
+                    int64_t n_rays, int32_t n_bins, int32_t Ni, float* samples, void* stream) {
+    MOFA_REQUIRE(bins && weights && u && samples, "sample_pdf: null pointer");
+    MOFA_REQUIRE(n_rays > 0 && n_bins >= 3 && n_bins <= kMaxS && Ni >= 1 && Ni <= kMaxNi,
+                 "sample_pdf: need 3 <= n_bins <= %d, 1 <= Ni <= %d", kMaxS, kMaxNi);
+    hipLaunchKernelGGL(k_sample_pdf_merge<true>, dim3(blocks_for(n_rays, kWavesPerBlock)), dim3(256), 0,
+                       (hipStream_t)stream, bins, (long long)bins_row_stride, weights, u, (long long)u_row_stride,
+                       (long long)n_rays, n_bins, Ni, samples, (float*)nullptr, (float*)nullptr);
+    return check_launch("k_sample_pdf");
 }
 
 }  // extern "C"

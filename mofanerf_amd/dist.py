@@ -14,10 +14,13 @@ from typing import List, Tuple
 import torch
 import torch.distributed as dist
 
-# The host driver of these nodes only supports dmabuf IPC: without this RCCL's cross-process buffer registration fails with
-# "hipIpcGetMemHandle: invalid argument".  It must be in the environment before the HIP runtime initialises (lazy in torch), so
-# it is set when this module is imported; an explicit setting of the caller wins.
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+def _rccl_env() -> None:
+    """The host driver of these nodes only supports dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's cross-process
+    buffer registration fails with "hipIpcGetMemHandle: invalid argument".  The variable must be in the environment before the
+    HIP runtime initialises (lazy in torch), so it is defaulted HERE — when a multi-process group is about to be created — not
+    as a side effect of importing the package; an explicit setting of the caller wins."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
@@ -26,6 +29,7 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
+        _rccl_env()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:      # MOFA_DIST_BACKEND=gloo lets several ranks share one GPU (functional test of the N>1 path)
@@ -51,23 +55,38 @@ def shard_list(items: List, rank: int, world: int) -> List:
     return items[b:e]
 
 
-def all_gather_tiles(local: torch.Tensor, n_total: int, world: int, rank: int, align: int = 1, group=None) -> torch.Tensor:
-    """All-gather row blocks produced under :func:`shard_range` into the full ``[n_total, C]`` tensor on every rank.
-    Uneven blocks are padded to the largest block so that a single ``all_gather_into_tensor`` (one RCCL call) does it."""
+def all_gather_tiles(local: torch.Tensor, n_total: int, world: int, rank: int, align: int = 1, group=None,
+                     out: torch.Tensor | None = None) -> torch.Tensor:
+    """All-gather row blocks produced under :func:`shard_range` into the full ``[n_total, C]`` tensor on every rank with ONE
+    collective.  When the blocks are equal (every benchmark shape: 512 rows over 1/2/4/8 ranks) the collective writes straight
+    into the result — no padding, no copies; pass ``out`` to reuse the frame buffer across calls.  Uneven blocks are padded to
+    the largest block and compacted afterwards."""
     if world == 1:
         return local
     sizes = [shard_range(n_total, r, world, align) for r in range(world)]
     mx = max(e - b for b, e in sizes)
+    even = all(e - b == mx for b, e in sizes)
+    stage_host = local.is_cuda and dist.get_backend(group) == "gloo"      # test configuration only: stage through the host
+    if even:
+        if out is None or out.shape[0] != n_total:
+            out = torch.empty(n_total, *local.shape[1:], dtype=local.dtype, device=local.device)
+        if stage_host:
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host, local.contiguous().cpu(), group=group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
     pad = torch.zeros(mx, *local.shape[1:], dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
-    out = torch.empty(world * mx, *local.shape[1:], dtype=local.dtype, device=local.device)
-    if local.is_cuda and dist.get_backend(group) == "gloo":      # test configuration only: stage through the host
-        host = torch.empty(out.shape, dtype=out.dtype)
+    buf = torch.empty(world * mx, *local.shape[1:], dtype=local.dtype, device=local.device)
+    if stage_host:
+        host = torch.empty(buf.shape, dtype=buf.dtype)
         dist.all_gather_into_tensor(host, pad.cpu(), group=group)
-        out.copy_(host)
+        buf.copy_(host)
     else:
-        dist.all_gather_into_tensor(out, pad, group=group)
-    return torch.cat([out[r * mx: r * mx + (e - b)] for r, (b, e) in enumerate(sizes)], 0)
+        dist.all_gather_into_tensor(buf, pad, group=group)
+    return torch.cat([buf[r * mx: r * mx + (e - b)] for r, (b, e) in enumerate(sizes)], 0)
 
 
 def barrier(group=None) -> None:

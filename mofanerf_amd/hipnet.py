@@ -39,6 +39,11 @@ class HipNet:
         self._split: Optional[torch.Tensor] = None
         self._split_key = None
 
+    def invalidate(self):
+        """Forget the packed / transposed / split copies of the weights (they are rebuilt on the next call).  Needed only
+        after an edit made through ``.data``, which bypasses the version counter the cache keys on."""
+        self._packed_key = self._packed_t_key = self._split_key = None
+
     # -- weights -----------------------------------------------------------------------------------
     def _weights(self):
         ws = [l.weight.detach() for l in self._linears]

@@ -27,6 +27,7 @@ class NetShape(C.Structure):
 SIGNATURES = {
     "mofa_abi_version": (C.c_int, []),
     "mofa_last_error": (C.c_char_p, []),
+    "mofa_config_reload": (C.c_int, []),
     "mofa_net_num_layers": (C.c_int, [NetShape]),
     "mofa_net_packed_floats": (_sz, [NetShape]),
     "mofa_net_folded_floats": (_sz, [NetShape]),
@@ -73,6 +74,7 @@ SIGNATURES = {
                                 _fp]),
     "mofa_composite_forward": (C.c_int, [_fp, _fp, _i64, _fp, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
     "mofa_sample_pdf_merge": (C.c_int, [_fp, _i64, _fp, _fp, _i64, _i64, _i32, _i32, _fp, _fp, _fp, _fp]),
+    "mofa_sample_pdf": (C.c_int, [_fp, _i64, _fp, _fp, _i64, _i64, _i32, _i32, _fp, _fp]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -97,6 +99,14 @@ def load() -> C.CDLL:
             raise MofaError(f"ABI version mismatch: library {lib.mofa_abi_version()} != binding 1")
         _lib = lib
     return _lib
+
+
+PROF_KINDS = 4     # MOFA_PROF_KINDS: k_layer fwd, k_mlp_fused, k_layer<BWD>, k_wgrad
+
+
+def reload_env() -> None:
+    """Re-read the library's MOFA_* measurement knobs from the environment (they are read once at load time)."""
+    check(load().mofa_config_reload(), "mofa_config_reload")
 
 
 def check(rc: int, what: str) -> None:

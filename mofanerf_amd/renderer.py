@@ -93,17 +93,27 @@ class Renderer(torch.nn.Module):
         return self._streams[key]
 
     # expCodes_Sigma is a plain list (not registered parameters, render_class.py:53-58): move it with the module
+    # — IN PLACE, the way nn.Module moves parameters: the tensor OBJECTS survive .cuda()/.to()/.float(), so an optimizer or
+    # `grad_vars` built before the move (create_nerf builds them, run_fit.py:175 then calls render.cuda()) keeps training them
     def _apply(self, fn, *a, **k):
         super()._apply(fn, *a, **k)
-        moved = []
-        for t in self.expCodes_Sigma:
-            with torch.no_grad():
-                n = fn(t.detach())
-            n.requires_grad_(t.requires_grad)
-            moved.append(n)
-        self.expCodes_Sigma = moved
+        with torch.no_grad():
+            for t in self.expCodes_Sigma:
+                t.data = fn(t.data)
+                if t.grad is not None:
+                    t.grad.data = fn(t.grad.data)
         self._cache.clear()
         return self
+
+    def invalidate_caches(self):
+        """Drop every derived device-side copy: packed / transposed / split weight panels of both networks, the cached
+        texture code and the constant sample rows.  The caches are keyed on ``(data_ptr, tensor._version)``, which every
+        autograd-visible in-place update bumps (optimizer steps, ``load_state_dict``, ``copy_``) — but an edit made THROUGH
+        ``.data`` (``w.data.copy_(...)``, ``w.data[:] = ...``) does not, so call this after one."""
+        for h in self._hipnets.values():
+            h.invalidate()
+        self._tex_cache = None
+        self._cache.clear()
 
     def grad_parameter(self):
         grad_vars = list(self.expCodes_Sigma)
@@ -146,7 +156,9 @@ class Renderer(torch.nn.Module):
         scale, bias = style(row)
         e = scale * self.expCodes_Sigma[self.expType].to(row.device) + bias
         if torch.is_grad_enabled():
-            return fold_torch(self._hip(net), e, row, tex_code.to(row.device).float())
+            # fitting (no weight gradients requested): the fold uses DETACHED weights and biases, so gradients reach the codes
+            # and the pose only and no network parameter ever receives a partial .grad (it stays None)
+            return fold_torch(self._hip(net), e, row, tex_code.to(row.device).float(), detach_params=not self._weight_grads)
         return self._hip(net).fold(e, row, tex_code.to(row.device))
 
     # ------------------------------------------------------------------------------------------------
@@ -190,20 +202,32 @@ class Renderer(torch.nn.Module):
         if rays.shape[-1] <= 8:
             raise NotImplementedError("use_viewdirs=False is not part of the shipped configuration")
         rays_o, rays_d, vd = (rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous(), rays[:, 8:11].contiguous())
-        near, far = self._near, self._far
         S = int(N_samples)
+        if S > 256 or (N_importance > 0 and S + int(N_importance) > 256):
+            raise NotImplementedError(f"the compositing / resampling kernels hold one ray per wavefront with at most 4 samples per "
+                                      f"lane: N_samples and N_samples + N_importance must be <= 256 (got {S}, {S + int(N_importance)})")
         st = lib.stream()
+        # near / far: the scalar fast path when render()/render_fitting() set them for THIS self.rays; otherwise (per-ray
+        # bounds, or batchify_rays()/render_rays() called directly on a caller-built self.rays) they are read from columns 6:8
+        scalar_bounds = getattr(self, "_rays_id", None) == id(self.rays) and self._near is not None
+        t_row = self._const_row(("t", S), lambda: torch.linspace(0., 1., steps=S), dev)
+        if scalar_bounds:
+            near, far = self._near, self._far
 
-        def z_row():
-            t = torch.linspace(0., 1., steps=S)
-            n, f = torch.tensor([[near]]), torch.tensor([[far]])
-            z = n * (1. - t) + f * t if not lindisp else 1. / (1. / n * (1. - t) + 1. / f * t)
-            return z.reshape(-1)
+            def z_row():
+                t = torch.linspace(0., 1., steps=S)
+                n, f = torch.tensor([[near]]), torch.tensor([[far]])
+                z = n * (1. - t) + f * t if not lindisp else 1. / (1. / n * (1. - t) + 1. / f * t)
+                return z.reshape(-1)
 
-        z = self._const_row(("z", near, far, S, bool(lindisp)), z_row, dev)
-        z_stride = 0
+            z = self._const_row(("z", near, far, S, bool(lindisp)), z_row, dev)
+            z_stride = 0
+        else:
+            n, f = rays[:, 6:7], rays[:, 7:8]
+            z = (n * (1. - t_row) + f * t_row if not lindisp else 1. / (1. / n * (1. - t_row) + 1. / f * t_row)).contiguous()
+            z_stride = S
         if perturb > 0.:
-            zz = z[None, :].expand(R, S)
+            zz = z[None, :].expand(R, S) if z_stride == 0 else z
             mids = .5 * (zz[..., 1:] + zz[..., :-1])
             upper, lower = torch.cat([mids, zz[..., -1:]], -1), torch.cat([zz[..., :1], mids], -1)
             if pytest:
@@ -240,7 +264,7 @@ class Renderer(torch.nn.Module):
             h = self._hip(net)
             rays_per = max(1, int(self.netchunk) // n_s)
             if grad:     # tape-keeping forward per sub-batch; the per-ray view bias is a differentiable torch expression
-                vb = view_bias_torch(h, vd)
+                vb = view_bias_torch(h, vd, detach_params=not self._weight_grads)
                 wts = [l.weight for l in h._linears] if self._weight_grads else []
                 parts = [NetFn.apply(h, rays_o[i:i + rays_per], rays_d[i:i + rays_per],
                                      zv[i:i + rays_per] if zs else zv, zs, n_s, folded, vb[i:i + rays_per], *wts)
@@ -270,6 +294,12 @@ class Renderer(torch.nn.Module):
                 main.wait_stream(s_)
             return raw
 
+        if getattr(self, "_rays_id", None) != id(self.rays):
+            # called directly on a caller-built self.rays (the reference documents batchify_rays / render_rays as callable once
+            # self.rays, shapeCodes, expType and decoding_texCodes are set): fold the per-call codes here
+            self._folded_coarse = self._fold_codes(network_fn, self.decoding_texCodes).clone()
+            self._folded_fine = (self._fold_codes(network_fine, self.decoding_texCodes).clone()
+                                 if network_fine is not None else None)
         raw = network(network_fn, self._folded_coarse, z, z_stride, S)
         c = composite(raw, z, z_stride, S, noise_for(S))
         ret = {"rgb_map": c["rgb"], "disp_map": c["disp"], "acc_map": c["acc"]}
@@ -341,10 +371,19 @@ class Renderer(torch.nn.Module):
         kwargs = dict(kwargs)
         kwargs.pop("network_query_fn", None)
         rays_o, rays_d, viewdirs, sh = self._make_rays(H, W, K, c2w, rays, use_viewdirs, c2w_staticcam, ndc)
-        near, far = _scalar(near), _scalar(far)
-        self._near, self._far = near, far
         ones = torch.ones_like(rays_d[..., :1])
-        self.rays = torch.cat([rays_o, rays_d, near * ones, far * ones, viewdirs], -1)
+
+        def bound(v):      # scalar (the shipped call sites) or a per-ray array, as render_class.py:174 broadcasts it
+            if torch.is_tensor(v) and v.numel() > 1 or isinstance(v, np.ndarray) and v.size > 1:
+                return None, torch.as_tensor(v, dtype=torch.float32).reshape(-1, 1).to(ones.device) * ones
+            return _scalar(v), _scalar(v) * ones
+
+        self._near, ncol = bound(near)
+        self._far, fcol = bound(far)
+        if self._near is None or self._far is None:
+            self._near = self._far = None
+        self.rays = torch.cat([rays_o, rays_d, ncol, fcol, viewdirs], -1)
+        self._rays_id = id(self.rays)
         self.decoding_texCodes = tex_code
         # inference (torch.no_grad(), as the reference's render-only call sites run): pure HIP, nothing recorded;
         # with autograd enabled (fitting / training) the tape-keeping forward + HIP backward path is used

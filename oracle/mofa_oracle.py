@@ -215,9 +215,13 @@ class OracleRenderer:
     def render_rays(self, rays: Tensor, shape_codes: Tensor, tex_code: Tensor, exp_type: int, N_samples: int,
                     N_importance: int, perturb: float = 0.0, white_bkgd: bool = False, lindisp: bool = False,
                     t_rand: Optional[Tensor] = None, u: Optional[Tensor] = None, noise0: Optional[Tensor] = None,
-                    noise1: Optional[Tensor] = None, retraw: bool = False, keep: bool = False):
+                    noise1: Optional[Tensor] = None, retraw: bool = False, keep: bool = False,
+                    w0_perturb: Optional[Tensor] = None):
         """``rays [R,11] = o3 d3 near far viewdir3``.  Stochastic inputs are explicit:
-        ``t_rand [R,S]`` (stratified jitter, :305), ``u [R,Ni]`` (:215), ``noise*`` (:463)."""
+        ``t_rand [R,S]`` (stratified jitter, :305), ``u [R,Ni]`` (:215), ``noise*`` (:463).
+        ``w0_perturb [R,S]`` (checker-only, not in the reference): multiplies the coarse weights before the resampling —
+        ``1 + U(-1e-6, 1e-6)`` mimics the rounding differences of a second correct fp32 implementation, so the outputs under
+        it measure how far THIS algorithm's pixels move by themselves (tests/harness.py::envelope_stats)."""
         R = rays.shape[0]
         o, d, vd = rays[:, 0:3], rays[:, 3:6], rays[:, 8:11]
         near, far = rays[:, 6:7], rays[:, 7:8]
@@ -237,7 +241,7 @@ class OracleRenderer:
             zmid = 0.5 * (z[..., 1:] + z[..., :-1])
             if u is None:
                 u = torch.linspace(0.0, 1.0, steps=N_importance)
-            zs = sample_pdf(zmid, w0[..., 1:-1], u)
+            zs = sample_pdf(zmid, (w0 if w0_perturb is None else w0 * w0_perturb)[..., 1:-1], u)
             zf, _ = torch.sort(torch.cat([z, zs], -1), -1)
             pts = o[..., None, :] + d[..., None, :] * zf[..., :, None]
             raw1 = self.run_network(pts, vd, self.fine if self.fine is not None else self.coarse, shape_codes,
@@ -273,7 +277,7 @@ class OracleRenderer:
         rays = torch.cat([o, d, near * torch.ones_like(d[:, :1]), far * torch.ones_like(d[:, :1]), vd], -1)
         parts: Dict[str, list] = {}
         dbg: Dict[str, list] = {}
-        per_ray = ("t_rand", "u", "noise0", "noise1")
+        per_ray = ("t_rand", "u", "noise0", "noise1", "w0_perturb")
         for i in range(0, rays.shape[0], chunk):
             kwi = {k: (v[i:i + chunk] if k in per_ray and v is not None and v.dim() > 1 else v) for k, v in kw.items()}
             r = self.render_rays(rays[i:i + chunk], shape_codes, tex_code, exp_type, **kwi)

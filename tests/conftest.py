@@ -36,3 +36,18 @@ def nan_equal_close(a, b, atol, rtol=0.0):
     lim = atol + rtol * np.abs(np.where(nb, 0, b))
     assert (d <= lim).all(), f"max abs err {d.max():.3e} (limit {atol:.1e}+{rtol:.1e}*|ref|)"
     return float(d.max())
+
+
+@pytest.fixture
+def knob(monkeypatch):
+    """Set a MOFA_* measurement knob for one test.  The library reads its knobs ONCE at load time (no getenv on the launch
+    paths), so after changing the environment the snapshot is re-read explicitly — and once more when the test ends."""
+    from mofanerf_amd import lib
+
+    def set_(name, value):
+        monkeypatch.setenv(name, value)
+        lib.reload_env()
+
+    yield set_
+    monkeypatch.undo()
+    lib.reload_env()

@@ -170,8 +170,7 @@ def g1_kats():
     save("kat.npz", out)
 
 
-def _render_case(name, H, K, angle, Dc, Wc, Df, Wf, chunk, netchunk, perturb=0.0, noise=0.0, white=False,
-                 pytest=False, intermediates=True, seed=0):
+def _case_setup(H, K, angle, Dc, Wc, Df, Wf, chunk, netchunk, perturb=0.0, noise=0.0, white=False, pytest=False, seed=0):
     r = mk_renderer(netchunk, seed)
     coarse, fine = mk_nerf(Dc, Wc, seed, "coarse"), mk_nerf(Df, Wf, seed, "fine")
     kw = kwargs_for(r, coarse, fine, perturb, noise, white)
@@ -179,11 +178,18 @@ def _render_case(name, H, K, angle, Dc, Wc, Df, Wf, chunk, netchunk, perturb=0.0
         kw["pytest"] = True
     bm, tex, exp = synth.codes(seed)
     c2w = pose_spherical(angle, 0.0, 16.0)[:3, :4]
-    out = dict(c2w=c2w, K=K, bm=bm, tex=tex, exp=exp, H=H, chunk=chunk, netchunk=netchunk,
-               arch=np.array([Dc, Wc, Df, Wf]), seed=seed, perturb=perturb, noise=noise, white=int(white))
+    meta = dict(c2w=c2w, K=K, bm=bm, tex=tex, exp=exp, H=H, chunk=chunk, netchunk=netchunk,
+                arch=np.array([Dc, Wc, Df, Wf]), seed=seed, perturb=perturb, noise=noise, white=int(white))
+    call = lambda: r.render_fitting(H, H, K, chunk=chunk, c2w=c2w, shapeCodes=bm, uvCodes=tex, expType=20, expCodes=exp,
+                                    retraw=True, **kw)
+    return call, meta
+
+
+def _render_case(name, H, K, angle, Dc, Wc, Df, Wf, chunk, netchunk, perturb=0.0, noise=0.0, white=False,
+                 pytest=False, intermediates=True, seed=0):
+    call, out = _case_setup(H, K, angle, Dc, Wc, Df, Wf, chunk, netchunk, perturb, noise, white, pytest, seed)
     with torch.no_grad(), Recorder() as rec:
-        rgb, disp, acc, ex = r.render_fitting(H, H, K, chunk=chunk, c2w=c2w, shapeCodes=bm, uvCodes=tex,
-                                              expType=20, expCodes=exp, retraw=True, **kw)
+        rgb, disp, acc, ex = call()
     out.update(rgb=rgb, disp=disp, acc=acc, rgb0=ex["rgb0"], disp0=ex["disp0"], acc0=ex["acc0"], z_std=ex["z_std"])
     if intermediates:
         nch = len(rec.spdf)
@@ -195,6 +201,35 @@ def _render_case(name, H, K, angle, Dc, Wc, Df, Wf, chunk, netchunk, perturb=0.0
         out["weights_fine"] = torch.cat([rec.r2o[2 * i + 1]["weights"] for i in range(nch)])
         out["z_samples"] = torch.cat([s["samples"] for s in rec.spdf])
     save(name, out)
+
+
+def _envelope(call, n_pert, eps, verbose=True):
+    """The reference's outputs under ``n_pert`` seeded relative perturbations ``w * (1 + U(-eps, eps))`` of its OWN coarse
+    weights (class PerturbCoarse), next to its unperturbed sample positions: the per-ray envelope a second correct fp32
+    implementation must land in.  ``moved``: samples per ray that move by more than 1e-3; ``agree``: every new sample of the
+    ray stays within a few ulp (6e-6) of the unperturbed one."""
+    import time
+    with torch.no_grad(), Recorder() as rec:
+        rgb, disp, acc, ex = call()
+    zs0 = torch.cat([s["samples"] for s in rec.spdf])
+    P = {k: [] for k in ("rgb", "acc", "disp", "z_std", "moved", "agree")}
+    for k in range(n_pert):
+        t0 = time.time()
+        with torch.no_grad(), PerturbCoarse(1000 + k, eps) as pc:
+            rgb_k, disp_k, acc_k, ex_k = call()
+        zs = torch.cat(pc.spdf)
+        P["rgb"].append(rgb_k.reshape(-1, 3)); P["acc"].append(acc_k.reshape(-1)); P["disp"].append(disp_k.reshape(-1))
+        P["z_std"].append(ex_k["z_std"].reshape(-1))
+        P["moved"].append(((zs - zs0).abs() > 1e-3).sum(-1).to(torch.uint8))
+        P["agree"].append(((zs - zs0).abs() <= 6e-6).all(-1))
+        if verbose:
+            d = (rgb_k - rgb).abs().reshape(-1, 3).max(-1)[0]
+            print(f"  perturbation {k}: {time.time() - t0:.1f} s; rays agreeing within ulps {P['agree'][-1].float().mean():.3f}; with a "
+                  f"moved sample {(P['moved'][-1] > 0).float().mean():.3f}; rgb diff max {d.max():.2e} mean {d.mean():.2e}; "
+                  f"rays > 1e-4: {(d > 1e-4).float().mean():.3f}", flush=True)
+    out = {"pert_" + k: torch.stack(v, 0) for k, v in P.items()}
+    out["pert_eps"] = eps
+    return (rgb, disp, acc, ex, rec), out
 
 
 def g2_small():
@@ -284,7 +319,197 @@ def g6_schema():
     print(f"wrote schema.json: {os.path.getsize(p) / 1024:.1f} KiB")
 
 
+class PerturbCoarse:
+    """Perturb the COARSE compositing weights the way a second correct fp32 implementation would (relative noise of a
+    few ulp: ``w * (1 + U(-eps, eps))``) before the reference resamples from them, and record the new sample positions.
+    The reference's outputs under this perturbation are its OWN envelope: how far a pixel legitimately moves when the
+    importance resampling (run_nerf_helpers.py:203-247, the ``denom < 1e-5`` branch at :243) sees weights that differ
+    only by rounding."""
+
+    def __init__(self, seed, eps):
+        self.rng, self.eps, self.n, self.spdf = np.random.default_rng(seed), eps, 0, []
+        self._r2o, self._spdf = render_class.raw2outputs, render_class.sample_pdf
+
+    def __enter__(self):
+        def r2o(raw, z, d, *a, **k):
+            out = list(self._r2o(raw, z, d, *a, **k))
+            if self.n % 2 == 0:
+                w = out[3]
+                out[3] = w * torch.from_numpy(1.0 + self.rng.uniform(-self.eps, self.eps, tuple(w.shape))).float()
+            self.n += 1
+            return tuple(out)
+
+        def spdf(bins, w, n, **k):
+            out = self._spdf(bins, w, n, **k)
+            self.spdf.append(out.detach().clone())
+            return out
+
+        render_class.raw2outputs, render_class.sample_pdf = r2o, spdf
+        return self
+
+    def __exit__(self, *a):
+        render_class.raw2outputs, render_class.sample_pdf = self._r2o, self._spdf
+
+
+def g7_config1(n_pert=4, eps=1e-6):
+    """BASELINE config 1: the 64x64 ``--renderType rendering`` frame (run_fit.py:357-362 geometry scaled: focal 150,
+    centre 32), chunk 4096, SHIPPED network sizes (coarse 256x8, fine 1024x10) — 4,096 rays of the reference itself,
+    with the intermediates a teacher-forced test needs, plus the reference's outputs under ``n_pert`` seeded ulp-level
+    perturbations of its own coarse weights (the per-ray envelope)."""
+    H, seed = 64, 0
+    K = synth.intrinsics(H, H)
+    arch = (8, 256, 10, 1024)
+    r = mk_renderer(196608, seed)
+    coarse, fine = mk_nerf(arch[0], arch[1], seed, "coarse"), mk_nerf(arch[2], arch[3], seed, "fine")
+    kw = kwargs_for(r, coarse, fine)
+    bm, tex, exp = synth.codes(seed)
+    c2w = pose_spherical(0.0, 0.0, 16.0)[:3, :4]
+    call = lambda: r.render_fitting(H, H, K, chunk=4096, c2w=c2w, shapeCodes=bm, uvCodes=tex, expType=20, expCodes=exp,
+                                    retraw=True, **kw)
+    out = dict(c2w=c2w, K=K, bm=bm, tex=tex, exp=exp, H=H, chunk=4096, netchunk=196608, arch=np.array(arch), seed=seed,
+               perturb=0.0, noise=0.0, white=0)
+    (rgb, disp, acc, ex, rec), env = _envelope(call, n_pert, eps)
+    assert len(rec.spdf) == 1
+    sub = np.arange(0, H * H, 16)                                    # 256 rays keep the bulky per-sample arrays
+    out.update(rgb=rgb, disp=disp, acc=acc, rgb0=ex["rgb0"], disp0=ex["disp0"], acc0=ex["acc0"], z_std=ex["z_std"],
+               z_coarse_row=rec.r2o[0]["z"][:1], weights_coarse=rec.r2o[0]["weights"], z_samples=rec.spdf[0]["samples"],
+               sub=sub, raw_coarse_sub=rec.r2o[0]["raw"][sub], raw_fine_sub=rec.r2o[1]["raw"][sub],
+               weights_fine_sub=rec.r2o[1]["weights"][sub])
+    assert torch.equal(rec.r2o[0]["z"], rec.r2o[0]["z"][:1].expand(H * H, -1))
+    assert torch.equal(rec.r2o[1]["z"], torch.sort(torch.cat([rec.r2o[0]["z"], rec.spdf[0]["samples"]], -1), -1)[0])
+    out.update(env)
+    save("e2e_c1.npz", out)
+
+
+def g11_envelopes(n_pert=8, eps=1e-6):
+    """Per-ray envelopes (see _envelope) for the small end-to-end fixtures g2 / g3, in separate files so that the original
+    fixtures stay byte-identical."""
+    K16 = np.array([[37.5, 0, 8.0], [0, 37.5, 8.0], [0, 0, 1]])
+    K8 = np.array([[18.75, 0, 4.0], [0, 18.75, 4.0], [0, 0, 1]])
+    for name, args, kws in (("e2e_small", (16, K16, 0.0, 8, 64, 10, 128, 96, 4096), {}),
+                            ("e2e_small_stoch", (16, K16, -60.0, 8, 64, 10, 64, 256, 100000),
+                             dict(perturb=1.0, noise=0.5, white=True, pytest=True)),
+                            ("e2e_true", (8, K8, 60.0, 8, 256, 10, 1024, 64, 196608), {})):
+        call, _ = _case_setup(*args, **kws)
+        (rgb, disp, acc, ex, rec), env = _envelope(call, n_pert, eps, verbose=False)
+        base = np.load(os.path.join(HERE, name + ".npz"))
+        assert np.array_equal(base["rgb"], rgb.numpy()), name        # same run as the committed fixture
+        save(name + "_env.npz", env)
+
+
+def _sampled(t, key, n=256):
+    """``n`` entries of a gradient tensor at seeded positions (the 27.5 M fine-network weight gradients are not stored
+    whole) + its L2 norm."""
+    flat = t.detach().reshape(-1)
+    idx = np.random.default_rng(zlib_crc(key)).integers(0, flat.numel(), size=min(n, flat.numel()))
+    return flat[torch.from_numpy(idx)], flat.double().norm().float()
+
+
+def zlib_crc(key):
+    import zlib
+    return zlib.crc32(key.encode())
+
+
+def g8_true_grads():
+    """Forward + backward through the reference's ``run_network`` (render_class.py:69-94) at the SHIPPED sizes with
+    explicit sample positions: raw = run_network(o + d z, d/|d|, net); loss = sum(raw * G).  Gradients w.r.t. rays,
+    codes, every weight and bias of the network (sampled entries + norms) and the StyleModule.  This is what pins the
+    width-1024 backward kernels (K = 2048 skip layers included) and the 64-bit tape offsets are pinned by size tests."""
+    out = {}
+    for tag, (D, W), R, S in (("fine", (10, 1024), 40, 48), ("coarse", (8, 256), 64, 64)):
+        rng = np.random.default_rng(D * W)
+        r = mk_renderer(196608, 0)
+        net = mk_nerf(D, W, 0, tag).train()
+        bm, tex, exp = [t.clone().requires_grad_(True) for t in synth.codes(0)]
+        o = torch.from_numpy(rng.uniform(-2, 2, (R, 3)).astype(np.float32)).requires_grad_(True)
+        d = torch.from_numpy(rng.normal(0, 0.3, (R, 3)).astype(np.float32)).requires_grad_(True)
+        z = torch.from_numpy(np.sort(rng.uniform(8, 26, (R, S)).astype(np.float32), -1))
+        G = torch.from_numpy(rng.normal(size=(R, S, 4)).astype(np.float32))
+        r.shapeCodes, r.expType, r.decoding_texCodes = bm.expand(R, 50), 20, tex
+        r.expCodes_Sigma.append(exp)
+        pts = o[:, None, :] + d[:, None, :] * z[:, :, None]
+        vd = d / torch.norm(d, dim=-1, keepdim=True)
+        raw = r.run_network(pts, vd, net)
+        (raw * G).sum().backward()
+        out.update({f"{tag}_{k}": v for k, v in dict(o=o, d=d, z=z, G=G, bm=bm, tex=tex, exp=exp, raw=raw, g_o=o.grad,
+                                                      g_d=d.grad, g_bm=bm.grad, g_tex=tex.grad, g_exp=exp.grad,
+                                                      arch=np.array([D, W])).items()})
+        for key, p in list(net.named_parameters()) + [("style." + k, v) for k, v in r.idSpecificMod.named_parameters()]:
+            out[f"{tag}_gs/{key}"], out[f"{tag}_gn/{key}"] = _sampled(p.grad, f"{tag}/{key}")
+    save("grads_true.npz", out)
+
+
+def g9_run_network_kat():
+    """``run_network`` (render_class.py:69-94: Embedder, expression modulation, code expansion, batchify, NeRF.forward)
+    from EXPLICIT points / view directions / codes at small widths — the input form the fused HIP network takes."""
+    out = {}
+    rng = np.random.default_rng(9)
+    for D, W, netchunk in ((8, 64, 1000), (10, 64, 4096), (8, 96, 777), (10, 128, 100000)):
+        r = mk_renderer(netchunk, 0)
+        net = mk_nerf(D, W, 3, "kat")
+        R, S = 23, 37
+        pts = torch.from_numpy(rng.uniform(-9, 9, (R, S, 3)).astype(np.float32))
+        vd = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=(R, 3)).astype(np.float32)), dim=-1)
+        bm, tex, _ = synth.codes(D + W)
+        r.shapeCodes, r.expType, r.decoding_texCodes = bm.expand(R, 50), 5, tex
+        with torch.no_grad():
+            raw = r.run_network(pts, vd, net)
+        t = f"rn{D}x{W}"
+        out.update({t + "_pts": pts, t + "_vd": vd, t + "_bm": bm, t + "_tex": tex, t + "_raw": raw,
+                    t + "_meta": np.array([D, W, netchunk, 3, 5])})     # D, W, netchunk, weight seed, expType
+    save("kat_run_network.npz", out)
+
+
+def g10_checkpoint():
+    """A checkpoint WRITTEN BY THE REFERENCE'S OWN MODULES in run_train.py:369-379's format (small nets 8x64 + 10x64 so the
+    file stays small; the texture encoder, whose size is fixed at 3.3 M parameters, gets weights on a 5-level grid (17 for its small tensors) so the
+    archive compresses) and the reference's renders from it: ``render_fitting`` (codes given) and ``render`` (texture
+    encoder on a seeded UV map).  The GPU test reloads it through ``factory.create_nerf``'s reload path
+    (create_model_condition.py:72-89)."""
+    import gzip, io
+    r = mk_renderer(4096, 0, with_tex=True)
+    tex_sd = r.texEncoder.state_dict()
+    for k, v in tex_sd.items():
+        step = v.abs().max() / (2 if v.numel() > 10000 else 8)
+        v.copy_(torch.round(v / step) * step)
+    coarse, fine = mk_nerf(8, 64, 11, "ckc"), mk_nerf(10, 64, 11, "ckf")
+    grad_vars = list(coarse.parameters()) + list(fine.parameters()) + list(r.grad_parameter())
+    opt = torch.optim.Adam(params=grad_vars, lr=5e-5, betas=(0.9, 0.999))
+    blob = {'global_step': 100, 'network_fn_state_dict': coarse.state_dict(), 'network_fine_state_dict': fine.state_dict(),
+            'network_render_textureEncoder': r.texEncoder.state_dict(), 'network_render_idSpecific': r.idSpecificMod.state_dict(),
+            'optimizer_state_dict': opt.state_dict(), 'expression_latent_codes_sigma': r.expCodes_Sigma}
+    buf = io.BytesIO()
+    torch.save(blob, buf)
+    p = os.path.join(HERE, "ref_ckpt_000100.tar.gz")
+    with gzip.GzipFile(p, "wb", compresslevel=9, mtime=0) as f:
+        f.write(buf.getvalue())
+    print(f"wrote ref_ckpt_000100.tar.gz: {os.path.getsize(p) / 1024:.1f} KiB (raw {len(buf.getvalue()) / 1024:.1f} KiB)")
+    kw = kwargs_for(r, coarse, fine)
+    bm, tex, exp = synth.codes(4)
+    K8 = synth.intrinsics(8, 8)
+    c2w = pose_spherical(35.0, 0.0, 16.0)[:3, :4]
+    rng = np.random.default_rng(5)
+    uv = torch.from_numpy(rng.uniform(0, 1, (512, 512, 3)).astype(np.float32))
+    with torch.no_grad(), Recorder() as rec:
+        rgb, disp, acc, ex = r.render_fitting(8, 8, K8, chunk=64, c2w=c2w, shapeCodes=bm, uvCodes=tex, expType=20,
+                                              expCodes=exp, retraw=True, **kw)
+    out = dict(c2w=c2w, K=K8, bm=bm, tex=tex, exp=exp, H=8, chunk=64, netchunk=4096, arch=np.array([8, 64, 10, 64]),
+               rgb=rgb, disp=disp, acc=acc, rgb0=ex["rgb0"], disp0=ex["disp0"], acc0=ex["acc0"], z_std=ex["z_std"],
+               z_coarse=rec.r2o[0]["z"], weights_coarse=rec.r2o[0]["weights"], z_samples=rec.spdf[0]["samples"],
+               z_fine=rec.r2o[1]["z"], raw_coarse=rec.r2o[0]["raw"], raw_fine=rec.r2o[1]["raw"],
+               weights_fine=rec.r2o[1]["weights"])
+    ro, rd = get_rays(8, 8, K8, c2w)
+    rays = torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)], 0)
+    r.expCodes_Sigma = r.expCodes_Sigma[:20]
+    with torch.no_grad():
+        rgb, disp, acc, ex = r.render(8, 8, K8, chunk=64, rays=rays, shapeCodes=bm.expand(64, 50), uvMap=uv, expType=7,
+                                      retraw=True, **kw)
+    out.update(t_tex_code=r.decoding_texCodes, t_rgb=rgb, t_acc=acc, t_rgb0=ex["rgb0"], t_acc0=ex["acc0"], t_raw=ex["raw"])
+    save("ckpt_render.npz", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
-        {"g1": g1_kats, "g2": g2_small, "g3": g3_true, "g4": g4_grads, "g5": g5_render_tex, "g6": g6_schema}[w]()
+        {"g1": g1_kats, "g2": g2_small, "g3": g3_true, "g4": g4_grads, "g5": g5_render_tex, "g6": g6_schema, "g7": g7_config1, "g8": g8_true_grads, "g9": g9_run_network_kat,
+         "g10": g10_checkpoint, "g11": g11_envelopes}[w]()

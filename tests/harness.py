@@ -45,7 +45,7 @@ def to_np(d):
     return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in d.items()}
 
 
-def classify_samples(z_coarse, weights_coarse, u, zs_hip, zs_ref, ulp_tol=6e-6, w_err=0.0):
+def classify_samples(z_coarse, weights_coarse, u, zs_hip, zs_ref, ulp_tol=6e-6, w_err=0.0, bins=None, bin_weights=None):
     """Decide which resampled positions legitimately differ between two fp32 implementations.
 
     ``sample_pdf`` (tools/run_nerf_helpers.py:242-245) divides by ``denom = cdf[i+1]-cdf[i]`` and REPLACES it by 1
@@ -60,12 +60,15 @@ def classify_samples(z_coarse, weights_coarse, u, zs_hip, zs_ref, ulp_tol=6e-6, 
 
     Returns ``(agree [R,Ni] bool, explained [R,Ni] bool)`` from the REFERENCE's coarse weights: ``agree`` = within a
     few ulp of z; ``explained`` = the disagreement is within the conditioning bound or sits at the threshold."""
-    z, w = torch.as_tensor(z_coarse).float(), torch.as_tensor(weights_coarse).float()
     zh, zr = torch.as_tensor(zs_hip).float(), torch.as_tensor(zs_ref).float()
     R, Ni = zr.shape
     u = torch.as_tensor(u).float().expand(R, Ni).contiguous()
-    bins = .5 * (z[:, 1:] + z[:, :-1])
-    ww = w[:, 1:-1] + 1e-5
+    if bins is not None:       # plain sample_pdf(bins, weights) form (``z_coarse`` / ``weights_coarse`` unused)
+        bins, ww = torch.as_tensor(bins).float(), torch.as_tensor(bin_weights).float() + 1e-5
+    else:
+        z, w = torch.as_tensor(z_coarse).float(), torch.as_tensor(weights_coarse).float()
+        bins = .5 * (z[:, 1:] + z[:, :-1])
+        ww = w[:, 1:-1] + 1e-5
     pdf = ww / ww.sum(-1, keepdim=True)
     cdf = torch.cat([torch.zeros(R, 1), torch.cumsum(pdf, -1)], -1)
     B = cdf.shape[-1]
@@ -94,9 +97,29 @@ def classify_samples(z_coarse, weights_coarse, u, zs_hip, zs_ref, ulp_tol=6e-6, 
     return agree, expl
 
 
-def render_pair(H, K, angle, arch, chunk, netchunk, device="cuda", seed=0, n_rays=None):
+PERT_EPS = 1e-6     # relative size of the coarse-weight perturbation behind every envelope (HIP's own coarse weights differ
+                    # from the reference's by 5e-7..8e-7 absolute on weights <= 1: measured)
+
+
+def oracle_envelope(o, ro, rd, chunk, bm, base_z_samples, exp_type=20, n_pert=8, eps=PERT_EPS, **kw):
+    """The ORACLE's outputs under ``n_pert`` seeded relative perturbations of its own coarse weights (the same recipe
+    tests/golden/make_golden.py::_envelope applies to the reference for the committed ``*_env.npz`` fixtures).  ``kw``: what
+    ``OracleRenderer.render`` takes (tex_code / uv_map, exp_codes, N_samples, ...).  Returns the ``pert_*`` dict
+    :func:`compare_render` takes."""
+    R, S = ro.reshape(-1, 3).shape[0], kw.get("N_samples", 64)
+    out = {"pert_rgb": [], "pert_acc": [], "pert_agree": []}
+    for k in range(n_pert):
+        m = torch.from_numpy(1.0 + np.random.default_rng(1000 + k).uniform(-eps, eps, (R, S))).float()
+        with torch.no_grad():
+            rgb, _, acc, ex = o.render(ro, rd, chunk, bm, exp_type, 8.0, 26.0, keep=True, w0_perturb=m, **kw)
+        out["pert_rgb"].append(rgb.reshape(-1, 3).numpy()), out["pert_acc"].append(acc.reshape(-1).numpy())
+        out["pert_agree"].append(((ex["_dbg"]["z_samples"] - torch.as_tensor(base_z_samples)).abs() <= 6e-6).all(-1).numpy())
+    return {k: np.stack(v, 0) for k, v in out.items()}
+
+
+def render_pair(H, K, angle, arch, chunk, netchunk, device="cuda", seed=0, n_rays=None, n_pert=8):
     """Render an HxH view (or its first ``n_rays`` rays) with the HIP path and with the oracle on identical rays.
-    Returns two dicts of numpy arrays (rgb, disp, acc, rgb0, disp0, acc0, z_std)."""
+    Returns two dicts of numpy arrays (rgb, disp, acc, rgb0, disp0, acc0, z_std) and the oracle's envelope."""
     render, kw, _ = make_product(arch, seed, netchunk, device)
     bm, tex, exp = synth.codes(seed)
     c2w = orc.pose_spherical(angle, 0.0, 16.0)[:3, :4]
@@ -119,22 +142,59 @@ def render_pair(H, K, angle, arch, chunk, netchunk, device="cuda", seed=0, n_ray
     d = ex["_dbg"]
     ref = to_np(dict(rgb=rgb, disp=disp, acc=acc, rgb0=ex["rgb0"], disp0=ex["disp0"], acc0=ex["acc0"], z_std=ex["z_std"],
                      z_samples=d["z_samples"], z_coarse=d["z_coarse"], weights_coarse=d["weights_coarse"]))
-    return hip, ref
+    env = oracle_envelope(o, ro, rd, chunk, bm, ref["z_samples"], n_pert=n_pert, tex_code=tex, exp_codes=exp, N_samples=64,
+                          N_importance=64)
+    return hip, ref, env
 
 
-def compare_render(hip, ref, u=None, tol=1e-4, min_agree=0.15, verbose=True):
+def envelope_stats(err, env, tol=1e-4, what="rgb"):
+    """Is an implementation's per-ray error INSIDE the reference's own envelope?
+
+    ``err [R]``: max-abs difference to the reference per ray.  ``env [K,R]``: the reference's (or oracle's) own per-ray
+    change under K seeded ulp-level perturbations of its coarse weights (``*_env.npz`` / :func:`oracle_envelope`).  The
+    resampling is discontinuous (tools/run_nerf_helpers.py:243) and the positional encoding amplifies a 1-ulp move of a sample
+    by 2^9, so a small set of rays moves by up to 1e-2 in the REFERENCE ITSELF; which rays, and by how much, is what the
+    envelope records.  Asserted, with R rays (slack = 3 rays):
+      * frame level — fraction of rays over ``tol`` <= 2x the worst draw's; mean error <= 2x the worst draw's mean;
+        max error <= 1.5x the envelope's max;
+      * per ray — err[r] <= max(tol, 1.5 * max_k env[k, r]) for >= 97 % of the rays (a flip the K draws did not sample is an
+        outlier, and outliers are budgeted, not waved through: each must still be below 1.5x the envelope's max);
+      * rays that no draw moves by more than 1e-5 ("stable", the large majority) exceed ``tol`` in <= 2 % of the cases.
+    Returns the measured numbers."""
+    err, env = np.asarray(err, np.float64), np.asarray(env, np.float64)
+    R = err.shape[0]
+    slack = 3.0 / R
+    env_ray = env.max(0)
+    stable = env_ray <= 1e-5
+    inside = err <= np.maximum(tol, 1.5 * env_ray)
+    st = {"frac_over": float((err > tol).mean()), "ref_frac_over": float((env > tol).mean(1).max()),
+          "mean": float(err.mean()), "ref_mean": float(env.mean(1).max()), "max": float(err.max()),
+          "ref_max": float(env.max()), "inside": float(inside.mean()), "stable": float(stable.mean()),
+          "stable_over": float((err[stable] > tol).mean()) if stable.any() else 0.0}
+    msg = f"{what}: {st}"
+    assert st["frac_over"] <= 2 * st["ref_frac_over"] + slack, msg
+    assert st["mean"] <= 2 * st["ref_mean"] + 2e-6, msg
+    assert st["max"] <= 1.5 * st["ref_max"] + tol, msg
+    assert st["inside"] >= 0.97 - slack, msg
+    assert st["stable_over"] <= 0.02 + slack, msg
+    return st
+
+
+def compare_render(hip, ref, env, u=None, tol=1e-4, verbose=True):
     """Parity of a coarse+fine render (dicts of numpy arrays, rays flat).
 
     * coarse outputs (rgb0/acc0/disp0, coarse weights): every ray, ``tol``;
-    * resampled positions: every disagreement must be EXPLAINED (see :func:`classify_samples`);
-    * fine outputs (rgb/acc/disp/z_std), tiered by how the ray's 64 new sample positions compare:
+    * resampled positions: every disagreement must be EXPLAINED (see :func:`classify_samples`), and the fraction of rays
+      whose 64 new positions all agree within a few ulp must be at least half of what the reference shows against ITSELF under
+      ulp-level noise (``env["pert_agree"]``);
+    * fine outputs (rgb/acc/disp/z_std), by how the ray's 64 new sample positions compare:
         A  bit-identical positions ......... ``tol`` (1e-4; only MLP/composite rounding is left)
         B  all within a few ulp of z ....... 1e-3: the reference amplifies a 1-ulp position change by 2^9*|d| in the
-                                             positional encoding (SURVEY.md §7 hard part 2; measured on the oracle by
-                                             tests/test_oracle_sensitivity.py)
-        C  >= 1 explained jump ............. sanity bound only (the reference's own output is unstable there)
-      The strict fine-pass gate for ALL rays is the teacher-forced test (reference sample positions fed to the HIP
-      network + compositing), tests/test_gpu_render.py::test_fine_pass_teacher_forced_*.
+                                             positional encoding (measured on the oracle by tests/test_oracle_sensitivity.py)
+      and for ALL rays together: inside the reference's own envelope, :func:`envelope_stats` (rgb and acc);
+      the strict fine-pass gate for ALL rays is the teacher-forced test (reference sample positions fed to the HIP
+      network + compositing), tests/test_gpu_render.py::test_fine_pass_teacher_forced_*, tests/test_gpu_config1.py.
+    ``env``: dict with ``pert_rgb [K,R,3]``, ``pert_acc [K,R]``, ``pert_agree [K,R]`` (fixture or :func:`oracle_envelope`).
     Returns a dict of measured errors."""
     from conftest import nan_equal_close
     flat = lambda a, n: np.asarray(a).reshape(-1, *np.asarray(a).shape[-n:]) if n else np.asarray(a).reshape(-1)
@@ -147,23 +207,32 @@ def compare_render(hip, ref, u=None, tol=1e-4, min_agree=0.15, verbose=True):
     zh, zr = flat(hip["z_samples"], 1), flat(ref["z_samples"], 1)
     if u is None:
         u = torch.linspace(0., 1., zr.shape[-1])
-    agree, expl = classify_samples(flat(ref["z_coarse"], 1), flat(ref["weights_coarse"], 1), u, zh, zr,
-                                   w_err=out.get("weights0", 0.0))
+    zc = flat(ref["z_coarse"], 1) if "z_coarse" in ref else np.broadcast_to(flat(ref["z_coarse_row"], 1), (zr.shape[0], flat(ref["z_coarse_row"], 1).shape[-1]))
+    agree, expl = classify_samples(zc, flat(ref["weights_coarse"], 1), u, zh, zr, w_err=out.get("weights0", 0.0))
     bad = ~(agree | expl)
     assert not bad.any(), f"{int(bad.sum())} resampled positions differ without being ill-conditioned/at the threshold"
     tier_a = (zh == zr).all(-1)
     tier_b = agree.all(-1).numpy() & ~tier_a
-    tier_c = ~(tier_a | tier_b)
-    out["frac_A_B_C"] = [round(float(t.mean()), 3) for t in (tier_a, tier_b, tier_c)]
-    assert (tier_a | tier_b).mean() >= min_agree, out
-    for name, mask, t in (("A", tier_a, tol), ("B", tier_b, 1e-3), ("C", tier_c, 0.2)):
+    out["frac_A_B_rest"] = [round(float(t.mean()), 3) for t in (tier_a, tier_b, ~(tier_a | tier_b))]
+    out["ref_self_agree"] = round(float(np.asarray(env["pert_agree"]).mean(1).min()), 3)
+    assert (tier_a | tier_b).mean() >= 0.5 * out["ref_self_agree"] - 3.0 / zr.shape[0], out
+    for name, mask, t in (("A", tier_a, tol), ("B", tier_b, 1e-3)):
         if not mask.any():
             continue
         out["rgb_" + name] = nan_equal_close(flat(hip["rgb"], 1)[mask], flat(ref["rgb"], 1)[mask], t)
         out["acc_" + name] = nan_equal_close(flat(hip["acc"], 0)[mask], flat(ref["acc"], 0)[mask], t)
-        if name != "C":
-            nan_equal_close(flat(hip["disp"], 0)[mask], flat(ref["disp"], 0)[mask], 10 * t * 1e-2, 10 * t)
-            out["z_std_" + name] = nan_equal_close(flat(hip["z_std"], 0)[mask], flat(ref["z_std"], 0)[mask], 1e-5)
+        nan_equal_close(flat(hip["disp"], 0)[mask], flat(ref["disp"], 0)[mask], 10 * t * 1e-2, 10 * t)
+        out["z_std_" + name] = nan_equal_close(flat(hip["z_std"], 0)[mask], flat(ref["z_std"], 0)[mask], 1e-5)
+    rgb_r, acc_r = flat(ref["rgb"], 1), flat(ref["acc"], 0)
+    out["env_rgb"] = envelope_stats(np.abs(flat(hip["rgb"], 1) - rgb_r).max(-1),
+                                    np.abs(np.asarray(env["pert_rgb"]) - rgb_r[None]).max(-1), tol, "rgb")
+    out["env_acc"] = envelope_stats(np.abs(flat(hip["acc"], 0) - acc_r), np.abs(np.asarray(env["pert_acc"]) - acc_r[None]), tol, "acc")
+    mse = float(((flat(hip["rgb"], 1).astype(np.float64) - rgb_r) ** 2).mean())
+    out["psnr_db"] = round(-10 * np.log10(max(mse, 1e-30)), 1)
+    ref_mse = float(((np.asarray(env["pert_rgb"], np.float64) - rgb_r[None]) ** 2).mean((1, 2)).max())
+    out["ref_psnr_db"] = round(-10 * np.log10(max(ref_mse, 1e-30)), 1)
+    assert out["psnr_db"] >= out["ref_psnr_db"] - 3.0 and out["psnr_db"] >= 60.0, out      # frame level: >= 60 dB and within 3 dB of the reference vs itself
     if verbose:
-        print({k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in out.items()})
+        fmt = lambda v: f"{v:.2e}" if isinstance(v, float) else ({k: (f"{x:.2e}" if isinstance(x, float) else x) for k, x in v.items()} if isinstance(v, dict) else v)
+        print({k: fmt(v) for k, v in out.items()})
     return out

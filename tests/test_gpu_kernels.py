@@ -93,9 +93,9 @@ def _layer(x1, w, b, x2=None, relu=True, bias_rows=None, div=0):
 
 @pytest.mark.parametrize("stage", ["glds", "reg"])
 @pytest.mark.parametrize("M,K,N", [(256, 64, 64), (700, 128, 128), (1024, 256, 256), (513, 96, 192), (2048, 1024, 128)])
-def test_layer_forward(M, K, N, stage, monkeypatch):
+def test_layer_forward(M, K, N, stage, knob):
     """One Linear+bias+ReLU.  Weights are ASYMMETRIC random (catches transposed operands / C layout)."""
-    monkeypatch.setenv("MOFA_STAGE", stage)
+    knob("MOFA_STAGE", stage)
     rng = np.random.default_rng(M + K + N)
     x = dev(rng.normal(size=(M, K)).astype(np.float32))
     w = dev((rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32))
@@ -128,6 +128,29 @@ def test_layer_forward_skip_concat_and_per_ray_bias():
     rows = dev(rng.normal(size=(M // S, N)).astype(np.float32))
     ref = torch.relu(x1.double() @ w[:, :K1].double().T + rows.double().repeat_interleave(S, 0)).float().cpu().numpy()
     nan_equal_close(_layer(x1, w[:, :K1].contiguous(), None, bias_rows=rows, div=S).cpu().numpy(), ref, 5e-6)
+
+
+@pytest.mark.parametrize("dephase", ["0", "1"])
+def test_persistent_layer_kernel_is_bit_identical(knob, dephase):
+    """MOFA_PERSIST=1 (k_layer_persist: 2 workgroups per CU walking the tiles, next tile's first panel requested before the
+    epilogue; MOFA_DEPHASE=1 adds group-wise start offsets) must reproduce k_layer bit for bit: plain layer with a ragged tile
+    count (more tiles than resident workgroups, not a multiple of 8), skip layer (two K sources) and per-ray bias."""
+    rng = np.random.default_rng(21)
+    M, K, N, S = 256 * 131, 256, 1024, 64          # 131 x 8 = 1048 tiles > 512 resident workgroups
+    x = dev(rng.normal(size=(M, K)).astype(np.float32))
+    x2 = dev(rng.normal(size=(M, 128)).astype(np.float32))
+    w = dev((rng.normal(size=(N, K + 128)) / 16).astype(np.float32))
+    b = dev(rng.normal(size=(N,)).astype(np.float32))
+    rows = dev(rng.normal(size=(M // S, 128)).astype(np.float32))
+    cases = [lambda: _layer(x, w[:, :K].contiguous(), b), lambda: _layer(x, w, b, x2=x2),
+             lambda: _layer(x, w[:128, :K].contiguous(), None, bias_rows=rows, div=S),
+             lambda: _layer(x[:700], w[:128, :K].contiguous(), b[:128])]
+    base = [c() for c in cases]
+    knob("MOFA_PERSIST", "1")
+    knob("MOFA_DEPHASE", dephase)
+    for c, ref in zip(cases, base):
+        for _ in range(2):
+            assert torch.equal(c(), ref)
 
 
 def test_layer0_positional_encoding_fused():
@@ -309,18 +332,57 @@ def test_sample_pdf_merge_vs_oracle():
 
 
 def test_sample_pdf_golden(golden):
-    g = golden("kat.npz")
-    bins, w = T(g["spdf_bins"]), T(g["spdf_w"])
-    # rebuild z whose midpoints are the fixture's bins is not possible in general; instead check the three anchor rows
-    # through the oracle-equivalent route: rows 0..2 are the edge cases (uniform pdf, single spike, leading empty bins)
-    z = torch.cat([bins[:, :1] * 2 - bins[:, 1:2], bins], -1)          # 64 edges; midpoints != bins, so use oracle
-    ww = torch.cat([torch.zeros(bins.shape[0], 1), w, torch.zeros(bins.shape[0], 1)], -1)
-    zs, zf, sd = _sample(dev(z), dev(ww), dev(torch.linspace(0., 1., 64)), 0)
-    ref = orc.sample_pdf(.5 * (z[:, 1:] + z[:, :-1]), w, torch.linspace(0., 1., 64))
+    """`sample_pdf(bins, weights, 64, det / pytest)` (run_nerf_helpers.py:203-247) through the bins-input entry point
+    `mofa_sample_pdf`, against the REFERENCE's own outputs `spdf_det` / `spdf_rand` (40 rays incl. all-zero weights, a single
+    spike and leading empty bins): identical inputs, and the kernel accumulates the cdf like torch's CPU cumsum, so almost
+    every sample must be within an ulp or two and the few that are not must sit on the reference's 1e-5 threshold."""
     from harness import classify_samples
-    agree, expl = classify_samples(z, ww, torch.linspace(0., 1., 64), zs, ref)
-    assert (agree | expl).all()
-    nan_equal_close(zs[0].numpy(), ref[0].numpy(), 1e-5)               # all-zero weights -> uniform pdf
+    g = golden("kat.npz")
+    bins, w = dev(g["spdf_bins"]), dev(g["spdf_w"])
+    R, B = bins.shape
+    np.random.seed(0)
+    u_rand = torch.Tensor(np.random.rand(R, 64))
+    for u, us, key in ((torch.linspace(0., 1., 64), 0, "spdf_det"), (u_rand, 64, "spdf_rand")):
+        out = torch.empty(R, 64, device=DEV)
+        lib.check(L().mofa_sample_pdf(lib.ptr(bins), B, lib.ptr(w), lib.ptr(dev(u)), us, R, B, 64, lib.ptr(out), lib.stream()),
+                  "mofa_sample_pdf")
+        got, ref = out.cpu(), T(g[key])
+        agree, expl = classify_samples(None, None, u, got, ref, bins=g["spdf_bins"], bin_weights=g["spdf_w"])
+        assert (agree | expl).all(), (key, int((~(agree | expl)).sum()))
+        frac_ulp = float(((got - ref).abs() <= 2e-6).float().mean())
+        print(key, "within 2e-6:", round(frac_ulp, 4), "bit-identical:", round(float((got == ref).float().mean()), 4))
+        assert frac_ulp > 0.97, (key, frac_ulp)
+        assert torch.equal(got[0], ref[0])                               # all-zero weights: uniform pdf, exact
+    anchor = torch.empty(1, 8, device=DEV)
+    lib.check(L().mofa_sample_pdf(lib.ptr(dev(torch.linspace(8, 26, 7)[None])), 7, lib.ptr(dev(torch.tensor([[0, .1, .6, .2, .05, 0]]))),
+                                  lib.ptr(dev(torch.linspace(0., 1., 8))), 0, 1, 7, 8, lib.ptr(anchor), lib.stream()), "mofa_sample_pdf")
+    nan_equal_close(anchor.cpu().numpy(), g["spdf_anchor"], 2e-6)        # SURVEY.md section 8c sanity anchor
+
+
+@pytest.mark.parametrize("D,W", [(8, 64), (10, 64), (8, 96), (10, 128)])
+def test_run_network_kat_golden(golden, D, W):
+    """`run_network(inputs, viewdirs, fn)` (render_class.py:69-94) on the REFERENCE's KAT: explicit points / view directions /
+    codes in, raw [R,S,4] out — Embedder, expression modulation, code expansion, netchunk batching and NeRF.forward in one
+    comparison against the reference's own output (fixture g9)."""
+    from mofanerf_amd.model import NeRF
+    from mofanerf_amd.renderer import Renderer
+    g = golden("kat_run_network.npz")
+    t = f"rn{D}x{W}"
+    _, _, netchunk, wseed, exp_type = [int(v) for v in g[t + "_meta"]]
+    render = Renderer(netchunk=netchunk, expCodesLen=30)
+    render.idSpecificMod.load_state_dict(synth.style_state(0))
+    for dst, src in zip(render.expCodes_Sigma, synth.exp_sigma(0)):
+        dst.data[:] = src
+    render = render.to(DEV).eval()
+    net = NeRF(D=D, W=W, input_ch=93, input_ch_views=27, input_ch_textureCodes=256, input_ch_shapeCodes=50, use_viewdirs=True)
+    net.load_state_dict(synth.nerf_state(D, W, wseed, "kat"))
+    net = net.to(DEV)
+    render.shapeCodes, render.expType, render.decoding_texCodes = dev(g[t + "_bm"]), exp_type, dev(g[t + "_tex"])
+    with torch.no_grad():
+        raw = render.run_network(dev(g[t + "_pts"]), dev(g[t + "_vd"]), net)
+    torch.cuda.synchronize()
+    err = nan_equal_close(raw.cpu().numpy(), g[t + "_raw"], 2e-5, 1e-5)
+    print(t, f"max abs err vs reference {err:.2e}")
 
 
 def test_layer_pipeline_race_screen_full_size():
@@ -365,7 +427,7 @@ def test_layer_pipeline_race_screen_full_size():
 
 
 @pytest.mark.parametrize("D,W,R,S", [(8, 256, 40, 64), (10, 96, 9, 128), (8, 64, 130, 64), (8, 192, 17, 32)])
-def test_persistent_fused_network_is_bit_identical_to_per_layer_launches(D, W, R, S, monkeypatch):
+def test_persistent_fused_network_is_bit_identical_to_per_layer_launches(D, W, R, S, knob):
     """Widths <= 256 run the whole MLP as ONE persistent launch (k_mlp_fused); it must reproduce the per-layer path
     bit for bit, in inference mode (recycled buffers) and in tape mode (every layer output kept)."""
     from mofanerf_amd.autograd import NetFn, fold_torch, view_bias_torch
@@ -384,7 +446,7 @@ def test_persistent_fused_network_is_bit_identical_to_per_layer_launches(D, W, R
     folded = h.fold(e.to(DEV), bm.to(DEV), tex.to(DEV)).clone()
     outs, tapes = {}, {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("MOFA_FUSED", mode)
+        knob("MOFA_FUSED", mode)
         raw = torch.full((R, S, 4), float("nan"), device=DEV)
         h.forward_rays(o, d, z, S, vd, S, raw, folded)
         outs[mode] = raw.clone()
@@ -438,7 +500,7 @@ def test_opt_in_split_product_layer(M, K, N, k2, pieces, tol, version):
     print(f"v{version} pieces={pieces} M={M} K={K + k2} N={N}: max abs err {err:.2e}")
 
 
-def test_opt_in_split_product_network(monkeypatch):
+def test_opt_in_split_product_network(monkeypatch, knob):
     """Whole fine-size-like network (10 x 128) under MOFA_GEMM=bf16x6 / bf16x3 vs the default exact-fp32 path."""
     from mofanerf_amd.hipnet import HipNet
     from mofanerf_amd.model import NeRF
@@ -454,7 +516,7 @@ def test_opt_in_split_product_network(monkeypatch):
     vd = torch.nn.functional.normalize(d, dim=-1).contiguous()
     bm, tex, e = synth.codes(3)
     folded = h.fold(e.to(DEV), bm.to(DEV), tex.to(DEV)).clone()
-    monkeypatch.setenv("MOFA_FUSED", "0")
+    knob("MOFA_FUSED", "0")
     outs = {}
     for mode in ("fp32", "bf16x6", "bf16x3", "fp16x3"):
         monkeypatch.setenv("MOFA_GEMM", mode)
@@ -469,7 +531,7 @@ def test_opt_in_split_product_network(monkeypatch):
     assert e6 < e3 and eh < e3
 
 
-def test_opt_in_fp16x3_piece_panels(monkeypatch):
+def test_opt_in_fp16x3_piece_panels(monkeypatch, knob):
     """fp16x3 can keep activations as PRE-SPLIT fp16 piece panels between layers whenever every layer width is a multiple
     of 128 (default from width 512 up; forced here for 8 x 256, view layer 128).  Splitting at every use instead (MOFA_SPLIT_HH=0) feeds the matrix pipe the very same
     pieces, so only the two heads - which then read h1 + h2 instead of the fp32 value, 2^-23 relative - may differ."""
@@ -490,7 +552,7 @@ def test_opt_in_fp16x3_piece_panels(monkeypatch):
     outs = {}
     for name, gemm, hh in (("fp32", "fp32", "1"), ("panels", "fp16x3", "1"), ("at_use", "fp16x3", "0")):
         monkeypatch.setenv("MOFA_GEMM", gemm)
-        monkeypatch.setenv("MOFA_SPLIT_HH", hh)
+        knob("MOFA_SPLIT_HH", hh)
         raw = torch.full((R, S, 4), float("nan"), device=DEV)
         h.forward_rays(o, d, z, S, vd, S, raw, folded)
         torch.cuda.synchronize()

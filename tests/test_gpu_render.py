@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import nan_equal_close
-from harness import compare_render, make_oracle, make_product, render_pair, to_np
+from harness import compare_render, make_oracle, make_product, oracle_envelope, render_pair, to_np
 from mofanerf_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -30,14 +30,14 @@ def _fit(g, **over):
     return out
 
 
-def _check(g, out, u=None, tol=1e-4):
+def _check(g, out, env, u=None, tol=1e-4):
     rgb, disp, acc, ex = out
     H = int(g["H"])
     assert rgb.shape == (H, H, 3) and disp.shape == (H, H) and ex["rgb0"].shape == (H, H, 3)
     assert ex["losses"] == 0
     hip = to_np(dict(rgb=rgb, disp=disp, acc=acc, rgb0=ex["rgb0"], disp0=ex["disp0"], acc0=ex["acc0"], z_std=ex["z_std"],
                      z_samples=ex["_z_samples"], z_fine=ex["_z_fine"], weights_coarse=ex["_weights0"]))
-    errs = compare_render(hip, g, u=u, tol=tol)
+    errs = compare_render(hip, g, env, u=u, tol=tol)
     zf = hip["z_fine"].reshape(H * H, -1)
     assert (np.diff(zf, axis=-1) >= 0).all()                   # merged sample positions are sorted
     return errs
@@ -46,13 +46,13 @@ def _check(g, out, u=None, tol=1e-4):
 def test_render_fitting_small_golden(golden):
     """256 rays, coarse 8x64 + fine 10x128, chunk 96 (3 ragged chunks), rays generated on the device."""
     g = golden("e2e_small.npz")
-    _check(g, _fit(g))
+    _check(g, _fit(g), golden("e2e_small_env.npz"))
 
 
 def test_render_fitting_true_size_golden(golden):
     """64 rays through the SHIPPED network sizes (coarse 256x8, fine 1024x10)."""
     g = golden("e2e_true.npz")
-    _check(g, _fit(g))
+    _check(g, _fit(g), golden("e2e_true_env.npz"))
 
 
 def test_render_fitting_stochastic_golden(golden):
@@ -60,7 +60,8 @@ def test_render_fitting_stochastic_golden(golden):
     g = golden("e2e_small_stoch.npz")
     np.random.seed(0)
     u = torch.Tensor(np.random.rand(int(g["H"]) ** 2, 64))
-    _check(g, _fit(g, perturb=1.0, raw_noise_std=float(g["noise"]), white_bkgd=True, pytest=True), u=u)
+    _check(g, _fit(g, perturb=1.0, raw_noise_std=float(g["noise"]), white_bkgd=True, pytest=True),
+           golden("e2e_small_stoch_env.npz"), u=u)
 
 
 def test_render_with_texture_encoder_golden(golden):
@@ -84,7 +85,9 @@ def test_render_with_texture_encoder_golden(golden):
                      z_std=r_ex["z_std"], z_samples=d["z_samples"], z_coarse=d["z_coarse"], weights_coarse=d["weights_coarse"]))
     hip = to_np(dict(rgb=rgb, disp=disp, acc=acc, rgb0=ex["rgb0"], disp0=ex["disp0"], acc0=ex["acc0"], z_std=ex["z_std"],
                      z_samples=ex["_z_samples"], weights_coarse=ex["_weights0"]))
-    compare_render(hip, ref)
+    env = oracle_envelope(o, rays[0], rays[1], 64, T(g["bm"]), ref["z_samples"], exp_type=7, uv_map=uv_cpu, N_samples=64,
+                          N_importance=64)
+    compare_render(hip, ref, env)
 
 
 def _teacher_forced(g, tol=1e-4):
@@ -219,8 +222,8 @@ def test_chunk_and_netchunk_invariance_shipped_sizes():
 
 def test_device_pair_vs_oracle_medium():
     """1024 rays (32x32 view), coarse 8x128 + fine 10x256: HIP vs oracle on identical rays."""
-    hip, ref = render_pair(32, synth.intrinsics(32, 32), 60.0, (8, 128, 10, 256), chunk=400, netchunk=20000, device=DEV)
-    compare_render(hip, ref)
+    hip, ref, env = render_pair(32, synth.intrinsics(32, 32), 60.0, (8, 128, 10, 256), chunk=400, netchunk=20000, device=DEV)
+    compare_render(hip, ref, env)
 
 
 def test_cpu_tensors_fail_loudly():

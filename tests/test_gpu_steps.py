@@ -93,29 +93,82 @@ def test_data_parallel_training_two_ranks_stay_identical():
     assert j["loss_rank0"][-1] != j["loss_rank0"][0] and all(np.isfinite(j["loss_rank0"]))
 
 
-def test_bench_two_rank_flow_emits_one_contract_json_line():
-    """bench.py under torch.distributed.run with 2 ranks (gloo on this GPU; the driver's 2/4/8-GPU runs use RCCL): row-block
-    sharding, all-gather of the tiles inside the timed region, max-over-ranks timing, ONE JSON line from rank 0."""
+def _run_json(cmd, env, timeout=900):
     import json
-    import os
-    import socket
     import subprocess
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+_CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data", "config", "roofline")
+
+
+def test_bench_self_spawns_two_ranks_and_emits_one_contract_json_line():
+    """`python bench.py --gpus 2` ALONE (no torchrun around it — the form the driver uses): bench.py re-executes itself under
+    torch.distributed.run with one process per rank (both on this GPU here, gloo; RCCL when there are two GPUs — next test):
+    row-block sharding, all-gather of the tiles straight into the frame inside the timed region, max-over-ranks timing, ONE JSON
+    line from rank 0 with the per-rank / collective fields."""
+    import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--size", "64",
-           "--arch", "8", "64", "10", "64"]
-    out = subprocess.run(cmd, env=dict(os.environ, MOFA_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    j = json.loads(lines[0])
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline"):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MOFA_DIST_BACKEND"] = "gloo"
+    j = _run_json([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--size", "64",
+                   "--arch", "8", "64", "10", "64"], env)
+    for k in _CONTRACT:
         assert k in j, k
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["unit"] == "rays/s" and "cpu_baseline" not in j
-    assert j["config"]["rays_per_step"] == 64 * 64 and j["dtype"] == "f32"
+    assert j["config"]["rays_per_step"] == 64 * 64 and j["config"]["rays_per_rank_per_step"] == 64 * 32 and j["dtype"] == "f32"
+    assert j["rccl_ranks"] == 2 and j["backend"] == "gloo" and j["collective"]["avg_ms_per_step_rank0"] >= 0 and j["scaling"] == "strong"
+
+
+@pytest.mark.parametrize("mode", ["fit", "train"])
+def test_bench_fit_and_train_modes_emit_contract_lines(mode):
+    """`bench.py --mode fit|train` (BASELINE configs 3 / 5) at a functional size: forward + backward lines with a roofline object
+    for the dominant MFMA kernel of the mode."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    j = _run_json([sys.executable, os.path.join(root, "bench.py"), "--mode", mode, "--steps", "2", "--warmup", "1", "--size", "64",
+                   "--rays", "512", "--arch", "8", "128", "10", "128", "--cpu-rays", "0"], env)
+    for k in _CONTRACT:
+        assert k in j, k
+    assert j["config"]["mode"] == mode and j["scaling"] == "weak" and j["value"] > 0 and j["config"]["rays_per_step"] == 512
+    assert j["roofline"]["bound"] == "mfma" and j["roofline"]["achieved"] > 0 and j["roofline"]["launches"] > 0
+    kinds = [j["roofline"]["kernel"]] + [o["kernel"] for o in j["roofline"]["other_mfma_kernels"]]
+    assert any("BWD" in k for k in kinds) and (mode == "fit" or any("k_wgrad" in k for k in kinds))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the real RCCL (backend nccl) path over xGMI")
+def test_two_rank_rccl_flows_on_two_gpus(tmp_path):
+    """With >= 2 GPUs visible: the SAME three multi-process entry points on backend nccl (= RCCL) — bench.py self-spawned
+    (all-gather of tiles), tools/train_dp.py (flat-bucket all-reduce + cross-rank parameter digest gathered on the GPU) and
+    tools/bulk_render.py (identity shards + GPU all-reduce of the counts)."""
+    import os
+    import socket
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MOFA_DIST_BACKEND")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    j = _run_json([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--size", "128",
+                   "--arch", "8", "64", "10", "64"], env)
+    assert j["n_gpus"] == 2 and j["backend"] == "nccl" and j["value"] > 0
+
+    def torchrun(script, *args):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), os.path.join(root, "tools", script), *args]
+
+    j = _run_json(torchrun("train_dp.py", "--steps", "3", "--rays", "128", "--size", "32", "--arch", "8", "64", "10", "64"), env)
+    assert j["world"] == 2 and j["parameters_identical_across_ranks"] is True
+    j = _run_json(torchrun("bulk_render.py", "--out", str(tmp_path / "rf"), "--identities", "2", "--expressions", "1", "--views", "1",
+                           "--size", "32", "--arch", "8", "64", "10", "64"), env)
+    assert j["world"] == 2 and j["images_rendered_total"] == 2
 
 
 def test_backward_is_deterministic():

@@ -167,3 +167,46 @@ def test_png_sink_matches_to8b(tmp_path):
         sink.close()
     with pytest.raises(ValueError):
         write_png(str(tmp_path / "bad.png"), np.zeros((4, 4), np.uint8))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="build container only: loads the file into the reference's own modules")
+def test_checkpoint_written_here_loads_into_the_reference_modules(tmp_path):
+    """(f4) `save_checkpoint` output is consumed by the REFERENCE's modules with strict `load_state_dict` and its own
+    reload loop (create_model_condition.py:72-89) — run in a subprocess because importing the reference needs process-wide
+    shims (stub imageio / cv2, Tensor.cuda = identity)."""
+    import subprocess
+    import sys
+    a = factory.default_args(device="cpu", netwidth=64, netwidth_fine=64, basedir=str(tmp_path), expname="rt", no_reload=True)
+    kw, _, _, grad_vars, opt, _, render = factory.create_nerf(a)
+    kw["network_fn"].load_state_dict(synth.nerf_state(8, 64, 5, "coarse"))
+    kw["network_fine"].load_state_dict(synth.nerf_state(10, 64, 5, "fine"))
+    path = factory.save_checkpoint(str(tmp_path / "rt" / "000042.tar"), 42, kw, render, opt)
+    code = f"""
+import sys, types, torch
+sys.path.insert(0, '/root/reference')
+for m in ('imageio', 'cv2'):
+    sys.modules[m] = types.ModuleType(m)
+torch.Tensor.cuda = lambda self, *a, **k: self
+from models import render_class
+from models.model import NeRF, get_embedder
+ck = torch.load({path!r}, map_location='cpu', weights_only=False)
+mk = lambda D, W: NeRF(D=D, W=W, input_ch_shapeCodes=50, input_ch_textureCodes=256, input_ch=93, output_ch=5, skips=[4],
+                       input_ch_views=27, use_viewdirs=True)
+coarse, fine = mk(8, 64), mk(10, 64)
+r = render_class.myRenderer(embed_fn=get_embedder(10, 0)[0], embeddirs_fn=get_embedder(4, 0)[0], netchunk=4096, uvCodesLen=256,
+                            expCodesLen=30)
+opt = torch.optim.Adam(params=list(coarse.parameters()) + list(fine.parameters()) + list(r.grad_parameter()), lr=5e-5)
+opt.load_state_dict(ck['optimizer_state_dict'])
+coarse.load_state_dict(ck['network_fn_state_dict'])
+fine.load_state_dict(ck['network_fine_state_dict'])
+r.texEncoder.load_state_dict(ck['network_render_textureEncoder'])
+r.idSpecificMod.load_state_dict(ck['network_render_idSpecific'])
+for latent, saved in zip(r.expCodes_Sigma, ck['expression_latent_codes_sigma']):
+    latent.data[:] = saved[:].detach().clone()
+assert ck['global_step'] == 42
+print('REFERENCE_LOADED', float(fine.rgb_linear.weight.sum()))
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "REFERENCE_LOADED" in out.stdout, out.stderr[-1500:]
+    got = float(out.stdout.split("REFERENCE_LOADED")[1].split()[0])
+    assert abs(got - float(kw["network_fine"].rgb_linear.weight.detach().sum())) < 1e-5

@@ -4,6 +4,8 @@ The reference has no tests of its own; tests/golden/make_golden.
 in the build container and these tests replay its inputs through the oracle.  Same torch CPU ops in
 the same order => tolerances are at the fp32 rounding floor (mostly bit-exact).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -134,3 +136,104 @@ def test_render_with_tex_encoder(golden):
     nan_equal_close(rgb.numpy(), g["rgb"], 2e-6)
     nan_equal_close(acc.numpy(), g["acc"], 2e-6)
     nan_equal_close(disp.numpy(), g["disp"], 2e-6, 2e-6)
+
+
+# ---- round 2 fixtures ------------------------------------------------------------------------------------------------------
+def test_run_network_kat(golden):
+    """run_network (render_class.py:69-94) from explicit points / view directions / codes — the reference's outputs."""
+    g = golden("kat_run_network.npz")
+    for D, W in ((8, 64), (10, 64), (8, 96), (10, 128)):
+        t = f"rn{D}x{W}"
+        _, _, netchunk, wseed, exp_type = [int(v) for v in g[t + "_meta"]]
+        r = orc.OracleRenderer(synth.nerf_state(D, W, wseed, "kat"), None, synth.style_state(0), synth.exp_sigma(0),
+                               netchunk=netchunk)
+        with torch.no_grad():
+            raw = r.run_network(T(g[t + "_pts"]), T(g[t + "_vd"]), r.coarse, T(g[t + "_bm"]), T(g[t + "_tex"]), exp_type)
+        nan_equal_close(raw.numpy(), g[t + "_raw"], 2e-6, 2e-6)
+
+
+def _sampled_idx(key, numel, n=256):
+    import zlib
+    return np.random.default_rng(zlib.crc32(key.encode())).integers(0, numel, size=min(n, numel))
+
+
+def test_true_size_gradients(golden):
+    """Backward through run_network at the SHIPPED widths (fixture g8): the oracle's fp32 autograd reproduces the reference's
+    gradients w.r.t. rays, codes and (sampled entries + norms of) every weight and bias."""
+    g = golden("grads_true.npz")
+    for tag in ("coarse", "fine"):
+        D, W = [int(v) for v in g[f"{tag}_arch"]]
+        st = {k: v.clone().requires_grad_(True) for k, v in synth.nerf_state(D, W, 0, tag).items()}
+        style = {k: v.clone().requires_grad_(True) for k, v in synth.style_state(0).items()}
+        bm, tex, exp = [T(g[f"{tag}_{k}"]).clone().requires_grad_(True) for k in ("bm", "tex", "exp")]
+        o, d = [T(g[f"{tag}_{k}"]).clone().requires_grad_(True) for k in ("o", "d")]
+        z, G = T(g[f"{tag}_z"]), T(g[f"{tag}_G"])
+        r = orc.OracleRenderer(st, None, style, synth.exp_sigma(0) + [exp], netchunk=196608)
+        pts = o[:, None, :] + d[:, None, :] * z[:, :, None]
+        vd = d / torch.norm(d, dim=-1, keepdim=True)
+        raw = r.run_network(pts, vd, st, bm.expand(o.shape[0], 50), tex, 20)
+        nan_equal_close(raw.detach().numpy(), g[f"{tag}_raw"], 5e-6, 5e-6)
+        (raw * G).sum().backward()
+        rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - b).max() / (np.abs(b).max() + 1e-30))
+        for name, t in (("g_o", o), ("g_d", d), ("g_bm", bm), ("g_tex", tex), ("g_exp", exp)):
+            assert rel(t.grad.numpy(), g[f"{tag}_{name}"]) < 2e-5, (tag, name)
+        for key, p in list(st.items()) + [("style." + k, v) for k, v in style.items()]:
+            ref_s, ref_n = g[f"{tag}_gs/{key}"], float(g[f"{tag}_gn/{key}"])
+            got = p.grad.reshape(-1)[_sampled_idx(f"{tag}/{key}", p.numel())].numpy()
+            assert np.abs(got - ref_s).max() <= 2e-5 * (np.abs(ref_s).max() + 1e-30) + 1e-6 * ref_n / np.sqrt(p.numel()) + 1e-12, (tag, key)
+            assert abs(float(p.grad.double().norm()) - ref_n) <= 1e-5 * ref_n + 1e-12, (tag, key)
+
+
+def test_config1_fixture_teacher_forced_subset(golden):
+    """BASELINE config 1 (64x64, chunk 4096, shipped sizes): the oracle's FINE pass on the fixture's own sample positions
+    reproduces the reference's raw / weights on the 256 rays the fixture keeps per-sample arrays for, and the fixture is
+    self-consistent (its z_fine is the sort of z_coarse and z_samples; its envelope entries are non-trivial)."""
+    g = golden("e2e_c1.npz")
+    sub = g["sub"]
+    H = int(g["H"])
+    r = _oracle_for(g)
+    r.exp_sigma.append(T(g["exp"]))
+    ro, rd = orc.get_rays(H, H, g["K"], T(g["c2w"]))
+    ro, rd = ro.reshape(-1, 3)[sub], rd.reshape(-1, 3)[sub]
+    vd = rd / torch.norm(rd, dim=-1, keepdim=True)
+    zc = T(g["z_coarse_row"]).expand(len(sub), -1)
+    zf = torch.sort(torch.cat([zc, T(g["z_samples"])[sub]], -1), -1)[0]
+    with torch.no_grad():
+        raw = r.run_network(ro[:, None, :] + rd[:, None, :] * zf[:, :, None], vd, r.fine, T(g["bm"]), T(g["tex"]), 20)
+        rgb, disp, acc, w, _ = orc.raw2outputs(raw, zf, rd)
+    nan_equal_close(raw.numpy(), g["raw_fine_sub"], 2e-5, 2e-5)
+    nan_equal_close(w.numpy(), g["weights_fine_sub"], 2e-6)
+    nan_equal_close(rgb.numpy(), g["rgb"].reshape(-1, 3)[sub], 2e-6)
+    nan_equal_close(acc.numpy(), g["acc"].reshape(-1)[sub], 2e-6)
+    env = np.abs(g["pert_rgb"] - g["rgb"].reshape(1, -1, 3)).max(-1)           # [n_pert, 4096]
+    assert env.shape[1] == H * H and (env.max(0) > 1e-4).mean() > 0.005       # the reference itself moves under ulp noise
+
+
+def test_reference_checkpoint_renders(golden, tmp_path):
+    """The checkpoint written by the reference's modules (g10) loads into the oracle's state dicts and reproduces the
+    reference's renders from it (render_fitting and the texture-encoder entry)."""
+    import gzip
+    raw = gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_ckpt_000100.tar.gz")).read()
+    p = tmp_path / "000100.tar"
+    p.write_bytes(raw)
+    ck = torch.load(str(p), map_location="cpu", weights_only=False)
+    assert ck["global_step"] == 100 and len(ck["expression_latent_codes_sigma"]) == 20
+    g = golden("ckpt_render.npz")
+    r = orc.OracleRenderer(ck["network_fn_state_dict"], ck["network_fine_state_dict"], ck["network_render_idSpecific"],
+                           [t.detach() for t in ck["expression_latent_codes_sigma"]], ck["network_render_textureEncoder"],
+                           netchunk=4096)
+    ro, rd = orc.get_rays(8, 8, g["K"], T(g["c2w"]))
+    with torch.no_grad():
+        rgb, disp, acc, ex = r.render(ro, rd, 64, T(g["bm"]), 20, 8.0, 26.0, tex_code=T(g["tex"]), exp_codes=T(g["exp"]),
+                                      N_samples=64, N_importance=64)
+    nan_equal_close(rgb.numpy(), g["rgb"], 2e-6)
+    nan_equal_close(acc.numpy(), g["acc"], 2e-6)
+    r.exp_sigma = r.exp_sigma[:20]
+    uv = T(np.random.default_rng(5).uniform(0, 1, (512, 512, 3)).astype(np.float32))
+    with torch.no_grad():
+        rgb, disp, acc, ex = r.render(ro.reshape(-1, 3), rd.reshape(-1, 3), 64, T(g["bm"]), 7, 8.0, 26.0, uv_map=uv,
+                                      N_samples=64, N_importance=64)
+        code = orc.tex_encoder(r.tex_enc, uv)
+    nan_equal_close(code.numpy(), g["t_tex_code"], 1e-6, 1e-5)
+    nan_equal_close(rgb.numpy(), g["t_rgb"], 2e-6)
+    nan_equal_close(acc.numpy(), g["t_acc"], 2e-6)

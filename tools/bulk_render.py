@@ -61,12 +61,16 @@ def main(argv=None):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     total = torch.tensor([float(sum(done))], dtype=torch.float64)
     if world > 1:
-        torch.distributed.all_reduce(total.to(dev) if torch.distributed.get_backend() == "nccl" else total)
+        if torch.distributed.get_backend() == "nccl":
+            total = total.to(dev)                      # keep the tensor the collective reduces INTO
+        torch.distributed.all_reduce(total)
     dt = mdist.barrier_max(dt, dev)
     if rank == 0:
-        imgs = float(total.item()) if world == 1 else None
-        print(json.dumps({"images_rendered_rank0": sum(done), "world": world, "seconds": round(dt, 3), "size": a.size,
-                          "rays_per_s_rank0": round(sum(done) * a.size * a.size / dt, 1)}), flush=True)
+        imgs = int(total.item())
+        print(json.dumps({"images_rendered_rank0": sum(done), "images_rendered_total": imgs, "world": world,
+                          "seconds": round(dt, 3), "size": a.size,
+                          "rays_per_s_rank0": round(sum(done) * a.size * a.size / dt, 1),
+                          "rays_per_s_total": round(imgs * a.size * a.size / dt, 1)}), flush=True)
     return sum(done)
 
 

@@ -120,6 +120,25 @@ if __name__ == "__main__" and "--peak" in sys.argv:
               f"({flops / (ms * 1e-3) / 1e12 / 157.3 * 100:5.1f}% of 157.3)", flush=True)
     sys.exit(0)
 
+if __name__ == "__main__" and "--persist" in sys.argv:
+    # A/B of the persistent twin of the layer kernel (MOFA_PERSIST / MOFA_DEPHASE), interleaved rounds in ONE process
+    arms = [("per-tile workgroups (shipped)", {"MOFA_PERSIST": "0", "MOFA_DEPHASE": "0"}),
+            ("persistent", {"MOFA_PERSIST": "1", "MOFA_DEPHASE": "0"}),
+            ("persistent + dephase", {"MOFA_PERSIST": "1", "MOFA_DEPHASE": "1"})]
+    for (M, K, N, k2) in ((196608, 1024, 1024, 0), (196608, 1024, 1024, 1024), (196608, 256, 256, 0), (131072, 1024, 1024, 0)):
+        res = {name: [] for name, _ in arms}
+        for rnd in range(3):
+            for name, env in arms:
+                os.environ.update(env)
+                lib.reload_env()
+                ms, tf = run(M, K, N, k2, iters=20)
+                res[name].append(tf)
+        for name, _ in arms:
+            v = res[name]
+            print(f"M={M:7d} K={K + k2:5d} N={N:5d} {name:32s}: " + " ".join(f"{t:7.2f}" for t in v) +
+                  f"  TFLOP/s (best {max(v):7.2f} = {max(v) / 157.3 * 100:5.1f}% of fp32 MFMA peak)", flush=True)
+    sys.exit(0)
+
 if __name__ == "__main__" and "--split-hh" in sys.argv:
     for (M, K, N) in ((196608, 1024, 1024), (196608, 256, 256)):
         ms, tf = run_split_hh(M, K, N)
@@ -145,6 +164,7 @@ if __name__ == "__main__":
              (196608, 256, 256, 256), (32768, 1024, 1024, 0), (65536, 64, 64, 0)]
     for stage in ("glds", "reg"):
         os.environ["MOFA_STAGE"] = stage
+        lib.reload_env()
         for (M, K, N, k2) in cases:
             ms, tf = run(M, K, N, k2)
             print(f"stage={stage:4s} M={M:7d} K={K + k2:5d} N={N:5d}: {ms:8.3f} ms  {tf:7.2f} TFLOP/s  "

@@ -62,8 +62,10 @@ def main(argv=None):
     same = True
     if world > 1:
         t = torch.tensor([digest], dtype=torch.int64)
+        if dist.get_backend() != "gloo":                      # RCCL needs every buffer — input AND outputs — on the GPU
+            t = t.to(dev)
         gathered = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(gathered, t if dist.get_backend() == "gloo" else t.to(dev))
+        dist.all_gather(gathered, t)
         same = all(int(g.item()) == digest for g in gathered)
     if rank == 0:
         print(json.dumps({"world": world, "rays_per_rank": a.rays, "steps": a.steps, "ms_per_step": [round(t * 1e3, 1) for t in times],
