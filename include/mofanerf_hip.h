@@ -188,12 +188,13 @@ int mofa_positional_encode(const float* x, int64_t n, int32_t n_freqs, float* ou
 /* ---- measurement hook ------------------------------------------------------------------------
  * A measurement session of the CALLING THREAD'S CURRENT DEVICE (state is per device, mutex-guarded; with no session
  * open the launch paths read one atomic flag).  Between mofa_prof_begin() and mofa_prof_end() every launch of the MFMA
- * kernels — [0] the per-layer forward kernel k_layer<128,false,*> / k_layer_persist<128>, [1] the persistent
+ * kernels — [0] the per-layer forward kernel k_layer<128,false,true> / k_layer_persist, [1] the persistent
  * whole-network kernel k_mlp_fused (widths <= 256), [2] the backward-data kernel k_layer<128,..,BWD>, [3] the
- * weight-gradient kernel k_wgrad — is bracketed by hipEventRecord on its own stream.  mofa_prof_end() synchronises those
+ * weight-gradient kernel k_wgrad, [4] the view layer's per-ray-bias instantiation of the forward kernel — is bracketed by
+ * hipEventRecord on its own stream.  mofa_prof_end() synchronises those
  * events (host blocks) and fills three arrays of length MOFA_PROF_KINDS: summed kernel time, launch count, FLOPs
  * executed (2*M*K*N of the padded shapes).  Used by bench.py only. */
-#define MOFA_PROF_KINDS 4
+#define MOFA_PROF_KINDS 5
 int mofa_prof_begin(void);
 int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops);
 

@@ -118,6 +118,67 @@ __device__ __forceinline__ void mma_panel(const float* __restrict__ Xt, const fl
     }
 }
 
+// Forward epilogue of one wave tile (NI x NJ accumulators of 32x32): bias + ReLU, one 16-byte store per accumulator quad
+// straight into the next layer's panels.  PERRAY (the view layer: bias row = ray of the point) is a TEMPLATE parameter on
+// purpose: with the per-ray bias loads inside the point loop under a RUN-TIME `if`, hipcc must assume at the join that the
+// loads may still be in flight and brackets every store with `s_waitcnt vmcnt(7)` — and because loads and stores share the
+// in-order vmcnt on gfx9, that also limits every wave of the ordinary layers to 7 stores in flight: the 32 stores per lane
+// of a tile then take 4-5 store-acknowledge round trips (the "12 us to issue the epilogue stores" of DESIGN.md 3.1) instead
+// of being fire-and-forget.  With PERRAY = false the bias is fetched once, waited for once, and the 32 stores issue back to
+// back with no wait between them.
+template <int NI>
+__device__ __forceinline__ void bias_fetch(const float* __restrict__ bias_base, int n_first, int lane, f32x4 (&bv)[NI][4]) {
+    int boff = n_first + 4 * (lane >> 5);
+    asm volatile("" : "+v"(boff));  // opaque AFTER the K loop: keeps hipcc from hoisting the 8 bias loads (32 VGPRs) above it
+#pragma unroll
+    for (int i = 0; i < NI; ++i)    // one bias row for every point: fetch it once, all 8 loads in flight together
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(bias_base + boff + 32 * i + 8 * q);
+}
+
+// FETCH = false: `bv` was filled by bias_fetch earlier (the persistent kernel fetches it BEFORE it requests the next tile's
+// first panel, so that the in-order vmcnt wait for the bias does not also wait for that panel).
+template <int NI, int NJ, bool PERRAY, bool HH, bool FETCH = true>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[NI][NJ], const float* __restrict__ bias_base, long long bias_rows,
+                                           int bias_row_div, int n_padded, float* __restrict__ y, long long m_padded,
+                                           long long m_first, int n_first, int relu, int lane, f32x4 (&bv)[NI][4]) {
+    const int lr = lane & 31, g = lane >> 5;
+    int boff = n_first + 4 * g;
+    if constexpr (!PERRAY && FETCH) bias_fetch<NI>(bias_base, n_first, lane, bv);
+    if constexpr (PERRAY) asm volatile("" : "+v"(boff));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const long long m = m_first + 32 * j + lr;
+        if constexpr (PERRAY) {     // per-ray bias (view layer): row = ray of this point
+            long long brow = m / bias_row_div;
+            if (brow >= bias_rows) brow = bias_rows - 1;
+            const float* bias = bias_base + brow * n_padded + boff;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(bias + 32 * i + 8 * q);
+        }
+        const int msw = (int)(m >> 2) & 3;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n_first + 32 * i + 8 * q + 4 * g;
+                f32x4 v;
+                v.x = acc[i][j][4 * q + 0] + bv[i][q].x;
+                v.y = acc[i][j][4 * q + 1] + bv[i][q].y;
+                v.z = acc[i][j][4 * q + 2] + bv[i][q].z;
+                v.w = acc[i][j][4 * q + 3] + bv[i][q].w;
+                if (relu) {
+                    v.x = relu_np(v.x), v.y = relu_np(v.y), v.z = relu_np(v.z), v.w = relu_np(v.w);
+                }
+                if constexpr (HH) store_quad_hh(y, m_padded, n, m, msw, v);
+                else *(f32x4*)(y + (long long)(n >> 4) * m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
+            }
+        }
+    }
+}
+
 // BN: feature-tile height; L0: X tile is generated (positional encoding) instead of loaded;
 // GLDS: stage operands with LDS-DMA (true) or through registers (false; kept as the A/B arm).
 // BWD: backward-data epilogue (no bias/ReLU; optional accumulate into y and ReLU mask from the saved activation):
@@ -125,7 +186,7 @@ __device__ __forceinline__ void mma_panel(const float* __restrict__ Xt, const fl
 #ifndef MOFA_LAYER_WAVES
 #define MOFA_LAYER_WAVES 2  // min waves per SIMD the register allocator must leave room for (= workgroups per CU)
 #endif
-template <int BN, bool L0, bool GLDS, bool BWD = false, bool HH = false>
+template <int BN, bool L0, bool GLDS, bool BWD = false, bool HH = false, bool PERRAY = false>
 __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BM = kRowTile;
@@ -272,45 +333,8 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
     }
     // epilogue: bias + ReLU, one 16-B store per accumulator quad into the next layer's panels
     f32x4 bv[NI][4];
-    int boff = n0 + wn * 64 + 4 * g;
-    asm volatile("" : "+v"(boff));  // opaque AFTER the K loop: keeps hipcc from hoisting the 8 bias loads (32 VGPRs) above it
-    if (!a.bias_row_div) {  // one bias row for every point: fetch it once, all 8 loads in flight together
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(a.bias + boff + 32 * i + 8 * q);
-    }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const long long m = m0 + wm * (32 * NJ) + 32 * j + lr;
-        if (a.bias_row_div) {  // per-ray bias (view layer): row = ray of this point
-            long long brow = m / a.bias_row_div;
-            if (brow >= a.bias_rows) brow = a.bias_rows - 1;
-            const float* bias = a.bias + brow * a.n_padded + n0 + wn * 64 + 4 * g;
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(bias + 32 * i + 8 * q);
-        }
-        const int msw = (int)(m >> 2) & 3;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * 64 + 32 * i + 8 * q + 4 * g;
-                f32x4 v;
-                v.x = acc[i][j][4 * q + 0] + bv[i][q].x;
-                v.y = acc[i][j][4 * q + 1] + bv[i][q].y;
-                v.z = acc[i][j][4 * q + 2] + bv[i][q].z;
-                v.w = acc[i][j][4 * q + 3] + bv[i][q].w;
-                if (a.relu) {
-                    v.x = relu_np(v.x), v.y = relu_np(v.y), v.z = relu_np(v.z), v.w = relu_np(v.w);
-                }
-                if constexpr (HH) store_quad_hh(a.y, a.m_padded, n, m, msw, v);
-                else *(f32x4*)(a.y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
-            }
-        }
-    }
+    store_tile<NI, NJ, PERRAY, HH>(acc, a.bias, a.bias_rows, a.bias_row_div, a.n_padded, a.y, a.m_padded, m0 + wm * (32 * NJ),
+                                   n0 + wn * 64, a.relu, lane, bv);
 }
 
 // ---- persistent twin of k_layer<128,false,true> (MOFA_PERSIST=1; A/B arm) ------------------------------
@@ -332,7 +356,6 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer_persist(const L
     const int wn = wave & 1, wm = wave >> 1;
     const int KT = a.k1p + a.k2p;
     const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
-    const int lr = lane & 31, g = lane >> 5;
 
     auto tile_of = [&](int it, long long& m0, int& n0) -> bool {
         const int local = w + it * wg_per_xcd;
@@ -373,7 +396,13 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer_persist(const L
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-        __syncthreads();                       // panel 0 of this tile has landed (requested before the previous epilogue)
+        // Panel 0 of this tile has landed?  It was requested BEFORE the previous tile's NI*NJ*4 = 32 stores per lane, and on
+        // gfx9 vector-memory operations of one wave retire IN ORDER (loads and stores share vmcnt; hipcc itself emits
+        // vmcnt(N > 0) across younger stores), so vmcnt(32) = "everything older than the last 32 stores" = the panel, WITHOUT
+        // waiting for the store acknowledgements of the chip-wide write burst (a plain __syncthreads() would: vmcnt(0)).
+        if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         for (int kt = 0; kt < KT; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < KT) stage_issue(cur ^ 1, kt + 1, m0, n0);
@@ -381,49 +410,48 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer_persist(const L
             mma_panel<NI, NJ>(xs, xs + BM * 16, wm * (32 * NJ), wn * 64, lane, acc);
             __syncthreads();
         }
-        // request the NEXT tile's first panel before this tile's stores (no wave reads LDS any more: the loop ended on a barrier)
+        // (1) bias + ReLU applied IN PLACE to the accumulators (the wait for the bias happens here, before anything else is in
+        // flight), (2) request the next tile's first panel, (3) this tile's 32 stores per lane, which need no wait at all.
+        // (No wave reads LDS any more: the K loop ended on a barrier.)
+        const bool perray = a.bias_row_div != 0;
+        if (!perray) {
+            f32x4 bv[NI][4];
+            bias_fetch<NI>(a.bias, n0 + wn * 64, lane, bv);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = acc[i][j][4 * q + e] + bv[i][q][e];
+                            acc[i][j][4 * q + e] = a.relu ? relu_np(v) : v;
+                        }
+        }
         long long m1 = 0;
         int n1 = 0;
         const bool more = tile_of(it + 1, m1, n1);
         if (more) stage_issue(0, 0, m1, n1);
-        // epilogue: bias + ReLU + panel store (k_layer's, verbatim)
-        f32x4 bv[NI][4];
-        int boff = n0 + wn * 64 + 4 * g;
-        asm volatile("" : "+v"(boff));
-        if (!a.bias_row_div) {
+        if (perray) {
+            f32x4 bv[NI][4];
+            store_tile<NI, NJ, true, false>(acc, a.bias, a.bias_rows, a.bias_row_div, a.n_padded, a.y, a.m_padded,
+                                            m0 + wm * (32 * NJ), n0 + wn * 64, a.relu, lane, bv);
+        } else {
+            const int lr = lane & 31, g = lane >> 5;
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(a.bias + boff + 32 * i + 8 * q);
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const long long m = m0 + wm * (32 * NJ) + 32 * j + lr;
-            if (a.bias_row_div) {
-                long long brow = m / a.bias_row_div;
-                if (brow >= a.bias_rows) brow = a.bias_rows - 1;
-                const float* bias = a.bias + brow * a.n_padded + n0 + wn * 64 + 4 * g;
+            for (int j = 0; j < NJ; ++j) {
+                const long long m = m0 + wm * (32 * NJ) + 32 * j + lr;
+                const int msw = (int)(m >> 2) & 3;
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(bias + 32 * i + 8 * q);
-            }
-            const int msw = (int)(m >> 2) & 3;
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wn * 64 + 32 * i + 8 * q + 4 * g;
-                    f32x4 v;
-                    v.x = acc[i][j][4 * q + 0] + bv[i][q].x;
-                    v.y = acc[i][j][4 * q + 1] + bv[i][q].y;
-                    v.z = acc[i][j][4 * q + 2] + bv[i][q].z;
-                    v.w = acc[i][j][4 * q + 3] + bv[i][q].w;
-                    if (a.relu) {
-                        v.x = relu_np(v.x), v.y = relu_np(v.y), v.z = relu_np(v.z), v.w = relu_np(v.w);
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n0 + wn * 64 + 32 * i + 8 * q + 4 * g;
+                        f32x4 v;
+                        v.x = acc[i][j][4 * q + 0], v.y = acc[i][j][4 * q + 1], v.z = acc[i][j][4 * q + 2], v.w = acc[i][j][4 * q + 3];
+                        *(f32x4*)(a.y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
                     }
-                    *(f32x4*)(a.y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
-                }
             }
         }
         if (!more) break;
@@ -683,7 +711,6 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
     constexpr int STAGE = (TM + BNMAX) * 16;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 31, g = lane >> 5;
     const int half_tiles = a.m_tiles * 2;
 
     for (int ht = blockIdx.x; ht < half_tiles; ht += gridDim.x) {
@@ -759,41 +786,11 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
             if (active) {
                 float* y = a.arena_w + l.y_off;
                 f32x4 bv[NI][4];
-                int boff = nbase + wn * 64 + 4 * g;
-                asm volatile("" : "+v"(boff));
-                if (!l.bias_row_div) {
-#pragma unroll
-                    for (int i = 0; i < NI; ++i)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(a.folded + l.bias_off + boff + 32 * i + 8 * q);
-                }
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const long long m = m0 + 32 * j + lr;
-                    if (l.bias_row_div) {
-                        long long brow = m / l.bias_row_div;
-                        if (brow >= a.bias_rows) brow = a.bias_rows - 1;
-                        const float* bias = a.view_bias_rows + l.bias_off + brow * np + boff;
-#pragma unroll
-                        for (int i = 0; i < NI; ++i)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(bias + 32 * i + 8 * q);
-                    }
-                    const int msw = (int)(m >> 2) & 3;
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int n = nbase + wn * 64 + 32 * i + 8 * q + 4 * g;
-                            f32x4 v;
-                            v.x = relu_np(acc[i][j][4 * q + 0] + bv[i][q].x);
-                            v.y = relu_np(acc[i][j][4 * q + 1] + bv[i][q].y);
-                            v.z = relu_np(acc[i][j][4 * q + 2] + bv[i][q].z);
-                            v.w = relu_np(acc[i][j][4 * q + 3] + bv[i][q].w);
-                            *(f32x4*)(y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
-                        }
-                    }
-                }
+                if (l.bias_row_div)
+                    store_tile<NI, NJ, true, false>(acc, a.view_bias_rows + l.bias_off, a.bias_rows, l.bias_row_div, np, y, a.m_padded, m0,
+                                                    nbase + wn * 64, 1, lane, bv);
+                else
+                    store_tile<NI, NJ, false, false>(acc, a.folded + l.bias_off, 1, 0, np, y, a.m_padded, m0, nbase + wn * 64, 1, lane, bv);
             }
             }   // feature blocks
             // this workgroup's stores of layer li feed its own loads of layer li+1
@@ -1249,12 +1246,12 @@ inline int stage_mode() { return config().stage_glds; }  // MOFA_STAGE=reg selec
 // The measurement session is explicit state the HOST opens and closes (mofa_prof_begin/end); it is kept per device and
 // guarded by a mutex, so two devices or two host threads in one process do not share or corrupt it.  When no session is
 // open the launch paths only read one relaxed atomic.
-constexpr int kProfKinds = 4;   // 0: k_layer<128,false,*> (forward), 1: k_mlp_fused, 2: k_layer<BWD> (backward-data), 3: k_wgrad
+constexpr int kProfKinds = MOFA_PROF_KINDS;   // 0: k_layer<128,false,true> (forward), 1: k_mlp_fused, 2: k_layer<BWD>, 3: k_wgrad, 4: k_layer<..PERRAY> (view layer)
 struct ProfState {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     std::vector<int> kind;
     size_t used = 0;
-    double flops[kProfKinds] = {0.0, 0.0, 0.0, 0.0};
+    double flops[kProfKinds] = {};
 };
 ProfState g_prof[kMaxDevices];
 std::atomic<bool> g_prof_on[kMaxDevices];
@@ -1293,7 +1290,7 @@ int launch_layer(LayerArgs a, hipStream_t st) {
     const unsigned grid = (unsigned)round_up(total, 8);
     const size_t lds = 2 * (size_t)(kRowTile + BN) * 16 * sizeof(float);
     const bool prof = BN == 128 && !L0 && prof_enabled();
-    const int pkind = BWD ? 2 : 0;
+    const int pkind = BWD ? 2 : (a.bias_row_div ? 4 : 0);   // the view layer's per-ray-bias instantiation is its own kernel
     if (prof && prof_open(st, pkind) != MOFA_OK) return MOFA_EHIP;
     bool launched = false;
     if constexpr (L0 && BN == 128) {
@@ -1317,6 +1314,8 @@ int launch_layer(LayerArgs a, hipStream_t st) {
     if (launched) {
     } else if constexpr (BWD)
         hipLaunchKernelGGL((k_layer<BN, false, true, true>), dim3(grid), dim3(256), lds, st, a);
+    else if (!L0 && a.bias_row_div)      // per-ray bias (the view layer): its own instantiation, see store_tile
+        hipLaunchKernelGGL((k_layer<BN, false, true, false, false, true>), dim3(grid), dim3(256), lds, st, a);
     else if (stage_mode())
         hipLaunchKernelGGL((k_layer<BN, L0, true>), dim3(grid), dim3(256), lds, st, a);
     else
@@ -1525,9 +1524,10 @@ int mofa_prof_begin(void) {
     return MOFA_OK;
 }
 
-/* arrays of MOFA_PROF_KINDS (4): [0] the per-layer forward MFMA kernel k_layer<128,false,*> (or its persistent twin),
- * [1] the persistent network kernel k_mlp_fused, [2] the backward-data kernel k_layer<128,..,BWD>, [3] the weight-gradient
- * kernel k_wgrad.  Session of the CURRENT device. */
+/* arrays of MOFA_PROF_KINDS: [0] the per-layer forward MFMA kernel k_layer<128,false,true,false,false,false> (or its
+ * persistent twin), [1] the persistent network kernel k_mlp_fused, [2] the backward-data kernel k_layer<128,..,BWD>, [3] the
+ * weight-gradient kernel k_wgrad, [4] the per-ray-bias instantiation k_layer<128,false,true,false,false,true> (view layer).
+ * Session of the CURRENT device. */
 int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops) {
     MOFA_REQUIRE(total_ms && launches && padded_flops, "prof_end: null pointer");
     std::lock_guard<std::mutex> lk(g_prof_mu);

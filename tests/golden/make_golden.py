@@ -436,6 +436,26 @@ def g8_true_grads():
                                                       arch=np.array([D, W])).items()})
         for key, p in list(net.named_parameters()) + [("style." + k, v) for k, v in r.idSpecificMod.named_parameters()]:
             out[f"{tag}_gs/{key}"], out[f"{tag}_gn/{key}"] = _sampled(p.grad, f"{tag}/{key}")
+        # The same modules and the same fp32 point set in DOUBLE: the yardstick.  The reference's fp32 gradients are themselves
+        # 1e-3 .. 1e-2 away from it (ReLU masks of units whose pre-activation is within fp32 noise of 0 flip, and every first-layer
+        # gradient passes through d/dx sin(2^9 x)), so an fp32 implementation is judged by ITS distance to this truth relative
+        # to the reference's own distance — not by its distance to another fp32 result.
+        r64 = mk_renderer(196608, 0)
+        r64.idSpecificMod.double()
+        net64 = mk_nerf(D, W, 0, tag).double().train()
+        bm64, tex64, exp64 = [t.detach().double().requires_grad_(True) for t in (bm, tex, exp)]
+        o64, d64 = o.detach().clone().requires_grad_(True), d.detach().clone().requires_grad_(True)     # fp32 leaves
+        r64.shapeCodes, r64.expType, r64.decoding_texCodes = bm64.expand(R, 50), 20, tex64
+        r64.expCodes_Sigma = [e.detach().double() for e in r64.expCodes_Sigma] + [exp64]
+        pts64 = (o64[:, None, :] + d64[:, None, :] * z[:, :, None]).double()
+        vd64 = (d64 / torch.norm(d64, dim=-1, keepdim=True)).double()
+        raw64 = r64.run_network(pts64, vd64, net64)
+        (raw64 * G.double()).sum().backward()
+        out.update({f"{tag}_t_{k}": v.detach().double() for k, v in dict(raw=raw64, g_o=o64.grad, g_d=d64.grad, g_bm=bm64.grad,
+                                                                           g_tex=tex64.grad, g_exp=exp64.grad).items()})
+        for key, p in list(net64.named_parameters()) + [("style." + k, v) for k, v in r64.idSpecificMod.named_parameters()]:
+            s64, n64 = _sampled(p.grad, f"{tag}/{key}")
+            out[f"{tag}_ts/{key}"], out[f"{tag}_tn/{key}"] = s64.double(), p.grad.double().norm()
     save("grads_true.npz", out)
 
 

@@ -162,7 +162,7 @@ def test_reference_written_checkpoint_reloads_and_renders(golden, tmp_path):
                                                    verbose=True, **kw)
     nan_equal_close(ex["rgb0"].cpu().numpy(), g["rgb0"], 1e-4)
     nan_equal_close(ex["acc0"].cpu().numpy(), g["acc0"], 1e-4)
-    nan_equal_close(ex["_weights0"].cpu().numpy(), g["weights_coarse"], 2e-5)
+    nan_equal_close(ex["_weights0"].reshape(64, 64).cpu().numpy(), g["weights_coarse"], 2e-5)
     # fine pass on the reference's positions
     ro, rd = orc.get_rays(8, 8, g["K"], T(g["c2w"]))
     ro, rd = ro.reshape(-1, 3).contiguous().to(DEV), rd.reshape(-1, 3).contiguous().to(DEV)
@@ -280,13 +280,14 @@ def test_per_ray_near_far_and_direct_batchify_rays():
         # the oracle takes per-ray bounds through the rays tensor
         o = make_oracle((8, 64, 10, 64), 0, 4096)
         o.exp_sigma.append(synth.codes(0)[2])
-        vd = rays[1].cpu() / torch.norm(rays[1].cpu(), dim=-1, keepdim=True)
+        vd_dev = rays[1] / torch.norm(rays[1], dim=-1, keepdim=True)      # as _make_rays computes it (on the device)
+        vd = vd_dev.cpu()
         r11 = torch.cat([rays[0].cpu(), rays[1].cpu(), near, torch.full((64, 1), 26.0), vd], -1)
         ref = o.render_rays(r11, synth.codes(0)[0], synth.codes(0)[1], 20, 64, 64)
         nan_equal_close(c[3]["rgb0"].cpu().numpy(), ref["rgb0"].numpy(), 1e-4)
         nan_equal_close(c[3]["acc0"].cpu().numpy(), ref["acc0"].numpy(), 1e-4)
         # direct batchify_rays on a caller-built ray tensor
-        render.rays = torch.cat([rays[0], rays[1], near.to(DEV), torch.full((64, 1), 26.0, device=DEV), vd.to(DEV)], -1)
+        render.rays = torch.cat([rays[0], rays[1], near.to(DEV), torch.full((64, 1), 26.0, device=DEV), vd_dev], -1)
         render.shapeCodes, render.expType, render.decoding_texCodes = bm, 20, tex
         d = render.batchify_rays(20, **{k: v for k, v in kw2.items() if k not in ("network_query_fn", "use_viewdirs", "ndc")})
         assert torch.equal(d["rgb0"], c[3]["rgb0"].reshape(-1, 3)) and torch.equal(d["rgb_map"], c[0].reshape(-1, 3))

@@ -343,8 +343,8 @@ def test_sample_pdf_golden(golden):
     np.random.seed(0)
     u_rand = torch.Tensor(np.random.rand(R, 64))
     for u, us, key in ((torch.linspace(0., 1., 64), 0, "spdf_det"), (u_rand, 64, "spdf_rand")):
-        out = torch.empty(R, 64, device=DEV)
-        lib.check(L().mofa_sample_pdf(lib.ptr(bins), B, lib.ptr(w), lib.ptr(dev(u)), us, R, B, 64, lib.ptr(out), lib.stream()),
+        out, u_dev = torch.empty(R, 64, device=DEV), dev(u)
+        lib.check(L().mofa_sample_pdf(lib.ptr(bins), B, lib.ptr(w), lib.ptr(u_dev), us, R, B, 64, lib.ptr(out), lib.stream()),
                   "mofa_sample_pdf")
         got, ref = out.cpu(), T(g[key])
         agree, expl = classify_samples(None, None, u, got, ref, bins=g["spdf_bins"], bin_weights=g["spdf_w"])
@@ -354,8 +354,10 @@ def test_sample_pdf_golden(golden):
         assert frac_ulp > 0.97, (key, frac_ulp)
         assert torch.equal(got[0], ref[0])                               # all-zero weights: uniform pdf, exact
     anchor = torch.empty(1, 8, device=DEV)
-    lib.check(L().mofa_sample_pdf(lib.ptr(dev(torch.linspace(8, 26, 7)[None])), 7, lib.ptr(dev(torch.tensor([[0, .1, .6, .2, .05, 0]]))),
-                                  lib.ptr(dev(torch.linspace(0., 1., 8))), 0, 1, 7, 8, lib.ptr(anchor), lib.stream()), "mofa_sample_pdf")
+    a_bins, a_w, a_u = dev(torch.linspace(8, 26, 7)[None]), dev(torch.tensor([[0, .1, .6, .2, .05, 0]])), dev(torch.linspace(0., 1., 8))
+    lib.check(L().mofa_sample_pdf(lib.ptr(a_bins), 7, lib.ptr(a_w), lib.ptr(a_u), 0, 1, 7, 8, lib.ptr(anchor), lib.stream()),
+              "mofa_sample_pdf")
+    torch.cuda.synchronize()
     nan_equal_close(anchor.cpu().numpy(), g["spdf_anchor"], 2e-6)        # SURVEY.md section 8c sanity anchor
 
 

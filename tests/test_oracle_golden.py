@@ -182,6 +182,19 @@ def test_true_size_gradients(golden):
             got = p.grad.reshape(-1)[_sampled_idx(f"{tag}/{key}", p.numel())].numpy()
             assert np.abs(got - ref_s).max() <= 2e-5 * (np.abs(ref_s).max() + 1e-30) + 1e-6 * ref_n / np.sqrt(p.numel()) + 1e-12, (tag, key)
             assert abs(float(p.grad.double().norm()) - ref_n) <= 1e-5 * ref_n + 1e-12, (tag, key)
+        # the fixture's fp64 yardstick (the reference's modules in double) against the oracle in double
+        st64 = {k: v.detach().double().requires_grad_(True) for k, v in st.items()}
+        sty64 = {k: v.detach().double().requires_grad_(True) for k, v in style.items()}
+        bm64, tex64, exp64 = [t.detach().double().requires_grad_(True) for t in (bm, tex, exp)]
+        o64, d64 = o.detach().clone().requires_grad_(True), d.detach().clone().requires_grad_(True)
+        r64 = orc.OracleRenderer(st64, None, sty64, [e.double() for e in synth.exp_sigma(0)] + [exp64], netchunk=196608)
+        raw64 = r64.run_network((o64[:, None, :] + d64[:, None, :] * z[:, :, None]).double(),
+                                (d64 / torch.norm(d64, dim=-1, keepdim=True)).double(), st64, bm64.expand(o.shape[0], 50), tex64, 20)
+        (raw64 * G.double()).sum().backward()
+        for name, t in (("raw", raw64.detach()), ("g_o", o64.grad), ("g_d", d64.grad), ("g_bm", bm64.grad), ("g_tex", tex64.grad), ("g_exp", exp64.grad)):
+            assert rel(t.numpy(), g[f"{tag}_t_{name}"]) < 1e-9, (tag, name)
+        key = "linear_BiM_xyz.linears1.Linear1.weight"
+        assert abs(float(st64[key].grad.norm()) - float(g[f"{tag}_tn/{key}"])) <= 1e-9 * float(g[f"{tag}_tn/{key}"])
 
 
 def test_config1_fixture_teacher_forced_subset(golden):

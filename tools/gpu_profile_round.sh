@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round profile recipe (run on the GPU box through gpurun): rocprofv3 kernel traces of the three bench modes, summarised to
+# markdown by tools/rocpd_stats.py (the 25 MB databases stay in /tmp), plus the two PMC passes behind roofline.traffic.
+#   bash tools/gpu_profile_round.sh r02
+set -u
+tag=${1:-rXX}
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+mkdir -p gpurun_out/$tag
+for mode in render fit train; do
+  extra="--steps 1 --warmup 1 --cpu-rays 0"
+  [ $mode = fit ] && extra="--steps 5 --warmup 2 --cpu-rays 0"
+  [ $mode = train ] && extra="--steps 2 --warmup 4 --cpu-rays 0"
+  rm -rf /tmp/prof_$mode
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_$mode -o bench -- python bench.py --mode $mode $extra > gpurun_out/$tag/bench_${mode}_under_rocprof.json 2> gpurun_out/$tag/bench_${mode}_under_rocprof.err
+  db=$(find /tmp/prof_$mode -name '*.db' | head -1)
+  python tools/rocpd_stats.py "$db" gpurun_out/$tag/kernel_stats_${mode}.md "rocprofv3 --kernel-trace --stats -- python bench.py --mode $mode $extra"
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o pmc -- python tools/pmc_layer.py > /dev/null 2> gpurun_out/$tag/pmc_$c.err
+  f=$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && grep -E "Kernel_Name|k_layer" "$f" | cut -c1-400 | head -8 > gpurun_out/$tag/pmc_$c.csv
+done
+ls -la gpurun_out/$tag
