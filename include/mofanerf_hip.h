@@ -179,6 +179,14 @@ int mofa_layer_forward(const float* x1, int32_t k1, const float* x2, int32_t k2,
 int mofa_layer0_forward(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
                         const float* pts, int64_t n_points, int32_t S, const float* w_packed, const float* bias,
                         float* y, int64_t m_padded, int32_t n_padded, void* stream);
+/* Layer 0 with ray generation FOLDED INTO THE PROLOGUE: the ray of point m is built from
+ * (intrinsics, c2w[3,4], pixel) by the arithmetic of mofa_get_rays — pixel = pixels[m / S] (flat row * img_w + col) or
+ * pix0 + m / S when pixels == NULL — then pts = o + d * z as in mofa_layer0_forward.  Bit-identical to
+ * mofa_get_rays(_at) followed by mofa_layer0_forward.  (The shipped renderer keeps the 24 B / ray arrays because compositing and
+ * the positional-encoding backward read them as well; this entry is the kernel-level form.) */
+int mofa_layer0_forward_cam(int32_t img_w, float fx, float fy, float cx, float cy, const float* c2w, const int32_t* pixels,
+                            int64_t pix0, const float* z, int64_t z_row_stride, int64_t n_points, int32_t S,
+                            const float* w_packed, const float* bias, float* y, int64_t m_padded, int32_t n_padded, void* stream);
 int mofa_head_forward(const float* x, int32_t k_padded, int64_t m_padded, const float* w_dense, const float* b,
                       int32_t n_out, float* raw, int32_t raw_off, int64_t n_points, void* stream);
 int mofa_view_bias(const float* viewdirs, int64_t n_rays, const float* w, int32_t n_out, int32_t ld,
@@ -203,6 +211,18 @@ int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops);
  * pixels [pix0, pix0+n) of an H x W image in row-major order.  c2w: 12 floats [3,4] (device). */
 int mofa_get_rays(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float* c2w, int64_t pix0,
                   int64_t n, float* rays_o, float* rays_d, float* viewdirs, void* stream);
+
+/* The same for a LIST of pixels (flat indices row * W + col, int32, device): the rays of a fitting / training batch without
+ * building the H x W grid first (run_fit.py:281-293 builds get_rays_withGrad's full grid and gathers N_rand of it;
+ * run_train.py:306-330).  Bit-identical to mofa_get_rays at those pixels. */
+int mofa_get_rays_at(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float* c2w, const int32_t* pixels,
+                     int64_t n, float* rays_o, float* rays_d, float* viewdirs, void* stream);
+
+/* Reverse of ray generation — the camera-pose gradient run_fit.py optimises (get_rays_withGrad, run_fit.py:116-127):
+ *   d_c2w[a][b] = sum_rays d_rays_d[ray][a] * dirs[ray][b] (b < 3),  d_c2w[a][3] = sum_rays d_rays_o[ray][a];  d_c2w: 12 floats.
+ * pixels == NULL: the contiguous pixel range [pix0, pix0 + n).  Deterministic (fixed-order double sums, no atomics). */
+int mofa_rays_pose_backward(int32_t W, float fx, float fy, float cx, float cy, const int32_t* pixels, int64_t pix0, int64_t n,
+                            const float* d_rays_o, const float* d_rays_d, float* d_c2w, void* stream);
 
 /* raw2outputs (render_class.py:440-482): one wavefront per ray, exclusive prefix product over the
  * samples.  noise may be NULL; disp is NaN where acc == 0 exactly like the reference. */

@@ -22,6 +22,21 @@ __host__ __device__ inline int64_t panel_index(int64_t rows, int64_t row, int k)
            (k & 3);
 }
 
+// One pinhole ray (tools/run_nerf_helpers.py:153-168) with the reference's operation order and separately rounded ops:
+// dirs = [(i - cx) / fx, -(j - cy) / fy, -1];  rays_d[a] = (dirs0 * c[a][0] + dirs1 * c[a][1]) + dirs2 * c[a][2];  rays_o = c[:, 3].
+// Shared by k_get_rays (full frames / pixel lists) and the layer-0 prologue's camera mode, so both are bit-identical.
+__device__ __forceinline__ void pinhole_ray(int i, int j, float fx, float fy, float cx, float cy, const float* __restrict__ c2w,
+                                            float (&ro)[3], float (&rd)[3]) {
+    const float d0 = __fdiv_rn((float)i - cx, fx);
+    const float d1 = -__fdiv_rn((float)j - cy, fy);
+    const float d2 = -1.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        rd[a] = __fadd_rn(__fadd_rn(__fmul_rn(d0, c2w[a * 4 + 0]), __fmul_rn(d1, c2w[a * 4 + 1])), __fmul_rn(d2, c2w[a * 4 + 2]));
+        ro[a] = c2w[a * 4 + 3];
+    }
+}
+
 // ReLU with torch's NaN behaviour (F.relu(nan) = nan; fmaxf(nan, 0) would be 0): a NaN that enters the network - bad
 // input, or an fp16 overflow in the opt-in split mode - must reach the image exactly as it does in the reference.
 __device__ __forceinline__ float relu_np(float v) { return v < 0.f ? 0.f : v; }

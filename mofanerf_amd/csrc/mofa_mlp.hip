@@ -54,6 +54,12 @@ struct LayerArgs {
     int n_tiles;          // n_padded / BN
     int total_tiles;
     int y_hh;             // opt-in fp16x3 mode only: write y as pre-split fp16 piece panels (store_quad_hh)
+    // layer-0 camera mode (mofa_layer0_forward_cam): rays are built in the prologue from (K, c2w, pixel) instead of being read
+    const float* cam_c2w;   // 12 floats [3,4] (device) or NULL = read rays_o / rays_d
+    const int* cam_pix;     // flat pixel index per ray, or NULL = pixel cam_pix0 + ray
+    long long cam_pix0;
+    float fx, fy, cx, cy;
+    int cam_w;
 };
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -223,10 +229,19 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
             const long long r = m / a.S;
             const int s = (int)(m - r * a.S);
             const float zz = a.z[r * a.z_row_stride + s];
+            float ro[3], rd[3];
+            if (a.cam_c2w) {   // the ray itself comes from (K, c2w, pixel): get_rays folded into the prologue
+                const long long pix = a.cam_pix ? (long long)a.cam_pix[r] : a.cam_pix0 + r;
+                const int pj = (int)(pix / a.cam_w), pi = (int)(pix - (long long)pj * a.cam_w);
+                pinhole_ray(pi, pj, a.fx, a.fy, a.cx, a.cy, a.cam_c2w, ro, rd);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ro[c] = a.rays_o[r * 3 + c], rd[c] = a.rays_d[r * 3 + c];
+            }
             // pts = o + d * z with a separately rounded multiply and add (render_class.py:315)
-            px = __fadd_rn(a.rays_o[r * 3 + 0], __fmul_rn(a.rays_d[r * 3 + 0], zz));
-            py = __fadd_rn(a.rays_o[r * 3 + 1], __fmul_rn(a.rays_d[r * 3 + 1], zz));
-            pz = __fadd_rn(a.rays_o[r * 3 + 2], __fmul_rn(a.rays_d[r * 3 + 2], zz));
+            px = __fadd_rn(ro[0], __fmul_rn(rd[0], zz));
+            py = __fadd_rn(ro[1], __fmul_rn(rd[1], zz));
+            pz = __fadd_rn(ro[2], __fmul_rn(rd[2], zz));
         }
     }
 
@@ -1484,6 +1499,19 @@ int mofa_layer0_forward(const float* rays_o, const float* rays_d, const float* z
     LayerArgs a{};
     a.w = w_packed, a.bias = bias, a.y = y, a.rays_o = rays_o, a.rays_d = rays_d, a.z = z, a.pts = pts;
     a.z_row_stride = z_row_stride, a.n_points = n_points, a.S = S > 0 ? S : 1;
+    a.k1p = 4, a.k2p = 0, a.n_padded = n_padded, a.m_padded = m_padded, a.relu = 1;
+    return dispatch_layer(a, true, (hipStream_t)stream);
+}
+
+int mofa_layer0_forward_cam(int32_t img_w, float fx, float fy, float cx, float cy, const float* c2w, const int32_t* pixels,
+                            int64_t pix0, const float* z, int64_t z_row_stride, int64_t n_points, int32_t S,
+                            const float* w_packed, const float* bias, float* y, int64_t m_padded, int32_t n_padded, void* stream) {
+    MOFA_REQUIRE(c2w && z && w_packed && bias && y && img_w > 0 && S > 0, "layer0_forward_cam: bad arguments");
+    MOFA_REQUIRE(n_points > 0 && n_points <= m_padded, "layer0_forward_cam: n_points=%lld m_padded=%lld", (long long)n_points,
+                 (long long)m_padded);
+    LayerArgs a{};
+    a.w = w_packed, a.bias = bias, a.y = y, a.z = z, a.z_row_stride = z_row_stride, a.n_points = n_points, a.S = S;
+    a.cam_c2w = c2w, a.cam_pix = (const int*)pixels, a.cam_pix0 = pix0, a.fx = fx, a.fy = fy, a.cx = cx, a.cy = cy, a.cam_w = img_w;
     a.k1p = 4, a.k2p = 0, a.n_padded = n_padded, a.m_padded = m_padded, a.relu = 1;
     return dispatch_layer(a, true, (hipStream_t)stream);
 }

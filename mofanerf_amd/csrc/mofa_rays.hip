@@ -22,30 +22,59 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 // ---- get_rays (tools/run_nerf_helpers.py:153-168) + viewdirs (render_class.py:399-401) -------------
+// `pix_list` (may be NULL): flat pixel indices j * W + i of the n rays (fitting / training batches gather 1-4 k of the H*W
+// pixels, run_fit.py:281-293, run_train.py:306-330); NULL = the contiguous range [pix0, pix0 + n).
 __global__ __launch_bounds__(256) void k_get_rays(int H, int W, float fx, float fy, float cx, float cy,
                                                   const float* __restrict__ c2w, long long pix0, long long n,
-                                                  float* __restrict__ rays_o, float* __restrict__ rays_d,
-                                                  float* __restrict__ viewdirs) {
+                                                  const int* __restrict__ pix_list, float* __restrict__ rays_o,
+                                                  float* __restrict__ rays_d, float* __restrict__ viewdirs) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
-    const long long pix = pix0 + t;
+    const long long pix = pix_list ? (long long)pix_list[t] : pix0 + t;
     const int j = (int)(pix / W), i = (int)(pix - (long long)j * W);
-    const float d0 = __fdiv_rn((float)i - cx, fx);
-    const float d1 = -__fdiv_rn((float)j - cy, fy);
-    const float d2 = -1.0f;
-    float rd[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)  // sum(dirs[..., None, :] * c2w[:3, :3], -1): ((d0*c0 + d1*c1) + d2*c2)
-        rd[a] = __fadd_rn(__fadd_rn(__fmul_rn(d0, c2w[a * 4 + 0]), __fmul_rn(d1, c2w[a * 4 + 1])),
-                          __fmul_rn(d2, c2w[a * 4 + 2]));
+    float ro[3], rd[3];
+    pinhole_ray(i, j, fx, fy, cx, cy, c2w, ro, rd);
     const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(rd[0], rd[0]), __fmul_rn(rd[1], rd[1])),
                                            __fmul_rn(rd[2], rd[2])));
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        rays_o[t * 3 + a] = c2w[a * 4 + 3];
+        rays_o[t * 3 + a] = ro[a];
         rays_d[t * 3 + a] = rd[a];
         if (viewdirs) viewdirs[t * 3 + a] = __fdiv_rn(rd[a], nrm);
     }
+}
+
+// d(loss)/d(c2w[3,4]) from the per-ray gradients (the reverse of pinhole_ray):
+//   d c2w[a][b] = sum_rays d_rays_d[ray][a] * dirs[ray][b]  (b < 3),   d c2w[a][3] = sum_rays d_rays_o[ray][a].
+// One block: thread-local double sums, wavefront butterflies, 4 waves combined through LDS — deterministic, no atomics.
+__global__ __launch_bounds__(256) void k_rays_pose_backward(int W, float fx, float fy, float cx, float cy, long long pix0,
+                                                            long long n, const int* __restrict__ pix_list,
+                                                            const float* __restrict__ d_rays_o,
+                                                            const float* __restrict__ d_rays_d, float* __restrict__ d_c2w) {
+    __shared__ double part[kWavesPerBlock][12];
+    double acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0;
+    for (long long t = threadIdx.x; t < n; t += 256) {
+        const long long pix = pix_list ? (long long)pix_list[t] : pix0 + t;
+        const int j = (int)(pix / W), i = (int)(pix - (long long)j * W);
+        const float dirs[3] = {__fdiv_rn((float)i - cx, fx), -__fdiv_rn((float)j - cy, fy), -1.0f};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double gd = (double)d_rays_d[t * 3 + a];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc[a * 4 + b] += gd * (double)dirs[b];
+            acc[a * 4 + 3] += (double)d_rays_o[t * 3 + a];
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const double v = wave_sum_d(acc[k]);
+        if (lane == 0) part[wv][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) d_c2w[threadIdx.x] = (float)(((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]);
 }
 
 // ---- raw2outputs (models/render_class.py:440-482) --------------------------------------------------
@@ -237,8 +266,25 @@ int mofa_get_rays(int32_t H, int32_t W, float fx, float fy, float cx, float cy, 
     MOFA_REQUIRE(c2w && rays_o && rays_d, "get_rays: null pointer");
     MOFA_REQUIRE(H > 0 && W > 0 && n > 0 && pix0 >= 0 && pix0 + n <= (int64_t)H * W, "get_rays: pixel range");
     hipLaunchKernelGGL(k_get_rays, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, H, W, fx, fy, cx, cy,
-                       c2w, (long long)pix0, (long long)n, rays_o, rays_d, viewdirs);
+                       c2w, (long long)pix0, (long long)n, (const int*)nullptr, rays_o, rays_d, viewdirs);
     return check_launch("k_get_rays");
+}
+
+int mofa_get_rays_at(int32_t H, int32_t W, float fx, float fy, float cx, float cy, const float* c2w, const int32_t* pixels,
+                     int64_t n, float* rays_o, float* rays_d, float* viewdirs, void* stream) {
+    MOFA_REQUIRE(c2w && pixels && rays_o && rays_d, "get_rays_at: null pointer");
+    MOFA_REQUIRE(H > 0 && W > 0 && n > 0 && (int64_t)H * W < (1ll << 31), "get_rays_at: bad image size / count");
+    hipLaunchKernelGGL(k_get_rays, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, H, W, fx, fy, cx, cy,
+                       c2w, 0ll, (long long)n, (const int*)pixels, rays_o, rays_d, viewdirs);
+    return check_launch("k_get_rays(at)");
+}
+
+int mofa_rays_pose_backward(int32_t W, float fx, float fy, float cx, float cy, const int32_t* pixels, int64_t pix0, int64_t n,
+                            const float* d_rays_o, const float* d_rays_d, float* d_c2w, void* stream) {
+    MOFA_REQUIRE(d_rays_o && d_rays_d && d_c2w && W > 0 && n > 0, "rays_pose_backward: bad arguments");
+    hipLaunchKernelGGL(k_rays_pose_backward, dim3(1), dim3(256), 0, (hipStream_t)stream, W, fx, fy, cx, cy, (long long)pix0,
+                       (long long)n, (const int*)pixels, d_rays_o, d_rays_d, d_c2w);
+    return check_launch("k_rays_pose_backward");
 }
 
 int mofa_composite_forward(const float* raw, const float* z, int64_t z_row_stride, const float* rays_d,

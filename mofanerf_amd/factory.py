@@ -59,7 +59,8 @@ def save_checkpoint(path: str, global_step: int, render_kwargs, render, optimize
 def create_nerf(args):
     embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
     if not args.use_viewdirs:
-        raise NotImplementedError("use_viewdirs=False is not part of the shipped configuration")
+        raise NotImplementedError("use_viewdirs=False: the reference's own path for it cannot run (models/model.py:121-137 uses "
+                                  "alpha_linear / rgb_linear, which exist only for use_viewdirs=True)")
     embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
     output_ch = 5 if args.N_importance > 0 else 4
     dev = torch.device(getattr(args, "device", "cuda"))

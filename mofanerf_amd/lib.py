@@ -65,6 +65,8 @@ SIGNATURES = {
     "mofa_from_panels": (C.c_int, [_fp, _i64, _i64, _i32, _fp, _fp]),
     "mofa_layer_forward": (C.c_int, [_fp, _i32, _fp, _i32, _fp, _fp, _i32, _i64, _fp, _i64, _i32, _i32, _fp]),
     "mofa_layer0_forward": (C.c_int, [_fp, _fp, _fp, _i64, _fp, _i64, _i32, _fp, _fp, _fp, _i64, _i32, _fp]),
+    "mofa_layer0_forward_cam": (C.c_int, [_i32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _i64, _fp, _i64, _i64, _i32,
+                                          _fp, _fp, _fp, _i64, _i32, _fp]),
     "mofa_head_forward": (C.c_int, [_fp, _i32, _i64, _fp, _fp, _i32, _fp, _i32, _i64, _fp]),
     "mofa_view_bias": (C.c_int, [_fp, _i64, _fp, _i32, _i32, _fp, _fp, _i32, _fp]),
     "mofa_positional_encode": (C.c_int, [_fp, _i64, _i32, _fp, _fp]),
@@ -72,6 +74,8 @@ SIGNATURES = {
     "mofa_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "mofa_get_rays": (C.c_int, [_i32, _i32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _i64, _i64, _fp, _fp, _fp,
                                 _fp]),
+    "mofa_get_rays_at": (C.c_int, [_i32, _i32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _i64, _fp, _fp, _fp, _fp]),
+    "mofa_rays_pose_backward": (C.c_int, [_i32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _i64, _i64, _fp, _fp, _fp, _fp]),
     "mofa_composite_forward": (C.c_int, [_fp, _fp, _i64, _fp, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
     "mofa_sample_pdf_merge": (C.c_int, [_fp, _i64, _fp, _fp, _i64, _i64, _i32, _i32, _fp, _fp, _fp, _fp]),
     "mofa_sample_pdf": (C.c_int, [_fp, _i64, _fp, _fp, _i64, _i64, _i32, _i32, _fp, _fp]),

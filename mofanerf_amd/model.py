@@ -55,7 +55,8 @@ class NeRF(nn.Module):
                  output_ch=4, skips=(4,), use_viewdirs=False):
         super().__init__()
         if not use_viewdirs:
-            raise NotImplementedError("the MI355X path implements the shipped configuration use_viewdirs=True")
+            raise NotImplementedError("use_viewdirs=False: the reference's own NeRF.forward cannot run without view directions "
+                                      "(models/model.py:121-137 uses alpha_linear / rgb_linear, created only for use_viewdirs=True)")
         if list(skips) != [schema.SKIP]:
             raise NotImplementedError("skips must be [4] (tools/create_model_condition.py:23)")
         self.D, self.W = D, W

@@ -52,6 +52,15 @@ class lossesLog:
         return loss
 
 
+# The reference's own use_viewdirs=False branch cannot execute: NeRF.forward (models/model.py:121-137) uses alpha_linear / rgb_linear,
+# which exist only when use_viewdirs=True (:104-110 builds output_linear instead), and run_network (models/render_class.py:86-92)
+# then hands `batchify` two inputs where its `v1, v2, v3 = inputs` (:101) needs three.  There is no behaviour to be equal to, so
+# the flag is rejected up front — with the reason — instead of failing deep inside a kernel launch.
+_NO_VIEWDIRS = ("use_viewdirs=False: the reference's own path for it cannot run (models/model.py:121-137 needs alpha_linear / "
+                "rgb_linear, created only for use_viewdirs=True; models/render_class.py:101 unpacks three network inputs), and every "
+                "shipped config sets use_viewdirs=True (configs/exp_mofanerf.txt)")
+
+
 def _scalar(v) -> float:
     return float(v.item() if torch.is_tensor(v) else v)
 
@@ -165,7 +174,7 @@ class Renderer(torch.nn.Module):
     def run_network(self, inputs, viewdirs, fn=None):
         """``inputs [R,S,3]`` points, ``viewdirs [R,3]`` -> raw ``[R,S,4]`` (render_class.py:69-94)."""
         if viewdirs is None:
-            raise NotImplementedError("use_viewdirs=False is not part of the shipped configuration")
+            raise NotImplementedError(_NO_VIEWDIRS)
         R, S = int(inputs.shape[0]), int(inputs.shape[1])
         h = self._hip(fn)
         folded = self._fold_codes(fn, self.decoding_texCodes)
@@ -200,7 +209,7 @@ class Renderer(torch.nn.Module):
         rays = self.rays[ray_batch[0]:ray_batch[1]]
         R, dev = int(rays.shape[0]), rays.device
         if rays.shape[-1] <= 8:
-            raise NotImplementedError("use_viewdirs=False is not part of the shipped configuration")
+            raise NotImplementedError(_NO_VIEWDIRS)
         rays_o, rays_d, vd = (rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous(), rays[:, 8:11].contiguous())
         S = int(N_samples)
         if S > 256 or (N_importance > 0 and S + int(N_importance) > 256):
@@ -334,12 +343,8 @@ class Renderer(torch.nn.Module):
 
     # ------------------------------------------------------------------------------------------------
     def _make_rays(self, H, W, K, c2w, rays, use_viewdirs, c2w_staticcam, ndc):
-        if ndc:
-            raise NotImplementedError("ndc=True (LLFF forward-facing scenes) is never used by MoFaNeRF: "
-                                      "create_nerf sets ndc=False for dataset_type=blender "
-                                      "(tools/create_model_condition.py:108-111)")
         if not use_viewdirs:
-            raise NotImplementedError("use_viewdirs=False is not part of the shipped configuration")
+            raise NotImplementedError(_NO_VIEWDIRS)
         L, dev = self._lib(), self._device()
         if dev.type != "cuda":
             raise lib.MofaError("the renderer must be on the GPU (render.cuda()); there is no CPU path")
@@ -365,6 +370,10 @@ class Renderer(torch.nn.Module):
             viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
         if c2w_staticcam is not None:      # visualise the effect of viewdirs only (render_class.py:161-163)
             rays_o, rays_d, _ = gen(c2w_staticcam)
+        if ndc:                            # forward-facing scenes (render_class.py:166-169); viewdirs stay the world-space ones
+            from .rays import ndc_rays
+            rays_o, rays_d = ndc_rays(int(H), int(W), _scalar(K[0][0]), 1., rays_o, rays_d)
+            rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
         return rays_o, rays_d, viewdirs, sh
 
     def _render_common(self, H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, tex_code, kwargs):

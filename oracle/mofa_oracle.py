@@ -133,6 +133,20 @@ def get_rays(H: int, W: int, K, c2w: Tensor) -> Tuple[Tensor, Tensor]:
     return rays_o, rays_d
 
 
+def ndc_rays(H: int, W: int, focal: float, near: float, rays_o: Tensor, rays_d: Tensor) -> Tuple[Tensor, Tensor]:
+    """tools/run_nerf_helpers.py:182-200: shift the origins to the near plane, then project to normalised device
+    coordinates (forward-facing scenes; ``render(..., ndc=True)``, models/render_class.py:166-169)."""
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    rays_o = rays_o + t[..., None] * rays_d
+    o0 = -1. / (W / (2. * focal)) * rays_o[..., 0] / rays_o[..., 2]
+    o1 = -1. / (H / (2. * focal)) * rays_o[..., 1] / rays_o[..., 2]
+    o2 = 1. + 2. * near / rays_o[..., 2]
+    d0 = -1. / (W / (2. * focal)) * (rays_d[..., 0] / rays_d[..., 2] - rays_o[..., 0] / rays_o[..., 2])
+    d1 = -1. / (H / (2. * focal)) * (rays_d[..., 1] / rays_d[..., 2] - rays_o[..., 1] / rays_o[..., 2])
+    d2 = -2. * near / rays_o[..., 2]
+    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+
+
 # --------------------------------------------------------------------------------------------
 # compositing — models/render_class.py:440-482
 # --------------------------------------------------------------------------------------------

@@ -397,6 +397,43 @@ def g11_envelopes(n_pert=8, eps=1e-6):
         save(name + "_env.npz", env)
 
 
+def g12_pose_grads():
+    """run_fit.py's pose path: rays from a camera pose that REQUIRES GRAD (get_rays on a tensor c2w = get_rays_withGrad,
+    run_fit.py:116-127), N_rand of them gathered at sampled pixels (:281-293), render_fitting, L1 loss, backward to the pose.
+    Stores the pixel list, the per-ray gradients and d loss / d c2w."""
+    r = mk_renderer(4096, 0)
+    coarse, fine = mk_nerf(8, 64, 0, "coarse"), mk_nerf(10, 64, 0, "fine")
+    kw = kwargs_for(r, coarse, fine)
+    bm, tex, exp = synth.codes(0)
+    H = 32
+    K = synth.intrinsics(H, H)
+    c2w = pose_spherical(25.0, 0.0, 16.0)[:3, :4].clone().requires_grad_(True)
+    ro, rd = get_rays(H, H, torch.from_numpy(K).float(), c2w)
+    ro.retain_grad(); rd.retain_grad()
+    rng = np.random.default_rng(12)
+    pix = np.sort(rng.choice(H * H, 96, replace=False))
+    rows, cols = torch.from_numpy(pix // H), torch.from_numpy(pix % H)
+    rays_o, rays_d = ro[rows, cols], rd[rows, cols]
+    rays_o.retain_grad(); rays_d.retain_grad()
+    target = torch.from_numpy(rng.uniform(0, 1, (96, 3)).astype(np.float32))
+    rgb, disp, acc, ex = r.render_fitting(H, H, K, chunk=96, rays=torch.stack([rays_o, rays_d], 0), shapeCodes=bm.expand(96, 50),
+                                          uvCodes=tex, expType=20, expCodes=exp, **kw)
+    loss = torch.nn.functional.l1_loss(rgb, target) + (ex["rgb0"] ** 2).mean()
+    loss.backward()
+    save("grads_pose.npz", dict(c2w=c2w, K=K, H=H, pix=pix.astype(np.int32), target=target, bm=bm, tex=tex, exp=exp, rays_o=rays_o,
+                                rays_d=rays_d, rgb=rgb, loss=loss, g_rays_o=rays_o.grad, g_rays_d=rays_d.grad, g_c2w=c2w.grad))
+
+
+def g13_ndc():
+    """ndc_rays (tools/run_nerf_helpers.py:182-200) on a 16x16 view, as render(..., ndc=True) calls it (near = 1)."""
+    from tools.run_nerf_helpers import ndc_rays
+    K = synth.intrinsics(16, 16)
+    c2w = pose_spherical(10.0, -15.0, 4.0)[:3, :4]
+    ro, rd = get_rays(16, 16, K, c2w)
+    no, nd = ndc_rays(16, 16, K[0][0], 1., ro, rd)
+    save("kat_ndc.npz", dict(K=K, c2w=c2w, rays_o=ro, rays_d=rd, ndc_o=no, ndc_d=nd))
+
+
 def _sampled(t, key, n=256):
     """``n`` entries of a gradient tensor at seeded positions (the 27.5 M fine-network weight gradients are not stored
     whole) + its L2 norm."""
@@ -529,7 +566,7 @@ def g10_checkpoint():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         {"g1": g1_kats, "g2": g2_small, "g3": g3_true, "g4": g4_grads, "g5": g5_render_tex, "g6": g6_schema, "g7": g7_config1, "g8": g8_true_grads, "g9": g9_run_network_kat,
-         "g10": g10_checkpoint, "g11": g11_envelopes}[w]()
+         "g10": g10_checkpoint, "g11": g11_envelopes, "g12": g12_pose_grads, "g13": g13_ndc}[w]()

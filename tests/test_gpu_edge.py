@@ -194,10 +194,8 @@ def test_unsupported_flags_fail_loudly():
     K, ro, rd = _rays(8)
     bm, tex, exp = _codes()
     rays = torch.stack([ro, rd], 0).to(DEV)
-    with pytest.raises(NotImplementedError), torch.no_grad():
-        render.render_fitting(8, 8, K, chunk=64, rays=rays, shapeCodes=bm, uvCodes=tex, expType=20, expCodes=exp,
-                              **dict(kw, ndc=True))
-    with pytest.raises(NotImplementedError), torch.no_grad():
+    # use_viewdirs=False: the reference's own branch cannot run (NeRF.forward needs alpha_linear / rgb_linear) -> rejected with the reason
+    with pytest.raises(NotImplementedError, match="alpha_linear"), torch.no_grad():
         render.render_fitting(8, 8, K, chunk=64, rays=rays, shapeCodes=bm, uvCodes=tex, expType=20, expCodes=exp,
                               **dict(kw, use_viewdirs=False))
     with pytest.raises(RuntimeError):
@@ -280,3 +278,32 @@ def test_nan_input_propagates_like_the_reference():
         g, w = got.cpu().numpy(), want.numpy()
         assert (np.isnan(g) == np.isnan(w)).all()
     assert torch.isnan(rgb[5]).all() and torch.isnan(acc[5]) and torch.isfinite(rgb[:5]).all() and torch.isfinite(rgb[6:]).all()
+
+
+def test_ndc_rays_forward_facing_flag(golden):
+    """`render(..., ndc=True)` (models/render_class.py:166-169; the signature's default): rays are mapped to normalised device
+    coordinates by ndc_rays (tools/run_nerf_helpers.py:182-200) after the view directions were taken, near / far = 0 / 1.
+    The mapped rays equal the reference's KAT; the render equals the oracle on the same NDC rays."""
+    from mofanerf_amd import rays as mrays
+    from harness import make_oracle
+    g = golden("kat_ndc.npz")
+    no, nd = mrays.ndc_rays(16, 16, float(g["K"][0][0]), 1., torch.from_numpy(g["rays_o"]).to(DEV), torch.from_numpy(g["rays_d"]).to(DEV))
+    nan_equal_close(no.cpu().numpy(), g["ndc_o"], 1e-6, 1e-6)
+    nan_equal_close(nd.cpu().numpy(), g["ndc_d"], 1e-6, 1e-6)
+    render, kw, _ = make_product(ARCH, 0, 4096, DEV)
+    bm, tex, exp = _codes()
+    kw = dict(kw, ndc=True, near=0.0, far=1.0)
+    with torch.no_grad():
+        rgb, disp, acc, ex = render.render_fitting(16, 16, g["K"], chunk=100, c2w=torch.from_numpy(g["c2w"]), shapeCodes=bm, uvCodes=tex,
+                                                   expType=20, expCodes=exp, **kw)
+    assert rgb.shape == (16, 16, 3)
+    o = make_oracle(ARCH, 0, 4096)
+    o.exp_sigma.append(synth.codes(0)[2])
+    ro, rd = torch.from_numpy(g["rays_o"]).reshape(-1, 3), torch.from_numpy(g["rays_d"]).reshape(-1, 3)
+    vd = rd / torch.norm(rd, dim=-1, keepdim=True)
+    r11 = torch.cat([torch.from_numpy(g["ndc_o"]).reshape(-1, 3), torch.from_numpy(g["ndc_d"]).reshape(-1, 3), torch.zeros(256, 1),
+                     torch.ones(256, 1), vd], -1)
+    with torch.no_grad():
+        ref = o.render_rays(r11, synth.codes(0)[0], synth.codes(0)[1], 20, 64, 64)
+    nan_equal_close(ex["rgb0"].reshape(-1, 3).cpu().numpy(), ref["rgb0"].numpy(), 1e-4)
+    nan_equal_close(ex["acc0"].reshape(-1).cpu().numpy(), ref["acc0"].numpy(), 1e-4)

@@ -250,3 +250,13 @@ def test_reference_checkpoint_renders(golden, tmp_path):
     nan_equal_close(code.numpy(), g["t_tex_code"], 1e-6, 1e-5)
     nan_equal_close(rgb.numpy(), g["t_rgb"], 2e-6)
     nan_equal_close(acc.numpy(), g["t_acc"], 2e-6)
+
+
+def test_ndc_rays(golden):
+    g = golden("kat_ndc.npz")
+    no, nd = orc.ndc_rays(16, 16, g["K"][0][0], 1., T(g["rays_o"]), T(g["rays_d"]))
+    assert np.array_equal(no.numpy(), g["ndc_o"]) and np.array_equal(nd.numpy(), g["ndc_d"])
+    from mofanerf_amd import rays as mrays                       # the product's torch expression, on CPU tensors
+    po, pd = mrays.ndc_rays(16, 16, float(g["K"][0][0]), 1., T(g["rays_o"]), T(g["rays_d"]))
+    nan_equal_close(po.numpy(), g["ndc_o"], 1e-6, 1e-6)
+    nan_equal_close(pd.numpy(), g["ndc_d"], 1e-6, 1e-6)

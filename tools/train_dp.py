@@ -47,7 +47,7 @@ def main(argv=None):
     for it in range(a.steps):
         pose = mrays.pose_spherical(float(rng.uniform(-60, 60)), 0.0, 16.0)[:3, :4].to(dev)
         pix = torch.from_numpy(rng.choice(a.size * a.size, a.rays, replace=False)).to(dev)
-        batch = mrays.rays_at_pixels(K, pose, pix // a.size, pix % a.size)
+        batch = mrays.rays_at_pixels(K, pose, pix // a.size, pix % a.size, a.size, a.size)
         target = torch.from_numpy(rng.uniform(0, 1, (a.rays, 3)).astype(np.float32)).to(dev)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         loss = steps.train_step(render, kw_train, opt, bucket, a.size, a.size, K, batch, target, shape.expand(a.rays, -1), uv,
