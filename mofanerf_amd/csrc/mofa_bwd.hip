@@ -2,6 +2,8 @@
 // The backward-data GEMMs reuse k_layer (mofa_mlp.hip, BWD epilogue); this file holds the HBM-bound pieces:
 // head backward, bias-gradient column sums, positional-encoding backward and raw2outputs backward.
 // Built with -ffp-contract=off like the forward.
+#include <type_traits>
+
 #include "mofa_common.h"
 
 extern "C" {
@@ -405,80 +407,144 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ g, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // one stage = GP + XP panel pieces of MC rows x 64 B, moved as 1 KiB (16-row) wave-instructions
-    auto stage = [&](int buf, long long chunk) {
+    // one stage = GP + XP panel pieces of MC rows x 64 B, moved as 1 KiB (16-row) wave-instructions.  Each wave owns every 4th
+    // piece; its source pointers are formed ONCE and advanced by a constant per chunk (chunks are consumed in order), so staging
+    // costs one 64-bit add per piece instead of a multiply-add chain.
+    constexpr int PPP = MC / 16;                    // 1 KiB pieces per panel
+    constexpr int PIECES = (GP + XP) * PPP;
+    constexpr int NQ = (PIECES + 3) / 4;
+    const float* srcq[NQ];
+    int dstq[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int pc = wave + 4 * q;
+        const int panel = pc / PPP, part = pc % PPP;
+        const float* src = (panel < GP) ? g + ((long long)(n0 / 16 + panel) * m_padded + part * 16) * 16
+                                        : x + ((long long)(k0 / 16 + panel - GP) * m_padded + part * 16) * 16;
+        srcq[q] = src + c_begin * (long long)(MC * 16) + lane * 4;
+        dstq[q] = panel * PSTR + part * 256;
+    }
+    auto stage = [&](int buf) {                     // stages the NEXT chunk (called once per chunk, in order)
         float* base = smem + buf * STAGE;
-        const long long m0 = chunk * MC;
-        constexpr int PPP = MC / 16;                // 1 KiB pieces per panel
-        constexpr int PIECES = (GP + XP) * PPP;
-        for (int pc = wave; pc < PIECES; pc += 4) {
-            const int panel = pc / PPP, part = pc % PPP;
-            const float* src = (panel < GP)
-                                   ? g + ((long long)(n0 / 16 + panel) * m_padded + m0 + part * 16) * 16
-                                   : x + ((long long)(k0 / 16 + panel - GP) * m_padded + m0 + part * 16) * 16;
-            glds16b(src + lane * 4, base + panel * PSTR + part * 256);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (wave + 4 * q < PIECES) glds16b(srcq[q], base + dstq[q]);
+            srcq[q] += MC * 16;
         }
     };
     float bsum[NI];                                 // bias gradient rides along: sum_m G[m][n] for this lane's features
 #pragma unroll
     for (int i = 0; i < NI; ++i) bsum[i] = 0.f;
 
+    // Operand fragments.  An fp32 MFMA operand is ONE value per lane and the contraction index here is the point, so which
+    // FEATURE a lane's row stands for is free: lane li of feature block i takes feature NI * li + i (and NJ * li + j on the X
+    // side).  The NI (NJ) values a lane needs for one point are then CONTIGUOUS in the panel row — one ds_read_b64 / b128 per
+    // operand and point instead of NI + NJ scalar reads (the scalar form spent ~20 address VALU ops per 8 MFMAs, and VALU time
+    // adds to MFMA time on this chip: DESIGN.md 3.1).  The accumulation order over the points is unchanged: results are
+    // bit-identical to the scalar-read kernel.
+    typedef float fvecA __attribute__((ext_vector_type(NI)));
+    typedef float fvecB __attribute__((ext_vector_type(NJ)));
     const int li = lane & 31, gsel = lane >> 5;
+    const int nl0 = wn * (TN / 2) + NI * li, kl0 = wk * (TK / 2) + NJ * li;      // first feature of this lane's fragment
+    // LDS float offsets of this lane's fragment for point `gsel` of a chunk, one per value of the row swizzle ((point >> 2) & 3 —
+    // a compile-time constant per unrolled point pair): every read below is base[sw] + an IMMEDIATE, so the K loop carries no
+    // address arithmetic (the buffer is a template constant too: the chunk loop is unrolled by two).
+    int a_base[4], b_base[4];
+#pragma unroll
+    for (int sw = 0; sw < 4; ++sw) {
+        a_base[sw] = (nl0 >> 4) * PSTR + (nl0 & 3) + gsel * 16 + ((((nl0 >> 2) & 3) ^ sw) << 2);
+        b_base[sw] = GP * PSTR + (kl0 >> 4) * PSTR + (kl0 & 3) + gsel * 16 + ((((kl0 >> 2) & 3) ^ sw) << 2);
+    }
+    const bool want_bias = bias_partial && kt == 0 && wk == 0;     // wave-uniform: only these waves carry the bias sums
+    // One loop body (two instantiations made hipcc keep the accumulators in two register sets and spill).  Rows beyond the
+    // batch (only the launch's last chunk can have them) are zeroed IN LDS before the chunk is consumed, so the loop never masks;
+    // the bias sums sit behind a wave-uniform scalar branch.
+    auto compute = [&](int cur) {
+        const float* base = smem + cur * STAGE;                       // 8 VALU adds per chunk fold this into the fragment addresses
+        auto load = [&](int mp, float (&a)[NI], float (&b)[NJ]) {
+            const int sw = (mp >> 1) & 3;                             // ((2 mp + gsel) >> 2) & 3: m0 is a multiple of 16
+            if constexpr (NI == 1) a[0] = base[a_base[sw] + mp * 32];
+            else {
+                const fvecA v = *(const fvecA*)(base + a_base[sw] + mp * 32);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) a[i] = v[i];
+            }
+            if constexpr (NJ == 1) b[0] = base[b_base[sw] + mp * 32];
+            else {
+                const fvecB v = *(const fvecB*)(base + b_base[sw] + mp * 32);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[j] = v[j];
+            }
+        };
+        // fragments of point pair mp + 1 are fetched while the MFMAs of pair mp issue; the scheduling barrier keeps hipcc from
+        // hoisting all MC/2 fetches to the top of the chunk
+        float a[2][NI], b[2][NJ];
+        load(0, a[0], b[0]);
+#pragma unroll
+        for (int mp = 0; mp < MC / 2; ++mp) {
+            const int cb = mp & 1;
+            if (mp + 1 < MC / 2) load(mp + 1, a[cb ^ 1], b[cb ^ 1]);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cb][i], b[cb][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (want_bias) {   // wave-uniform: the one column of waves that owns the bias sums re-reads its G fragments (LDS, 8 reads)
+#pragma unroll
+            for (int mp = 0; mp < MC / 2; ++mp) {
+                const int sw = (mp >> 1) & 3;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) bsum[i] += base[a_base[sw] + mp * 32 + i];
+            }
+        }
+    };
     if (c_begin < c_end) {
-        stage(0, c_begin);
+        stage(0);
         __syncthreads();
         for (long long c = c_begin; c < c_end; ++c) {
             const int cur = (int)((c - c_begin) & 1);
-            if (c + 1 < c_end) stage(cur ^ 1, c + 1);
-            const float* gs = smem + cur * STAGE;
-            const float* xs = gs + GP * PSTR;
+            if (c + 1 < c_end) stage(cur ^ 1);
             const long long m0 = c * MC;
-#pragma unroll 4
-            for (int mp = 0; mp < MC / 2; ++mp) {
-                const int ml = 2 * mp + gsel;                         // this lane's point within the chunk
-                const bool live = (m0 + ml) < n_points;               // rows beyond the batch contribute nothing
-                const int sw = (ml >> 2) & 3;                         // m0 is a multiple of 16: same swizzle as global
-                float a[NI], b[NJ];
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int nl = wn * (TN / 2) + 32 * i + li;       // feature within the tile
-                    const float v = gs[(nl >> 4) * PSTR + ml * 16 + ((((nl >> 2) & 3) ^ sw) << 2) + (nl & 3)];
-                    a[i] = live ? v : 0.f;
-                    bsum[i] += a[i];
+            if (m0 + MC > n_points) {  // the batch ends inside this chunk (block-uniform, at most once per launch): zero the dead G rows
+                float* gsm = smem + cur * STAGE;
+                for (int t = tid; t < GP * MC * 16; t += 256) {
+                    const int panel = t / (MC * 16), rem = t - panel * (MC * 16);
+                    if (m0 + (rem >> 4) >= n_points) gsm[panel * PSTR + rem] = 0.f;
                 }
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int kl = wk * (TK / 2) + 32 * j + li;
-                    b[j] = xs[(kl >> 4) * PSTR + ml * 16 + ((((kl >> 2) & 3) ^ sw) << 2) + (kl & 3)];
-                }
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                __syncthreads();
             }
+            compute(cur);
             __syncthreads();
         }
     }
-    if (bias_partial && kt == 0 && wk == 0) {       // one column of workgroups owns the bias partials [split][n_padded]
+    if (want_bias) {       // one column of workgroups owns the bias partials [split][n_padded]
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);      // even + odd points
-            if (lane < 32) bias_partial[(long long)split * n_padded + n0 + wn * (TN / 2) + 32 * i + li] = tot;
+            if (lane < 32) bias_partial[(long long)split * n_padded + n0 + wn * (TN / 2) + NI * li + i] = tot;
         }
     }
-    // partial[split][n][k], row-major [n_padded][k_padded]
+    // partial[split][n][k], row-major [n_padded][k_padded]; accumulator row rr <-> feature NI * rr + i, column li <-> inputs
+    // NJ * li .. + NJ - 1: one NJ-wide store per (feature, lane) — 32 lanes cover NJ * 128 contiguous bytes
     float* out = partial + (long long)split * n_padded * k_padded;
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * gsel;
+            const int n = n0 + wn * (TN / 2) + NI * rr + i;
+            const int k = k0 + wk * (TK / 2) + NJ * li;
+            float* dst = out + (long long)n * k_padded + k;
+            if constexpr (NJ == 1) dst[0] = acc[i][0][r];
+            else {
+                fvecB v;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wn * (TN / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * gsel;
-                const int k = k0 + wk * (TK / 2) + 32 * j + li;
-                out[(long long)n * k_padded + k] = acc[i][j][r];
+                for (int j = 0; j < NJ; ++j) v[j] = acc[i][j][r];
+                *(fvecB*)dst = v;
             }
+        }
 }
 
 // dst[n][col0 + k] = sum_s partial[s][n][k]   for n < n_out, k < ncols  (natural PyTorch [out, in] gradient layout)

@@ -104,5 +104,5 @@ def test_pose_gradient_vs_reference_fixture(golden):
     torch.cuda.synchronize()
     a = c2w.grad.cpu().numpy().ravel().astype(np.float64)
     cos = float(a @ ref.ravel() / (np.linalg.norm(a) * np.linalg.norm(ref) + 1e-30))
-    print(f"pose gradient: teacher-forced rel err {err:.1e}; end-to-end cosine {cos:.5f}, loss {float(loss):.6f} vs {float(g['loss']):.6f}")
-    assert cos > 0.99 and abs(float(loss) - float(g["loss"])) < 1e-4
+    print(f"pose gradient: teacher-forced rel err {err:.1e}; end-to-end cosine {cos:.5f}, loss {float(loss.detach()):.6f} vs {float(g['loss']):.6f}")
+    assert cos > 0.99 and abs(float(loss.detach()) - float(g["loss"])) < 1e-4
