@@ -78,9 +78,25 @@ class NeRF(nn.Module):
             out += blk.linears1.layers() + blk.linears2.layers()
         return out + [self.linear_view_xyBMuv[0], self.alpha_linear[0], self.rgb_linear]
 
-    def forward(self, *a, **k):
-        raise RuntimeError("NeRF parameters are evaluated by the fused HIP path (positional encoding happens inside "
-                           "the kernel): call Renderer.run_network / render / render_fitting instead of the module")
+    def forward(self, input_pts, input_bmCodes, input_views, input_uvCodes):
+        """The reference module's own call form (models/model.py:121-137): per-point ALREADY-EMBEDDED inputs
+        ``[n,93] [n,50] [n,27] [n,256] -> [n,4]`` (rgb pre-sigmoid, sigma pre-ReLU) — what the reference's eager ``batchify``
+        hands to the network.  Runs on the same MFMA layer kernel without the constant folding (HipNet.forward_embedded).
+        Inference only: the renderer's own path (``run_network`` / ``render`` / ``render_fitting``) is the one with a HIP backward,
+        so a call that would need gradients here fails loudly instead of silently detaching."""
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
+                                        any(torch.is_tensor(t) and t.requires_grad for t in (input_pts, input_bmCodes, input_views, input_uvCodes))):
+            raise RuntimeError("NeRF.forward on embedded inputs is inference-only on the HIP path (call it under torch.no_grad()); "
+                               "gradients flow through Renderer.run_network / render / render_fitting")
+        from . import lib
+        from .hipnet import HipNet
+        if not (torch.is_tensor(input_pts) and input_pts.is_cuda and next(self.parameters()).is_cuda):
+            raise lib.MofaError("NeRF.forward needs its parameters and inputs on the GPU (net.cuda()); there is no CPU path")
+        h = getattr(self, "_hip_embedded", None)
+        if h is None:
+            h = HipNet(self)
+            object.__setattr__(self, "_hip_embedded", h)             # not a submodule / parameter: a device-side cache
+        return h.forward_embedded(input_pts, input_bmCodes, input_views, input_uvCodes)
 
 
 class StyleModule(nn.Module):

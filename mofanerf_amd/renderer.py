@@ -188,8 +188,21 @@ class Renderer(torch.nn.Module):
         return raw
 
     def batchify(self, fn, chunk):
-        raise RuntimeError("batchify(fn, netchunk) is internal to the reference's eager path; the HIP path "
-                           "sub-batches points inside run_network / render_rays")
+        """The reference's eager helper (models/render_class.py:96-109): a version of ``fn`` applied to ``chunk``-sized slices of
+        already-embedded inputs ``[embedded93, shapeCodes, embedded_dirs]`` (+ the expanded texture code).  ``fn`` is a ``NeRF``
+        (its ``forward`` runs the HIP layer kernels on embedded inputs).  The renderer itself does not use it — ``run_network``
+        fuses embedding, code folding and sub-batching — it exists so that code written against the reference keeps working."""
+        fn = unwrap(fn)
+        if chunk is None:
+            return fn
+
+        def ret(inputs):
+            v1, v2, v3 = inputs
+            t = self.decoding_texCodes.reshape(1, -1).expand(v1.shape[0], -1)
+            return torch.cat([fn(v1[i:i + chunk], v2[i:i + chunk], v3[i:i + chunk], t[i:i + chunk])
+                              for i in range(0, v1.shape[0], chunk)], 0)
+
+        return ret
 
     def batchify_rays(self, chunk=1024 * 32, **kwargs):
         """Render ``self.rays`` in chunks of ``chunk`` rays (render_class.py:111-123)."""

@@ -198,8 +198,9 @@ def test_unsupported_flags_fail_loudly():
     with pytest.raises(NotImplementedError, match="alpha_linear"), torch.no_grad():
         render.render_fitting(8, 8, K, chunk=64, rays=rays, shapeCodes=bm, uvCodes=tex, expType=20, expCodes=exp,
                               **dict(kw, use_viewdirs=False))
-    with pytest.raises(RuntimeError):
-        kw["network_fn"](torch.zeros(1, 93, device=DEV), None, None, None)
+    with pytest.raises(RuntimeError, match="inference-only"):      # NeRF.forward (embedded inputs) refuses to drop gradients silently
+        kw["network_fn"](torch.zeros(1, 93, device=DEV), torch.zeros(1, 50, device=DEV), torch.zeros(1, 27, device=DEV),
+                         torch.zeros(1, 256, device=DEV))
     with pytest.raises(lib.MofaError):
         lib.check(lib.load().mofa_composite_forward(1, 1, 0, 1, None, 4, 300, 0, 1, 1, 1, 1, 1, None), "composite S=300")
 

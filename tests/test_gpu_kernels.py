@@ -215,16 +215,27 @@ def test_head_and_view_bias():
 
 @pytest.mark.parametrize("D,W", [(8, 64), (10, 64), (8, 96)])
 def test_net_forward_golden(golden, D, W):
-    """mofa_net_pack + mofa_net_fold + mofa_net_forward == reference NeRF.forward on the KAT inputs (points given
-    as already-embedded features in the fixture, so this test rebuilds them from explicit points instead)."""
+    """`NeRF.forward(input_pts, input_bmCodes, input_views, input_uvCodes)` (models/model.py:121-137) in the reference module's OWN
+    call form — per-point, already-embedded inputs — against the reference's outputs `nerf{D}x{W}_out` of the KAT fixture, and the
+    fused path (`mofa_net_pack` + `mofa_net_fold` + `mofa_net_forward` from explicit points) against the oracle."""
     from mofanerf_amd.hipnet import HipNet
     from mofanerf_amd.model import NeRF
+    g = golden("kat.npz")
     rng = np.random.default_rng(D * W)
     net = NeRF(D=D, W=W, input_ch=93, input_ch_views=27, input_ch_textureCodes=256, input_ch_shapeCodes=50,
                use_viewdirs=True)
     st = synth.nerf_state(D, W)
     net.load_state_dict(st)
     net = net.to(DEV)
+    t = f"nerf{D}x{W}"
+    n = g[t + "_pts"].shape[0]
+    with torch.no_grad():
+        out = net(dev(g[t + "_pts"]), dev(g[t + "_bm"]).expand(n, -1), dev(g[t + "_views"]), dev(g[t + "_tex"]).expand(n, -1))
+    torch.cuda.synchronize()
+    err = nan_equal_close(out.cpu().numpy(), g[t + "_out"], 2e-5, 1e-5)
+    print(t, f"NeRF.forward on embedded inputs vs the reference: {err:.2e}")
+    with pytest.raises(RuntimeError):                # gradients through this entry are refused, not silently dropped
+        net(dev(g[t + "_pts"]), dev(g[t + "_bm"]).expand(n, -1), dev(g[t + "_views"]), dev(g[t + "_tex"]).expand(n, -1))
     R, S = 23, 64
     pts = T(rng.uniform(-9, 9, (R, S, 3)).astype(np.float32))
     vd = torch.nn.functional.normalize(T(rng.normal(size=(R, 3)).astype(np.float32)), dim=-1)
@@ -240,6 +251,48 @@ def test_net_forward_golden(golden, D, W):
     v27 = orc.positional_encode(vd[:, None].expand(R, S, 3).reshape(-1, 3), 4)
     ref = orc.nerf_forward(st, x93, bm.expand(n, -1), v27, tex[None].expand(n, -1)).reshape(R, S, 4)
     nan_equal_close(raw.cpu().numpy(), ref.numpy(), 2e-5, 1e-5)
+    # the nominal (unfolded, embedded-input) entry and the fused entry agree with each other on the same points
+    with torch.no_grad():
+        emb = net(dev(x93), dev(bm).expand(n, -1), dev(v27), dev(tex[None]).expand(n, -1)).reshape(R, S, 4)
+    nan_equal_close(emb.cpu().numpy(), raw.cpu().numpy(), 2e-5, 1e-5)
+
+
+def test_reference_eager_run_network_body_runs_on_these_classes(golden):
+    """The body of the reference's eager `run_network` (models/render_class.py:69-94: embed, expand the codes, `batchify(fn, netchunk)`)
+    written against THESE classes — `get_embedder`, `Renderer.batchify`, `NeRF.forward` — reproduces the reference's KAT output and
+    the fused `run_network`."""
+    from mofanerf_amd.embedder import get_embedder
+    from mofanerf_amd.model import NeRF
+    from mofanerf_amd.renderer import Renderer
+    g = golden("kat_run_network.npz")
+    D, W = 10, 64
+    t = f"rn{D}x{W}"
+    _, _, netchunk, wseed, exp_type = [int(v) for v in g[t + "_meta"]]
+    embed_fn, _ = get_embedder(10, 0)
+    embeddirs_fn, _ = get_embedder(4, 0)
+    render = Renderer(embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=netchunk, expCodesLen=30)
+    render.idSpecificMod.load_state_dict(synth.style_state(0))
+    for dst, src in zip(render.expCodes_Sigma, synth.exp_sigma(0)):
+        dst.data[:] = src
+    render = render.to(DEV).eval()
+    net = NeRF(D=D, W=W, input_ch=93, input_ch_views=27, input_ch_textureCodes=256, input_ch_shapeCodes=50, use_viewdirs=True)
+    net.load_state_dict(synth.nerf_state(D, W, wseed, "kat"))
+    net = net.to(DEV)
+    inputs, viewdirs = dev(g[t + "_pts"]), dev(g[t + "_vd"])
+    render.shapeCodes, render.expType, render.decoding_texCodes = dev(g[t + "_bm"]), exp_type, dev(g[t + "_tex"])
+    with torch.no_grad():
+        inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+        shapeCodes = render.shapeCodes[0, :].expand([inputs_flat.shape[0], render.shapeCodes.shape[-1]])
+        exp_scale, exp_bias = render.idSpecificMod(render.shapeCodes[0, :].reshape(1, -1))
+        embedded = render.embed_fn(inputs_flat)
+        code = (exp_scale * render.expCodes_Sigma[render.expType] + exp_bias).expand([inputs_flat.shape[0], -1])
+        embedded = [torch.cat([embedded, code], -1), shapeCodes]
+        input_dirs_flat = torch.reshape(viewdirs[:, None].expand(inputs.shape), [-1, 3])
+        embedded.append(render.embeddirs_fn(input_dirs_flat))
+        outputs = torch.reshape(render.batchify(net, render.netchunk)(embedded), list(inputs.shape[:-1]) + [4])
+        fused = render.run_network(inputs, viewdirs, net)
+    nan_equal_close(outputs.cpu().numpy(), g[t + "_raw"], 2e-5, 1e-5)
+    nan_equal_close(outputs.cpu().numpy(), fused.cpu().numpy(), 2e-5, 1e-5)
 
 
 def test_get_rays_golden(golden):

@@ -93,8 +93,13 @@ def test_unsupported_configurations_raise():
         NeRF(D=8, W=64, input_ch=93, input_ch_views=27, use_viewdirs=False)
     with pytest.raises(NotImplementedError):
         NeRF(D=8, W=64, input_ch=93, input_ch_views=27, skips=(3,), use_viewdirs=True)
-    with pytest.raises(RuntimeError):
-        NeRF(D=8, W=64, input_ch=93, input_ch_views=27, use_viewdirs=True)(torch.zeros(1, 93))
+    net = NeRF(D=8, W=64, input_ch=93, input_ch_views=27, input_ch_shapeCodes=50, input_ch_textureCodes=256, use_viewdirs=True)
+    z = [torch.zeros(1, k) for k in (93, 50, 27, 256)]
+    with pytest.raises(RuntimeError, match="inference-only"):          # no silent detach when gradients would be needed
+        net(*z)
+    from mofanerf_amd import lib
+    with pytest.raises(lib.MofaError), torch.no_grad():                 # and no CPU path: CPU parameters fail loudly
+        net(*z)
 
 
 def test_mac_counts_match_survey():
