@@ -268,15 +268,18 @@ __global__ __launch_bounds__(256) void k_composite_backward(
 }
 
 // ---- head bias gradient: out[c] = sum_m d_raw[m][off + c]  (single block; 4 floats per point) ------------------
-__global__ __launch_bounds__(256) void k_raw_colsum(const float* __restrict__ d_raw, long long n_points, int off, int n,
-                                                    float* __restrict__ out) {
-    __shared__ float red[256][4];
+__global__ __launch_bounds__(1024) void k_raw_colsum(const float* __restrict__ d_raw, long long n_points, int off, int n,
+                                                     float* __restrict__ out) {
+    __shared__ float red[1024][4];
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (long long m = threadIdx.x; m < n_points; m += 256)
-        for (int c = 0; c < n; ++c) acc[c] += d_raw[m * 4 + off + c];
+    for (long long m = threadIdx.x; m < n_points; m += 1024) {      // one 16-byte load per point: the 4 raw columns
+        const f32x4 v = *(const f32x4*)(d_raw + m * 4);
+        const float r[4] = {v.x, v.y, v.z, v.w};
+        for (int c = 0; c < n; ++c) acc[c] += r[off + c];
+    }
     for (int c = 0; c < 4; ++c) red[threadIdx.x][c] = acc[c];
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = 512; s > 0; s >>= 1) {
         if (threadIdx.x < s)
             for (int c = 0; c < 4; ++c) red[threadIdx.x][c] += red[threadIdx.x + s][c];
         __syncthreads();
@@ -306,7 +309,7 @@ int mofa_head_backward(const float* d_raw, int32_t raw_off, int32_t n_out, const
 }
 
 int mofa_internal_raw_colsum(const float* d_raw, long long n_points, int off, int n, float* out, void* stream) {
-    hipLaunchKernelGGL(k_raw_colsum, dim3(1), dim3(256), 0, (hipStream_t)stream, d_raw, n_points, off, n, out);
+    hipLaunchKernelGGL(k_raw_colsum, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_raw, n_points, off, n, out);
     return check_launch("k_raw_colsum");
 }
 
@@ -554,32 +557,52 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)n_out * ncols) return;
     const int n = (int)(idx / ncols), k = (int)(idx - (long long)n * ncols);
+    const float* p = partial + (long long)n * k_padded + k;
+    const long long stride = (long long)n_padded * k_padded;
     float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += partial[((long long)sp * n_padded + n) * k_padded + k];
+    int sp = 0;
+    for (; sp + 8 <= splits; sp += 8) {      // 8 independent loads in flight, summed in the fixed split order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(long long)(sp + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; sp < splits; ++sp) s += p[(long long)sp * stride];
     dst[(long long)n * ld + col0 + k] = s;
 }
 
+// out[n] = sum_s partial[s][n]: 64 columns per block, the splits dealt round-robin to 4 thread groups, combined through LDS in a
+// fixed order (deterministic) — a single thread walking all the splits of its column was a 60 us latency chain
 __global__ __launch_bounds__(256) void k_bias_reduce(const float* __restrict__ partial, int splits, int n_padded,
                                                      float* __restrict__ out) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= n_padded) return;
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += partial[(long long)sp * n_padded + n];
-    out[n] = s;
+    if (col < n_padded)
+        for (int sp = grp; sp < splits; sp += 4) s += partial[(long long)sp * n_padded + col];
+    red[grp][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (grp == 0 && col < n_padded) out[col] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
-// head weight gradient: dst[o][k] = sum_m d_raw[m][off+o] * X[m][k]; one block per 16-feature panel of X
+// head weight gradient: dst[o][k] = sum_m d_raw[m][off+o] * X[m][k]; blockIdx.x = 16-feature panel of X, blockIdx.y = slice of the
+// points.  gridDim.y == 1: results go straight to dst; otherwise to partial[slice][o][k_padded] and k_head_wgrad_reduce sums the
+// slices in order (deterministic).
 __global__ __launch_bounds__(256) void k_head_wgrad(const float* __restrict__ d_raw, int raw_off, int n_out,
                                                     const float* __restrict__ x, long long m_padded,
-                                                    long long n_points, int ncols, float* __restrict__ dst, int ld) {
+                                                    long long n_points, int ncols, float* __restrict__ dst, int ld,
+                                                    float* __restrict__ partial, int k_padded) {
     __shared__ float red[256][17];
     const int panel = blockIdx.x;
     const float* base = x + (long long)panel * m_padded * 16;
+    const long long per = ((n_points + gridDim.y - 1) / gridDim.y + 255) / 256 * 256;
+    const long long m_lo = (long long)blockIdx.y * per, m_hi = (m_lo + per < n_points) ? m_lo + per : n_points;
     for (int o = 0; o < n_out; ++o) {
         float acc[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) acc[c] = 0.f;
-        for (long long m = threadIdx.x; m < n_points; m += 256) {
+        for (long long m = m_lo + threadIdx.x; m < m_hi; m += 256) {
             const float gw = d_raw[m * 4 + raw_off + o];
             const int sw = (int)(m >> 2) & 3;
             const f32x4* row = (const f32x4*)(base + m * 16);
@@ -599,9 +622,21 @@ __global__ __launch_bounds__(256) void k_head_wgrad(const float* __restrict__ d_
                 for (int c = 0; c < 16; ++c) red[threadIdx.x][c] += red[threadIdx.x + s][c];
             __syncthreads();
         }
-        if (threadIdx.x < 16 && panel * 16 + (int)threadIdx.x < ncols)
-            dst[(long long)o * ld + panel * 16 + threadIdx.x] = red[0][threadIdx.x];
+        if (threadIdx.x < 16) {
+            if (partial) partial[((long long)blockIdx.y * n_out + o) * k_padded + panel * 16 + threadIdx.x] = red[0][threadIdx.x];
+            else if (panel * 16 + (int)threadIdx.x < ncols) dst[(long long)o * ld + panel * 16 + threadIdx.x] = red[0][threadIdx.x];
+        }
     }
+}
+
+__global__ __launch_bounds__(256) void k_head_wgrad_reduce(const float* __restrict__ partial, int slices, int n_out, int k_padded,
+                                                           int ncols, float* __restrict__ dst, int ld) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_out * ncols) return;
+    const int o = idx / ncols, k = idx - o * ncols;
+    float s = 0.f;
+    for (int sl = 0; sl < slices; ++sl) s += partial[((long long)sl * n_out + o) * k_padded + k];
+    dst[(long long)o * ld + k] = s;
 }
 
 // positional-encoding features of every point as panels [4][m_padded][16] (the X operand of layer 0's weight gradient)
@@ -704,7 +739,7 @@ int mofa_weight_grad(const float* g, int32_t n_padded, const float* x, int32_t k
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace, p.splits,
                        n_padded, k_padded, n_out, ncols, dst, ld, col0);
     if (bias_out)
-        hipLaunchKernelGGL(k_bias_reduce, dim3((unsigned)((n_padded + 255) / 256)), dim3(256), 0, st, bias_partial, p.splits,
+        hipLaunchKernelGGL(k_bias_reduce, dim3((unsigned)((n_padded + 63) / 64)), dim3(256), 0, st, bias_partial, p.splits,
                            n_padded, bias_out);
     return check_launch("k_wgrad_reduce");
 }
@@ -714,8 +749,24 @@ int mofa_head_weight_grad(const float* d_raw, int32_t raw_off, int32_t n_out, co
     MOFA_REQUIRE(d_raw && x && dst && k_padded % 16 == 0 && ncols <= k_padded && n_out >= 1 && raw_off + n_out <= 4,
                  "head_weight_grad: bad arguments");
     hipLaunchKernelGGL(k_head_wgrad, dim3(k_padded / 16), dim3(256), 0, (hipStream_t)stream, d_raw, raw_off, n_out, x,
-                       (long long)m_padded, (long long)n_points, ncols, dst, ld);
+                       (long long)m_padded, (long long)n_points, ncols, dst, ld, (float*)nullptr, k_padded);
     return check_launch("k_head_wgrad");
+}
+
+/* internal (mofa_net_backward): the same with the points split over `slices` workgroup rows; `workspace` holds
+ * slices * n_out * k_padded floats of partials (the weight-gradient scratch is free at that point) */
+int mofa_internal_head_weight_grad_split(const float* d_raw, int32_t raw_off, int32_t n_out, const float* x, int32_t k_padded,
+                                         int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, float* workspace,
+                                         void* stream) {
+    int slices = (int)((n_points + 16383) / 16384);          // >= 16 k points per slice; ~1000 workgroups at training sizes
+    if (slices > 16) slices = 16;
+    if (slices <= 1 || !workspace)
+        return mofa_head_weight_grad(d_raw, raw_off, n_out, x, k_padded, m_padded, n_points, ncols, dst, ld, stream);
+    hipLaunchKernelGGL(k_head_wgrad, dim3(k_padded / 16, slices), dim3(256), 0, (hipStream_t)stream, d_raw, raw_off, n_out, x,
+                       (long long)m_padded, (long long)n_points, ncols, dst, ld, workspace, k_padded);
+    hipLaunchKernelGGL(k_head_wgrad_reduce, dim3((unsigned)((n_out * ncols + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace,
+                       slices, n_out, k_padded, ncols, dst, ld);
+    return check_launch("k_head_wgrad(split)");
 }
 
 int mofa_pe_panels(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride, int64_t n_points,

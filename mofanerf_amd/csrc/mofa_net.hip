@@ -55,6 +55,9 @@ int mofa_head_weight_grad(const float* d_raw, int32_t raw_off, int32_t n_out, co
                           int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, void* stream);
 int mofa_pe_panels(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride, int64_t n_points,
                    int32_t S, int64_t m_padded, float* out, void* stream);
+int mofa_internal_head_weight_grad_split(const float* d_raw, int32_t raw_off, int32_t n_out, const float* x, int32_t k_padded,
+                                         int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, float* workspace,
+                                         void* stream);
 }
 
 namespace mofa {
@@ -543,10 +546,11 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
         MOFA_TRY(mofa_bias_grad_rays(g0, Mp, n_rays, S, p.L[p.view].n_padded, d_view_bias_rows, stream));
         if (d_weights) {
             MOFA_REQUIRE(d_weights[p.rgb] && d_weights[p.alpha], "net_backward: head d_weights are null");
-            MOFA_TRY(mofa_head_weight_grad(d_raw, 0, 3, T(p.view), r.k_padded[0], Mp, M, r.ld, d_weights[p.rgb], r.ld, stream));
+            MOFA_TRY(mofa_internal_head_weight_grad_split(d_raw, 0, 3, T(p.view), r.k_padded[0], Mp, M, r.ld, d_weights[p.rgb], r.ld, wws,
+                                                          stream));
             const Layer& a = p.L[p.alpha];
-            MOFA_TRY(mofa_head_weight_grad(d_raw, 3, 1, T(p.bim_skip + n2 - 1), a.k_padded[0], Mp, M, a.ld, d_weights[p.alpha],
-                                           a.ld, stream));
+            MOFA_TRY(mofa_internal_head_weight_grad_split(d_raw, 3, 1, T(p.bim_skip + n2 - 1), a.k_padded[0], Mp, M, a.ld,
+                                                          d_weights[p.alpha], a.ld, wws, stream));
         }
         MOFA_TRY(wgrad(p.view, 0, g0, T(p.uv_skip + n2 - 1)));
     }
