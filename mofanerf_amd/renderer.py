@@ -231,7 +231,7 @@ class Renderer(torch.nn.Module):
         st = lib.stream()
         # near / far: the scalar fast path when render()/render_fitting() set them for THIS self.rays; otherwise (per-ray
         # bounds, or batchify_rays()/render_rays() called directly on a caller-built self.rays) they are read from columns 6:8
-        scalar_bounds = getattr(self, "_rays_id", None) == id(self.rays) and self._near is not None
+        scalar_bounds = getattr(self, "_rays_ref", None) is self.rays and self._near is not None
         t_row = self._const_row(("t", S), lambda: torch.linspace(0., 1., steps=S), dev)
         if scalar_bounds:
             near, far = self._near, self._far
@@ -316,7 +316,7 @@ class Renderer(torch.nn.Module):
                 main.wait_stream(s_)
             return raw
 
-        if getattr(self, "_rays_id", None) != id(self.rays):
+        if getattr(self, "_rays_ref", None) is not self.rays:
             # called directly on a caller-built self.rays (the reference documents batchify_rays / render_rays as callable once
             # self.rays, shapeCodes, expType and decoding_texCodes are set): fold the per-call codes here
             self._folded_coarse = self._fold_codes(network_fn, self.decoding_texCodes).clone()
@@ -405,7 +405,7 @@ class Renderer(torch.nn.Module):
         if self._near is None or self._far is None:
             self._near = self._far = None
         self.rays = torch.cat([rays_o, rays_d, ncol, fcol, viewdirs], -1)
-        self._rays_id = id(self.rays)
+        self._rays_ref = self.rays          # (a reference, not an id: ids are reused after garbage collection)
         self.decoding_texCodes = tex_code
         # inference (torch.no_grad(), as the reference's render-only call sites run): pure HIP, nothing recorded;
         # with autograd enabled (fitting / training) the tape-keeping forward + HIP backward path is used
