@@ -102,6 +102,9 @@ __device__ __forceinline__ float pe_feature(int k, float x0, float x1, float x2,
     return r < 3 ? sinf(arg) : cosf(arg);
 }
 
+#ifndef MOFA_SETPRIO
+#define MOFA_SETPRIO 0
+#endif
 template <int NI, int NJ>
 __device__ __forceinline__ void mma_panel(const float* __restrict__ Xt, const float* __restrict__ Wt, int xrow0,
                                           int wrow0, int lane, f32x16 (&acc)[NI][NJ]) {
@@ -114,6 +117,9 @@ __device__ __forceinline__ void mma_panel(const float* __restrict__ Xt, const fl
         for (int i = 0; i < NI; ++i) a[i] = *(const f32x4*)(Wt + (wrow0 + 32 * i + lr) * 16 + p);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) b[j] = *(const f32x4*)(Xt + (xrow0 + 32 * j + lr) * 16 + p);
+#if MOFA_SETPRIO   // A/B arm (tools/ab_layer.py): raise the wave's issue priority while its MFMA block issues
+        __builtin_amdgcn_s_setprio(MOFA_SETPRIO);
+#endif
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -121,6 +127,9 @@ __device__ __forceinline__ void mma_panel(const float* __restrict__ Xt, const fl
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+#if MOFA_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
 }
 

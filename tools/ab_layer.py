@@ -1,9 +1,17 @@
 #!/usr/bin/env python3
-"""Interleaved A/B of layer-kernel variants (separate processes per variant, several rounds)."""
+"""Interleaved A/B of layer-kernel variants (separate processes per variant, several rounds).
+    python tools/ab_layer.py                      # the round-1 set
+    python tools/ab_layer.py name=path/to/lib.so  # base vs the named alternative builds (MOFA_LIB)
+Alternative builds: MOFA_SETPRIO=1 MOFA_LIB_OUT=build_arms/prio1.so python -m mofanerf_amd.build --force"""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-variants = {"base(2 WG/CU)": {}, "waves3(spills)": {"MOFA_LIB": os.path.join(root, "mofanerf_amd", "libmofanerf_hip_w3.so")},
-            "BN64(4 WG/CU)": {"MOFA_BN64": "1"}}
+variants = {"base(2 WG/CU)": {}}
+if len(sys.argv) > 1:
+    for a in sys.argv[1:]:
+        name, path = a.split("=", 1)
+        variants[name] = {"MOFA_LIB": os.path.join(root, path)}
+else:
+    variants.update({"waves3(spills)": {"MOFA_LIB": os.path.join(root, "mofanerf_amd", "libmofanerf_hip_w3.so")}, "BN64(4 WG/CU)": {"MOFA_BN64": "1"}})
 code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tools'); import microbench_layer as m; "
         "print(' '.join(f'{m.run(*c, iters=20)[1]:.1f}' for c in [(196608,1024,1024,0),(196608,256,256,0),(32768,1024,1024,0)]))" % (root, root))
 for rnd in range(3):
