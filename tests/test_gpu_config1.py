@@ -295,3 +295,40 @@ def test_per_ray_near_far_and_direct_batchify_rays():
         with torch.no_grad():
             render.render_fitting(8, 8, None, chunk=64, rays=rays, shapeCodes=bm, uvCodes=tex, expType=20, expCodes=exp,
                                   **dict(kw, N_samples=200, N_importance=100))
+
+
+def test_texture_code_cache_semantics():
+    """(f1) The per-UV-map cache of the texture code on render-only calls (bulk rendering shows one UV map for every expression /
+    view of an identity, render_refine_trainSet.py:288-289): a cached call returns bit-identical images without running the
+    encoder, an in-place change of the map (version bump) or of an encoder weight recomputes, a `.data` edit needs
+    `invalidate_caches()`, and with autograd enabled the encoder always runs (training)."""
+    render, kw, kw_train = make_product((8, 64, 10, 64), 0, 4096, DEV, with_tex=True)
+    bm = synth.codes(0)[0].to(DEV)
+    uv = T(np.random.default_rng(5).uniform(0, 1, (512, 512, 3)).astype(np.float32)).to(DEV)
+    K = synth.intrinsics(8, 8)
+    c2w = orc.pose_spherical(5.0, 0.0, 16.0)[:3, :4]
+    calls = []
+    enc = render.texEncoder
+    orig = enc.forward
+    enc.forward = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    run = lambda: render.render(8, 8, K, chunk=64, c2w=c2w, shapeCodes=bm, uvMap=uv, expType=3, **kw)[0].clone()
+    with torch.no_grad():
+        a = run()
+        b = run()
+        assert torch.equal(a, b) and len(calls) == 1                       # second call served from the cache
+        uv.mul_(0.5)                                                       # in-place edit: version bump -> recomputed
+        c = run()
+        assert len(calls) == 2 and not torch.equal(a, c)
+        enc.encoder.mu.weight.mul_(1.01)                                   # encoder weight changed -> recomputed
+        d = run()
+        assert len(calls) == 3 and not torch.equal(c, d)
+        enc.encoder.mu.weight.data.mul_(1.01)                              # through .data: invisible ...
+        e = run()
+        assert len(calls) == 3 and torch.equal(d, e)
+        render.invalidate_caches()                                         # ... until the caches are dropped
+        f = run()
+        assert len(calls) == 4 and not torch.equal(e, f)
+    rgb = render.render(8, 8, K, chunk=64, c2w=c2w, shapeCodes=bm, uvMap=uv, expType=3, **dict(kw_train, perturb=0.0))[0]
+    rgb2 = render.render(8, 8, K, chunk=64, c2w=c2w, shapeCodes=bm, uvMap=uv, expType=3, **dict(kw_train, perturb=0.0))[0]
+    assert len(calls) == 6 and rgb.requires_grad and torch.allclose(rgb, rgb2, atol=1e-6)     # autograd on: the encoder always runs
+    assert torch.allclose(rgb.detach(), f, atol=2e-3)     # the taped forward folds the codes in torch: same frame up to the resampling sensitivity
