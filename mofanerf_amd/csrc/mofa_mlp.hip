@@ -60,6 +60,9 @@ struct LayerArgs {
     long long cam_pix0;
     float fx, fy, cx, cy;
     int cam_w;
+#ifdef MOFA_TIMELINE   // measurement build only (tools/timeline_layer.py): per-workgroup time stamps, 8 x u64 per tile
+    unsigned long long* timeline;
+#endif
 };
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -312,9 +315,16 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+#ifdef MOFA_TIMELINE
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tc1 = 0, tc2 = 0;
+    if (a.timeline && tid == 0) ts0 = wall_clock64();
+#endif
     stage_issue(0, 0);
     stage_commit(0);
     __syncthreads();
+#ifdef MOFA_TIMELINE
+    if (a.timeline && tid == 0) ts1 = wall_clock64(), tc1 = clock64();   // first operand panel has landed: the K loop starts
+#endif
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < KT) stage_issue(cur ^ 1, kt + 1);
@@ -323,6 +333,9 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
         if (kt + 1 < KT) stage_commit(cur ^ 1);
         __syncthreads();
     }
+#ifdef MOFA_TIMELINE
+    if (a.timeline && tid == 0) ts2 = wall_clock64(), tc2 = clock64();   // K loop done (all four waves): the epilogue starts
+#endif
 
     const int lr = lane & 31, g = lane >> 5;
     if constexpr (BWD) {
@@ -359,6 +372,15 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
     f32x4 bv[NI][4];
     store_tile<NI, NJ, PERRAY, HH>(acc, a.bias, a.bias_rows, a.bias_row_div, a.n_padded, a.y, a.m_padded, m0 + wm * (32 * NJ),
                                    n0 + wn * 64, a.relu, lane, bv);
+#ifdef MOFA_TIMELINE
+    if (a.timeline && tid == 0) {      // wave 0: its 32 stores per lane are ISSUED (not acknowledged)
+        unsigned long long* t = a.timeline + (long long)logical * 8;
+        t[0] = ts0, t[1] = ts1, t[2] = ts2, t[3] = wall_clock64();
+        t[4] = __builtin_amdgcn_s_getreg(GETREG_IMMED(32 - 1, 0, HW_ID));
+        t[5] = __builtin_amdgcn_s_getreg(GETREG_IMMED(4 - 1, 0, 20));        // XCC_ID
+        t[6] = tc2 - tc1;                                                     // clock64() (s_memtime) ticks spent in the K loop
+    }
+#endif
 }
 
 // ---- persistent twin of k_layer<128,false,true> (MOFA_PERSIST=1; A/B arm) ------------------------------
@@ -1304,15 +1326,22 @@ inline void prof_close(hipStream_t st, int kind, double flops) {
     P.flops[kind] += flops;
 }
 
+#ifdef MOFA_TIMELINE
+unsigned long long* g_timeline = nullptr;   // measurement build only: set by mofa_internal_set_timeline
+#endif
+
 template <int BN, bool L0, bool BWD = false>
 int launch_layer(LayerArgs a, hipStream_t st) {
+#ifdef MOFA_TIMELINE
+    a.timeline = (BN == 128 && !L0 && !BWD) ? g_timeline : nullptr;
+#endif
     a.n_tiles = a.n_padded / BN;
     const long long mt = a.m_padded / kRowTile;
     const long long total = mt * a.n_tiles;
     MOFA_REQUIRE(total > 0 && total < (1ll << 30), "layer: tile count %lld out of range", total);
     a.total_tiles = (int)total;
     const unsigned grid = (unsigned)round_up(total, 8);
-    const size_t lds = 2 * (size_t)(kRowTile + BN) * 16 * sizeof(float);
+    const size_t lds = 2 * (size_t)(kRowTile + BN) * 16 * sizeof(float) + (size_t)(config().lds_pad > 0 ? config().lds_pad : 0);
     const bool prof = BN == 128 && !L0 && prof_enabled();
     const int pkind = BWD ? 2 : (a.bias_row_div ? 4 : 0);   // the view layer's per-ray-bias instantiation is its own kernel
     if (prof && prof_open(st, pkind) != MOFA_OK) return MOFA_EHIP;
@@ -1619,6 +1648,15 @@ int mofa_internal_head_forward_hh(const float* x, int32_t k_padded, int64_t m_pa
                        (long long)m_padded, w_dense, b, n_out, raw, raw_off, (long long)n_points, 1);
     return check_launch("k_head(hh)");
 }
+
+#ifdef MOFA_TIMELINE
+/* measurement build only: per-tile stamps [tiles][8] u64 = {entry, first panel landed, K loop done, stores issued, HW_ID, XCC_ID,
+ * clock64 ticks in the K loop, -} */
+int mofa_internal_set_timeline(unsigned long long* buf) {
+    g_timeline = buf;
+    return MOFA_OK;
+}
+#endif
 
 /* measurement aid (tools/microbench_layer.py --peak): `blocks` workgroups of 4 waves running iters x 64 fp32 MFMAs each */
 int mofa_internal_mfma_peak_probe(float* out, int32_t blocks, int32_t iters, int32_t random_operands, void* stream) {

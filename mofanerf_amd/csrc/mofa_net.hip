@@ -82,6 +82,7 @@ Config read_env() {
     c.bn64 = getenv("MOFA_BN64") != nullptr;
     c.fused = tri("MOFA_FUSED"), c.split_hh = tri("MOFA_SPLIT_HH"), c.persist = tri("MOFA_PERSIST");
     c.dephase = tri("MOFA_DEPHASE") == 1;
+    if ((e = getenv("MOFA_LDS_PAD"))) c.lds_pad = atoi(e);
     return c;
 }
 // two slots + an atomic index: readers never see a half-written snapshot, reload is rare and host-side only

@@ -9,7 +9,11 @@ variants = {"base(2 WG/CU)": {}}
 if len(sys.argv) > 1:
     for a in sys.argv[1:]:
         name, path = a.split("=", 1)
-        variants[name] = {"MOFA_LIB": os.path.join(root, path)}
+        if path.startswith("env:"):                   # name=env:KEY=VALUE  (an environment knob instead of another build)
+            k, v = path[4:].split("=", 1)
+            variants[name] = {k: v}
+        else:
+            variants[name] = {"MOFA_LIB": os.path.join(root, path)}
 else:
     variants.update({"waves3(spills)": {"MOFA_LIB": os.path.join(root, "mofanerf_amd", "libmofanerf_hip_w3.so")}, "BN64(4 WG/CU)": {"MOFA_BN64": "1"}})
 code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tools'); import microbench_layer as m; "
