@@ -47,7 +47,7 @@ int mofa_abi_version(void);
 const char* mofa_last_error(void);   /* thread-local text of the calling thread's last failure */
 
 /* Library-wide state is limited to what is listed here; everything else is in caller-owned buffers.
- *   - measurement / A-B knobs (MOFA_STAGE, MOFA_FUSED, MOFA_PERSIST, MOFA_DEPHASE, MOFA_LDS_PAD, MOFA_BN64, MOFA_SPLIT_V, MOFA_SPLIT_HH):
+ *   - measurement / A-B knobs (MOFA_STAGE, MOFA_FUSED, MOFA_PERSIST, MOFA_DEPHASE, MOFA_RING3, MOFA_LDS_PAD, MOFA_BN64, MOFA_SPLIT_V, MOFA_SPLIT_HH):
  *     read from the environment ONCE when the library is loaded into an immutable snapshot; no launch path calls getenv.
  *     mofa_config_reload() re-reads them (tests and A/B tools that change a knob inside one process call it explicitly).
  *   - per-device caches (CU count, a one-time function attribute) and the per-device measurement session below. */

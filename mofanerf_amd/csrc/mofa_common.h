@@ -55,6 +55,7 @@ struct Config {
     int split_hh = -1;    // MOFA_SPLIT_HH=0/1: fp16 piece panels off / on (opt-in fp16x3 mode)
     int persist = -1;     // MOFA_PERSIST=0/1: persistent per-layer kernel (k_layer_persist) off / on
     int dephase = 0;      // MOFA_DEPHASE=1: per-workgroup start offset in k_layer_persist (A/B arm)
+    int ring3 = -1;       // MOFA_RING3=0/1: 3-stage LDS ring twin of the layer kernel (k_layer_ring3) off / on
     int lds_pad = 0;      // MOFA_LDS_PAD=bytes: extra dynamic LDS per workgroup of the layer kernel (occupancy A/B: 8192 -> 2 per CU)
 };
 const Config& config();

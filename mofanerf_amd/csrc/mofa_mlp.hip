@@ -383,6 +383,69 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
 #endif
 }
 
+// ---- 3-stage-ring twin of k_layer<128,false,true> (MOFA_RING3=1; A/B arm) --------------------------------------------------
+// The timeline says a workgroup that is ALONE in its K loop drives the pipe at 75 %, a pair at 94 %.  In k_layer
+// the next panel's LDS-DMA is requested half a panel (2,048 MFMA cycles of ONE wave) before the barrier that waits for it; alone
+// on its SIMD a wave then sits out the rest of an L2 round trip every panel.  Here the ring has three stages (72 KiB per
+// workgroup, still two per CU): panel kt+2 is requested at the top of panel kt and waited for two panels later with a COUNTED
+// vmcnt (panel kt+1's loads may stay in flight across the barrier), one barrier per panel.  Same tiles, same arithmetic order,
+// bit-identical results.
+template <bool PERRAY>
+__global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer_ring3(const LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BN = 128, BM = kRowTile, NI = 2, NJ = 4;
+    constexpr int STAGE = (BM + BN) * 16, XR = BM / 64, WR = BN / 64, LOADS = XR + WR;
+    const int per_xcd = gridDim.x >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= a.total_tiles) return;
+    const int mt = logical / a.n_tiles, nt = logical - mt * a.n_tiles;
+    const long long m0 = (long long)mt * BM;
+    const int n0 = nt * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    const int KT = a.k1p + a.k2p;
+
+    auto stage_issue = [&](int buf, int kt) {
+        float* xs = smem + buf * STAGE;
+        float* ws = xs + BM * 16;
+        const float* base = kt < a.k1p ? a.x1 : a.x2;
+        const int kk = kt < a.k1p ? kt : kt - a.k1p;
+        const float* src = base + ((long long)kk * a.m_padded + m0) * 16;
+#pragma unroll
+        for (int r = 0; r < XR; ++r) glds16(src + (r * 256 + tid) * 4, xs + (r * 256 + wave * 64) * 4);
+        const float* wsrc = a.w + ((long long)kt * a.n_padded + n0) * 16;
+#pragma unroll
+        for (int r = 0; r < WR; ++r) glds16(wsrc + (r * 256 + tid) * 4, ws + (r * 256 + wave * 64) * 4);
+    };
+
+    f32x16 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    stage_issue(0, 0);
+    if (KT > 1) stage_issue(1, 1);
+    int cur = 0, nxt2 = 2;                                  // ring positions of panel kt and of panel kt + 2
+    for (int kt = 0; kt < KT; ++kt) {
+        // this wave's loads of panel kt have landed once at most the LOADS newer ones (panel kt + 1) are still in flight
+        if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // ... and every other wave's; also: everyone is done reading panel kt - 1
+        if (kt + 2 < KT) stage_issue(nxt2, kt + 2);         // refill the stage panel kt - 1 just vacated
+        const float* xs = smem + cur * STAGE;
+        mma_panel<NI, NJ>(xs, xs + BM * 16, wm * (32 * NJ), wn * 64, lane, acc);
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+    }
+    f32x4 bv[NI][4];
+    store_tile<NI, NJ, PERRAY, false>(acc, a.bias, a.bias_rows, a.bias_row_div, a.n_padded, a.y, a.m_padded, m0 + wm * (32 * NJ),
+                                      n0 + wn * 64, a.relu, lane, bv);
+}
+
 // ---- persistent twin of k_layer<128,false,true> (MOFA_PERSIST=1; A/B arm) ------------------------------
 // Same tile, same panels, same K loop, same epilogue, bit-identical results.  What changes is the SCHEDULE: the grid is
 // 2 workgroups per CU and every workgroup WALKS its share of the tiles instead of exiting after one, so that
@@ -1353,8 +1416,22 @@ int launch_layer(LayerArgs a, hipStream_t st) {
         }
     }
     if constexpr (BN == 128 && !L0 && !BWD) {
-        // MOFA_PERSIST=1: the persistent twin (bit-identical; A/B arm until it is measured faster)
         const Config& cfg = config();
+        if (cfg.ring3 == 1 && stage_mode()) {   // MOFA_RING3=1: the 3-stage-ring twin (bit-identical; A/B arm)
+            const size_t lds3 = 3 * (size_t)(kRowTile + BN) * 16 * sizeof(float);
+            static std::atomic<bool> attr3[kMaxDevices];
+            const int dev = current_device();
+            if (!attr3[dev].load(std::memory_order_acquire)) {
+                if (hipFuncSetAttribute((const void*)k_layer_ring3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)k_layer_ring3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess)
+                    return check_launch("hipFuncSetAttribute(k_layer_ring3)");
+                attr3[dev].store(true, std::memory_order_release);
+            }
+            if (a.bias_row_div) hipLaunchKernelGGL((k_layer_ring3<true>), dim3(grid), dim3(256), lds3, st, a);
+            else hipLaunchKernelGGL((k_layer_ring3<false>), dim3(grid), dim3(256), lds3, st, a);
+            launched = true;
+        }
+        // MOFA_PERSIST=1: the persistent twin (bit-identical; A/B arm until it is measured faster)
         if (!launched && cfg.persist == 1 && stage_mode()) {
             const int cus = compute_units(current_device());
             long long G = 2LL * cus / 8 * 8;                                  // two resident workgroups per CU, multiple of 8 XCDs

@@ -151,6 +151,11 @@ def test_persistent_layer_kernel_is_bit_identical(knob, dephase):
     for c, ref in zip(cases, base):
         for _ in range(2):
             assert torch.equal(c(), ref)
+    knob("MOFA_PERSIST", "0")
+    knob("MOFA_RING3", "1")                      # the 3-stage LDS ring twin (k_layer_ring3): same arithmetic order
+    for c, ref in zip(cases, base):
+        for _ in range(2):
+            assert torch.equal(c(), ref)
 
 
 def test_layer0_positional_encoding_fused():
