@@ -12,7 +12,7 @@ per-RAY algebra whose inputs are the things the scripts optimise:
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List
 
 import torch
 import torch.nn.functional as F

@@ -15,7 +15,7 @@ There is no eager/CPU fallback: CPU tensors or a missing library raise ``MofaErr
 from __future__ import annotations
 
 import os
-from typing import Dict, Optional
+from typing import Dict
 
 import numpy as np
 import torch

@@ -4,7 +4,6 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import nan_equal_close
 from harness import make_product
 from mofanerf_amd import lib, rays, synth
 from oracle import mofa_oracle as orc
