@@ -11,11 +11,16 @@ models/tex_encoder_mod.py:39-73) — see :mod:`mofanerf_amd.schema`.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import schema
+
+
+_EMBEDDED_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()     # NeRF module -> HipNet (NeRF.forward on embedded inputs)
 
 
 def _xavier_relu_(m: nn.Module) -> None:
@@ -92,10 +97,9 @@ class NeRF(nn.Module):
         from .hipnet import HipNet
         if not (torch.is_tensor(input_pts) and input_pts.is_cuda and next(self.parameters()).is_cuda):
             raise lib.MofaError("NeRF.forward needs its parameters and inputs on the GPU (net.cuda()); there is no CPU path")
-        h = getattr(self, "_hip_embedded", None)
+        h = _EMBEDDED_CACHE.get(self)        # device-side cache kept OUTSIDE the module: deepcopy / pickling of the module stay plain
         if h is None:
-            h = HipNet(self)
-            object.__setattr__(self, "_hip_embedded", h)             # not a submodule / parameter: a device-side cache
+            h = _EMBEDDED_CACHE[self] = HipNet(self)
         return h.forward_embedded(input_pts, input_bmCodes, input_views, input_uvCodes)
 
 
