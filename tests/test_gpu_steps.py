@@ -127,6 +127,22 @@ def test_bench_self_spawns_two_ranks_and_emits_one_contract_json_line():
 
 
 @pytest.mark.parametrize("mode", ["fit", "train"])
+def test_bench_fit_and_train_modes_two_ranks(mode):
+    """`bench.py --mode fit|train --gpus 2` self-spawned (both ranks on this GPU, gloo): replicas (fit) / data-parallel with the flat
+    gradient bucket all-reduced inside the timed region (train); weak scaling, value = rays of BOTH ranks per second."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MOFA_DIST_BACKEND"] = "gloo"
+    j = _run_json([sys.executable, os.path.join(root, "bench.py"), "--mode", mode, "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "64",
+                   "--rays", "256", "--arch", "8", "64", "10", "64"], env)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["rays_per_step"] == 512 and j["config"]["rays_per_rank_per_step"] == 256
+    assert j["value"] > 0 and j["rccl_ranks"] == 2 and "cpu_baseline" not in j
+    assert ("all_reduce" in j["collective"]["what"]) == (mode == "train")
+
+
+@pytest.mark.parametrize("mode", ["fit", "train"])
 def test_bench_fit_and_train_modes_emit_contract_lines(mode):
     """`bench.py --mode fit|train` (BASELINE configs 3 / 5) at a functional size: forward + backward lines with a roofline object
     for the dominant MFMA kernel of the mode."""
