@@ -56,6 +56,7 @@ struct Config {
     int persist = -1;     // MOFA_PERSIST=0/1: persistent per-layer kernel (k_layer_persist) off / on
     int dephase = 0;      // MOFA_DEPHASE=1: per-workgroup start offset in k_layer_persist (A/B arm)
     int ring3 = -1;       // MOFA_RING3=0/1: 3-stage LDS ring twin of the layer kernel (k_layer_ring3) off / on
+    int pipe = -1;        // MOFA_PIPE=0/1: software-pipelined twin of the layer kernel (k_layer_pipe) off / on
     int lds_pad = 0;      // MOFA_LDS_PAD=bytes: extra dynamic LDS per workgroup of the layer kernel (occupancy A/B: 8192 -> 2 per CU)
 };
 const Config& config();

@@ -145,6 +145,7 @@ def test_persistent_layer_kernel_is_bit_identical(knob, dephase):
     cases = [lambda: _layer(x, w[:, :K].contiguous(), b), lambda: _layer(x, w, b, x2=x2),
              lambda: _layer(x, w[:128, :K].contiguous(), None, bias_rows=rows, div=S),
              lambda: _layer(x[:700], w[:128, :K].contiguous(), b[:128])]
+    knob("MOFA_PIPE", "0")                       # reference: the plain K loop (k_layer<.., PIPE = false>)
     base = [c() for c in cases]
     knob("MOFA_PERSIST", "1")
     knob("MOFA_DEPHASE", dephase)
@@ -153,6 +154,43 @@ def test_persistent_layer_kernel_is_bit_identical(knob, dephase):
             assert torch.equal(c(), ref)
     knob("MOFA_PERSIST", "0")
     knob("MOFA_RING3", "1")                      # the 3-stage LDS ring twin (k_layer_ring3): same arithmetic order
+    for c, ref in zip(cases, base):
+        for _ in range(2):
+            assert torch.equal(c(), ref)
+
+
+def test_pipelined_k_loop_is_bit_identical(knob):
+    """The shipped K loop (kloop_pipelined: fragment reads and LDS-DMA requests interleaved with the MFMAs, requests a full panel
+    ahead) against the plain loop it replaced (MOFA_PIPE=0): forward (plain, skip layer with two K sources, per-ray bias, ragged
+    point count, the smallest eligible K = 64) and backward-data (mask + accumulate) must agree bit for bit; K = 48 (odd panel
+    count) silently takes the plain loop."""
+    rng = np.random.default_rng(22)
+    M, K, N, S = 256 * 67, 256, 1024, 64
+    x = dev(rng.normal(size=(M, K)).astype(np.float32))
+    x2 = dev(rng.normal(size=(M, 128)).astype(np.float32))
+    w = dev((rng.normal(size=(N, K + 128)) / 16).astype(np.float32))
+    b = dev(rng.normal(size=(N,)).astype(np.float32))
+    rows = dev(rng.normal(size=(M // S, 128)).astype(np.float32))
+    st = lib.stream()
+    gk, ko = 256, 384                             # backward data: dX[M, ko] = G[M, gk] @ Wt, raw panel buffers
+    g_p = dev(rng.normal(size=(M * gk,)).astype(np.float32))
+    wt_p = dev((rng.normal(size=(ko * gk,)) / 16).astype(np.float32))
+    mask_p = dev(rng.normal(size=(M * ko,)).astype(np.float32))
+    dx0 = dev(rng.normal(size=(M * ko,)).astype(np.float32))
+
+    def bwd():
+        dx = dx0.clone()
+        lib.check(L().mofa_layer_backward_data(lib.ptr(g_p), gk, lib.ptr(wt_p), lib.ptr(mask_p), 1, lib.ptr(dx), M, ko, st), "bwd")
+        return dx
+
+    cases = [lambda: _layer(x, w[:, :K].contiguous(), b), lambda: _layer(x, w, b, x2=x2),
+             lambda: _layer(x, w[:128, :K].contiguous(), None, bias_rows=rows, div=S),
+             lambda: _layer(x[:700], w[:128, :K].contiguous(), b[:128]),
+             lambda: _layer(x[:, :64].contiguous(), w[:256, :64].contiguous(), b[:256]),
+             lambda: _layer(x[:, :48].contiguous(), w[:256, :48].contiguous(), b[:256]), bwd]
+    knob("MOFA_PIPE", "0")
+    base = [c() for c in cases]
+    knob("MOFA_PIPE", "1")
     for c, ref in zip(cases, base):
         for _ in range(2):
             assert torch.equal(c(), ref)

@@ -12,14 +12,16 @@ if len(sys.argv) > 1:
         if path.startswith("env:"):                   # name=env:KEY=VALUE  (an environment knob instead of another build)
             k, v = path[4:].split("=", 1)
             variants[name] = {k: v}
-        else:
-            variants[name] = {"MOFA_LIB": os.path.join(root, path)}
+        else:                                         # name=path/to/lib.so[,KEY=VALUE...]  (another build, optionally with knobs)
+            path, *knobs = path.split(",")
+            variants[name] = {"MOFA_LIB": os.path.join(root, path), **dict(k.split("=", 1) for k in knobs)}
 else:
     variants.update({"waves3(spills)": {"MOFA_LIB": os.path.join(root, "mofanerf_amd", "libmofanerf_hip_w3.so")}, "BN64(4 WG/CU)": {"MOFA_BN64": "1"}})
 code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tools'); import microbench_layer as m; "
-        "print(' '.join(f'{m.run(*c, iters=20)[1]:.1f}' for c in [(196608,1024,1024,0),(196608,256,256,0),(32768,1024,1024,0)]))" % (root, root))
+        "print(' '.join(f'{m.run(*c, iters=20)[1]:.1f}' for c in [(196608,1024,1024,0),(196608,256,256,0),(32768,1024,1024,0)]), "
+        "f'{m.run_bwd(196608,1024,1024,iters=20)[1]:.1f}')" % (root, root))
 for rnd in range(3):
     for name, env in variants.items():
         e = dict(os.environ); e.update(env); e["MOFA_STAGE"] = "glds"
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True)
-        print(f"round {rnd} {name:16s} TFLOP/s [W1024 big, W256, W1024 small]: {out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:]}", flush=True)
+        print(f"round {rnd} {name:16s} TFLOP/s [W1024 big, W256, W1024 small, BWD W1024]: {out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:]}", flush=True)

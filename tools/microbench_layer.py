@@ -92,6 +92,27 @@ def run(M, K, N, k2=0, iters=10):
     return ms, 2.0 * M * (K + k2) * N / (ms * 1e-3) / 1e12
 
 
+def run_bwd(M, K, N, iters=10):
+    """Backward-data launch dX[M, N] = G[M, K] @ Wt (+ accumulate, ReLU mask): k_layer<128,..,BWD> on raw panel buffers."""
+    g = torch.randn(M * K, device=dev)
+    wt = torch.randn(N * K, device=dev) * 0.03
+    mask = torch.randn(M * N, device=dev)
+    dx = torch.zeros(M * N, device=dev)
+    st = lib.stream()
+    args = (lib.ptr(g), K, lib.ptr(wt), lib.ptr(mask), 1, lib.ptr(dx), M, N, st)
+    for _ in range(3):
+        lib.check(L.mofa_layer_backward_data(*args), "bwd")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        lib.check(L.mofa_layer_backward_data(*args), "bwd")
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms, 2.0 * M * K * N / (ms * 1e-3) / 1e12
+
+
 if __name__ == "__main__" and "--peak" in sys.argv:
     import ctypes as C
     f = L.mofa_internal_mfma_peak_probe
