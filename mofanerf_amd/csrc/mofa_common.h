@@ -39,7 +39,8 @@ __device__ __forceinline__ void pinhole_ray(int i, int j, float fx, float fy, fl
 
 // ReLU with torch's NaN behaviour (F.relu(nan) = nan; fmaxf(nan, 0) would be 0): a NaN that enters the network - bad
 // input, or an fp16 overflow in the opt-in split mode - must reach the image exactly as it does in the reference.
-__device__ __forceinline__ float relu_np(float v) { return v < 0.f ? 0.f : v; }
+// gfx950's v_maximum3_f32 is IEEE-754-2019 `maximum` (NaN-propagating): ONE instruction instead of compare + select.
+__device__ __forceinline__ float relu_np(float v) { return __builtin_elementwise_maximum(v, 0.0f); }
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
