@@ -154,17 +154,15 @@ __device__ __forceinline__ void mma_panel(const float* __restrict__ Xt, const fl
 #ifndef MOFA_PIPE_GAP
 #define MOFA_PIPE_GAP 4      // MFMAs between two LDS-DMA requests
 #endif
+// xb / x2b / wb: the tile's first panel in the two activation sources (x2b is only dereferenced when KT > k1p) and in the
+// weight pack; xstep / wstep: floats between consecutive panels; xrow0 / wrow0: this wave's first row in the staged X / W
+// tile; `wave`: index of the wave's 1 KiB slot inside each 4 KiB staging round.
 template <int NI, int NJ, int BM, int BN>
-__device__ __forceinline__ void kloop_pipelined(const LayerArgs& a, float* smem, long long m0, int n0, int tid, int wave, int lane,
-                                                int wn, int wm, f32x16 (&acc)[NI][NJ]) {
+__device__ __forceinline__ void kloop_pipelined(const float* xb, const float* x2b, const float* wb, long long xstep, long long wstep,
+                                                int k1p, int KT, float* smem, int tid, int wave, int lane, int xrow0, int wrow0,
+                                                f32x16 (&acc)[NI][NJ]) {
     constexpr int STAGE = (BM + BN) * 16, XR = BM / 64, WR = BN / 64;
     const int lr = lane & 31, g = lane >> 5, sw = (lane >> 2) & 3;
-    const int KT = a.k1p + a.k2p;
-    // sources of the next panel to request: wave-uniform bases stepped once per panel + one per-lane offset
-    const long long xstep = a.m_padded * 16, wstep = (long long)a.n_padded * 16;
-    const float* xb = a.x1 + m0 * 16;
-    const float* x2b = a.x2 + m0 * 16;          // only dereferenced when k2p > 0
-    const float* wb = a.w + (long long)n0 * 16;
     int pq = 0;                                  // panel xb / wb point at
     const int toff = tid * 4;
     float* const lds_wave = smem + wave * 256;   // this wave's 1 KiB slot inside each 4 KiB round
@@ -181,16 +179,16 @@ __device__ __forceinline__ void kloop_pipelined(const LayerArgs& a, float* smem,
         for (int r = 0; r < WR; ++r) glds16(wb + r * 1024 + toff, ws + r * 1024);
         ++pq;
         wb += wstep;
-        xb = pq == a.k1p ? x2b : xb + xstep;
+        xb = pq == k1p ? x2b : xb + xstep;
     };
     auto read = [&](int stage, int h, Frag& f) {
         const float* Xt = smem + stage * STAGE;
         const float* Wt = Xt + BM * 16;
         const int p = ((2 * h + g) ^ sw) << 2;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) f.a[i] = *(const f32x4*)(Wt + (wn * 64 + 32 * i + lr) * 16 + p);
+        for (int i = 0; i < NI; ++i) f.a[i] = *(const f32x4*)(Wt + (wrow0 + 32 * i + lr) * 16 + p);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) f.b[j] = *(const f32x4*)(Xt + (wm * (32 * NJ) + 32 * j + lr) * 16 + p);
+        for (int j = 0; j < NJ; ++j) f.b[j] = *(const f32x4*)(Xt + (xrow0 + 32 * j + lr) * 16 + p);
     };
     auto mfma_half = [&](const Frag& f) {       // the same (e, i, j) order as mma_panel
 #pragma unroll
@@ -450,7 +448,8 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
 #ifdef MOFA_TIMELINE
         if (a.timeline && tid == 0) ts1 = wall_clock64(), tc1 = clock64();   // (includes the first two panels' fetch)
 #endif
-        kloop_pipelined<NI, NJ, BM, BN>(a, smem, m0, n0, tid, wave, lane, wn, wm, acc);
+        kloop_pipelined<NI, NJ, BM, BN>(a.x1 + m0 * 16, a.x2 + m0 * 16, a.w + (long long)n0 * 16, a.m_padded * 16,
+                                        (long long)a.n_padded * 16, a.k1p, KT, smem, tid, wave, lane, wm * (32 * NJ), wn * 64, acc);
 #ifdef MOFA_TIMELINE
         __builtin_amdgcn_s_barrier();
 #endif
@@ -946,6 +945,7 @@ struct FusedArgs {
     const float* pts;
     long long z_row_stride, n_points, m_padded, bias_rows;
     int S, n_layers, m_tiles;
+    int pipe;             // 1: full 256-feature blocks use kloop_pipelined (MOFA_PIPE != 0)
     FusedLayer L[kMaxFusedLayers];
 };
 
@@ -1021,14 +1021,21 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-            stage_issue(0, 0);
-            __syncthreads();
-            for (int kt = 0; kt < KT; ++kt) {
-                const int cur = kt & 1;
-                if (kt + 1 < KT) stage_issue(cur ^ 1, kt + 1);
-                const float* xs = smem + cur * STAGE;
-                if (active) mma_panel<NI, NJ>(xs, xs + TM * 16, 0, wn * 64, lane, acc);
+            if (a.pipe && !l0 && np - nbase >= BNMAX && KT >= 4 && !(KT & 1)) {
+                // full 256-feature block of an ordinary layer: the software-pipelined K loop of k_layer (bit-identical)
+                kloop_pipelined<NI, NJ, TM, BNMAX>(a.arena + l.x1_off + m0 * 16, a.arena + l.x2_off + m0 * 16, wbase + (long long)nbase * 16,
+                                                   a.m_padded * 16, (long long)np * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc);
+                __syncthreads();    // every wave is done reading the stages before the next block / layer requests into them
+            } else {
+                stage_issue(0, 0);
                 __syncthreads();
+                for (int kt = 0; kt < KT; ++kt) {
+                    const int cur = kt & 1;
+                    if (kt + 1 < KT) stage_issue(cur ^ 1, kt + 1);
+                    const float* xs = smem + cur * STAGE;
+                    if (active) mma_panel<NI, NJ>(xs, xs + TM * 16, 0, wn * 64, lane, acc);
+                    __syncthreads();
+                }
             }
             if (active) {
                 float* y = a.arena_w + l.y_off;
@@ -1912,6 +1919,7 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
     a.rays_o = rays_o, a.rays_d = rays_d, a.z = z, a.pts = pts;
     a.z_row_stride = z_row_stride, a.n_points = n_points, a.m_padded = m_padded, a.bias_rows = bias_rows;
     a.S = S > 0 ? S : 1, a.n_layers = n_layers, a.m_tiles = (int)(m_padded / kRowTile);
+    a.pipe = config().pipe != 0 ? 1 : 0;
     for (int i = 0; i < n_layers; ++i) {
         MOFA_REQUIRE(n_padded[i] > 0 && n_padded[i] % 64 == 0, "fused_forward: layer %d has n_padded=%d", i, n_padded[i]);
         a.L[i] = FusedLayer{x1_off[i], x2_off[i], y_off[i], w_off[i], bias_off[i], k1p[i], k2p[i], n_padded[i], bias_row_div[i]};
