@@ -383,7 +383,7 @@ template <int TN, int TK>
 __global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ g, const float* __restrict__ x,
                                                   long long m_padded, long long n_points, int n_padded, int k_padded,
                                                   int chunks_per_split, float* __restrict__ partial,
-                                                  float* __restrict__ bias_partial) {
+                                                  float* __restrict__ bias_partial, int pipe) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int MC = WgCfg<TN, TK>::MC;
     constexpr int PSTR = MC * 16 + 16;              // LDS stride between 16-feature panels (+16: bank spread)
@@ -503,7 +503,130 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ g, c
             }
         }
     };
-    if (c_begin < c_end) {
+    bool done = false;
+    if constexpr (TN == 128 && TK == 256) {
+        // Software-pipelined chunk loop (the forward kernel's kloop_pipelined, DESIGN.md 3.1, transposed to this contraction): a
+        // chunk's 64 MFMAs are two halves of four point pairs; the first half carries the fragment reads of the second, the second
+        // half carries the reads of the NEXT chunk's first half and the six LDS-DMA requests of the chunk after that (one per four
+        // MFMAs, after the reads), with the workgroup barrier between the halves.  Same stages, same MFMA order: bit-identical.
+        // Needs an even chunk count >= 4 and no ragged last chunk (the plain loop below handles everything else).
+        static_assert(MC == 16 && PIECES % 4 == 0, "pipelined weight-gradient loop: 16-point chunks, whole rounds of pieces");
+        const long long nch = c_end - c_begin;
+        if (pipe && nch >= 4 && (nch & 1) == 0 && c_end * MC <= n_points) {
+            struct WFrag {
+                float a[4][NI], b[4][NJ];
+            };
+            auto readh = [&](int st, int h, WFrag& f) {
+                const float* base = smem + st * STAGE;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int mp = 4 * h + t, sw = (mp >> 1) & 3;
+                    const fvecA va = *(const fvecA*)(base + a_base[sw] + mp * 32);
+                    const fvecB vb = *(const fvecB*)(base + b_base[sw] + mp * 32);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) f.a[t][i] = va[i];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) f.b[t][j] = vb[j];
+                }
+            };
+            auto mfmah = [&](const WFrag& f) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t][i], f.b[t][j], acc[i][j], 0, 0, 0);
+            };
+            // wave-uniform source bases (SGPRs) + one per-lane offset: a request costs no vector address arithmetic
+            const float* sq[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int pc = wave + 4 * q;
+                sq[q] = (pc < GP ? g + (long long)(n0 / 16 + pc) * m_padded * 16 : x + (long long)(k0 / 16 + pc - GP) * m_padded * 16) +
+                        c_begin * (long long)(MC * 16);
+            }
+            const unsigned loff = (unsigned)lane * 4u;
+            auto request = [&](int st) {
+                float* base = smem + st * STAGE;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    glds16b(sq[q] + loff, base + dstq[q]);
+                    sq[q] += MC * 16;
+                }
+            };
+            auto bias_add = [&](const WFrag& f) {     // one column of waves owns the bias sums: a REAL wave-uniform branch
+                if (want_bias) {
+                    asm volatile("" ::: "memory");    // (not if-converted: the other waves must not pay for the adds)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) bsum[i] += f.a[t][i];
+                }
+            };
+            auto half_a = [&](int st, WFrag& cur, WFrag& nxt) {
+                __builtin_amdgcn_sched_barrier(0);
+                readh(st, 1, nxt);
+                mfmah(cur);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                bias_add(cur);
+            };
+            auto sync_point = [&]() {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            };
+            auto half_b = [&](int st, bool do_request, bool do_read, WFrag& cur, WFrag& nxt) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (do_read) readh(st ^ 1, 0, nxt);
+                if (do_request) request(st);
+                mfmah(cur);
+                if (do_read) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                if (do_request) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 32, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                bias_add(cur);
+            };
+            WFrag fa, fb;
+            request(0);
+            request(1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
+            __builtin_amdgcn_s_barrier();
+            readh(0, 0, fa);
+            for (long long c = 0; c + 2 < nch; c += 2) {
+                half_a(0, fa, fb);
+                sync_point();
+                half_b(0, true, true, fb, fa);
+                half_a(1, fa, fb);
+                sync_point();
+                half_b(1, true, true, fb, fa);
+            }
+            half_a(0, fa, fb);
+            sync_point();
+            half_b(0, false, true, fb, fa);
+            half_a(1, fa, fb);
+            half_b(1, false, false, fb, fa);
+            done = true;
+        }
+    }
+    if (!done && c_begin < c_end) {
         stage(0);
         __syncthreads();
         for (long long c = c_begin; c < c_end; ++c) {
@@ -676,7 +799,7 @@ int launch_wgrad(const float* g, const float* x, long long m_padded, long long n
     const int prof = mofa_internal_prof_open(st, 3);       // measurement session open? (bench.py --mode train)
     if (prof < 0) return MOFA_EHIP;
     hipLaunchKernelGGL((k_wgrad<TN, TK>), grid, dim3(256), lds, st, g, x, m_padded, n_points, n_padded, k_padded,
-                       chunks_per_split, partial, bias_partial);
+                       chunks_per_split, partial, bias_partial, config().pipe != 0 ? 1 : 0);
     if (prof) mofa_internal_prof_close(st, 3, 2.0 * (double)n_points * (double)n_padded * (double)k_padded);
     return check_launch("k_wgrad");
 }

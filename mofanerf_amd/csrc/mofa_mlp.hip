@@ -164,7 +164,7 @@ __device__ __forceinline__ void kloop_pipelined(const float* xb, const float* x2
     constexpr int STAGE = (BM + BN) * 16, XR = BM / 64, WR = BN / 64;
     const int lr = lane & 31, g = lane >> 5, sw = (lane >> 2) & 3;
     int pq = 0;                                  // panel xb / wb point at
-    const int toff = tid * 4;
+    const unsigned toff = (unsigned)tid * 4u;
     float* const lds_wave = smem + wave * 256;   // this wave's 1 KiB slot inside each 4 KiB round
 
     struct Frag {
@@ -174,9 +174,9 @@ __device__ __forceinline__ void kloop_pipelined(const float* xb, const float* x2
         float* xs = lds_wave + stage * STAGE;
         float* ws = xs + BM * 16;
 #pragma unroll
-        for (int r = 0; r < XR; ++r) glds16(xb + r * 1024 + toff, xs + r * 1024);
+        for (int r = 0; r < XR; ++r) glds16(xb + (r * 1024u + toff), xs + r * 1024);
 #pragma unroll
-        for (int r = 0; r < WR; ++r) glds16(wb + r * 1024 + toff, ws + r * 1024);
+        for (int r = 0; r < WR; ++r) glds16(wb + (r * 1024u + toff), ws + r * 1024);
         ++pq;
         wb += wstep;
         xb = pq == k1p ? x2b : xb + xstep;

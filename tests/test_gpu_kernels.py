@@ -196,6 +196,41 @@ def test_pipelined_k_loop_is_bit_identical(knob):
             assert torch.equal(c(), ref)
 
 
+def test_pipelined_weight_gradient_loop_is_bit_identical(knob):
+    """k_wgrad<128,256>'s software-pipelined chunk loop (default) against its plain loop (MOFA_PIPE=0): dW and the bias sums
+    that ride along must agree bit for bit — even chunk counts take the pipelined loop, a ragged point count (last chunk
+    partly empty) and an odd chunk count silently take the plain one."""
+    rng = np.random.default_rng(23)
+    Np, Kp, Mp = 256, 512, 256 * 40
+    g_p = dev(rng.normal(size=(Mp * Np,)).astype(np.float32))
+    x_p = dev(rng.normal(size=(Mp * Kp,)).astype(np.float32))
+    st = lib.stream()
+
+    def run(n_points):
+        ws = torch.empty(L().mofa_weight_grad_workspace_floats(n_points, Np, Kp), device=DEV)
+        dw, db = torch.zeros(Np, Kp, device=DEV), torch.zeros(Np, device=DEV)
+        lib.check(L().mofa_weight_grad(lib.ptr(g_p), Np, lib.ptr(x_p), Kp, Mp, n_points, Np, Kp, lib.ptr(dw), Kp, 0, lib.ptr(db),
+                                       lib.ptr(ws), st), "weight_grad")
+        return dw, db
+
+    sizes = [Mp, Mp - 256 * 3, 16 * 250, 16 * 250 - 5, 16 * 7]
+    knob("MOFA_PIPE", "0")
+    base = [run(n) for n in sizes]
+    knob("MOFA_PIPE", "1")
+    for n, (dw0, db0) in zip(sizes, base):
+        dw, db = run(n)
+        assert torch.equal(dw, dw0) and torch.equal(db, db0), n
+    dw, db = base[0]                                   # and the numbers themselves: fp64 reference on a slice
+    assert torch.allclose(db[:8].double(), _unswizzle(g_p, Mp, Np)[:, :8].double().sum(0), rtol=1e-4, atol=1e-2)
+
+
+def _unswizzle(panels, Mp, K):
+    """[K/16][Mp][16] swizzled panels -> [Mp, K] (inverse of mofa_to_panels, through the library)."""
+    out = torch.empty(Mp, K, device=DEV)
+    lib.check(L().mofa_from_panels(lib.ptr(panels), Mp, Mp, K, lib.ptr(out), lib.stream()), "from_panels")
+    return out
+
+
 def test_layer0_positional_encoding_fused():
     """layer 0 = PE(o + d*z) @ W[:, :63].T + b, ReLU; compared with the oracle's PE + a torch fp64 matmul."""
     rng = np.random.default_rng(5)
