@@ -16,10 +16,12 @@ for mode in render fit train; do
   db=$(find /tmp/prof_$mode -name '*.db' | head -1)
   python tools/rocpd_stats.py "$db" gpurun_out/$tag/kernel_stats_${mode}.md "rocprofv3 --kernel-trace --stats -- python bench.py --mode $mode $extra"
 done
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o pmc -- python tools/pmc_layer.py > /dev/null 2> gpurun_out/$tag/pmc_$c.err
-  f=$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)
-  [ -n "$f" ] && grep -E "Kernel_Name|k_layer" "$f" | cut -c1-400 | head -8 > gpurun_out/$tag/pmc_$c.csv
+# one rocprofv3 --pmc pass per counter group (no tracing options next to --pmc)
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
+  n=$(echo $c | tr ' ' '+')
+  rm -rf /tmp/pmc_$n
+  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$n -o pmc -- python tools/pmc_layer.py > /dev/null 2> gpurun_out/$tag/pmc_$n.err
+  f=$(find /tmp/pmc_$n -name '*counter_collection.csv' | head -1)
+  [ -n "$f" ] && grep -E "Kernel_Name|k_layer" "$f" | cut -c1-400 | head -12 > gpurun_out/$tag/pmc_$n.csv
 done
 ls -la gpurun_out/$tag
