@@ -58,36 +58,55 @@ __global__ __launch_bounds__(256) void k_head_backward(const float* __restrict__
 }
 
 // ---- bias gradient: out[n] = sum_{m < n_points} G[m][n]; one block per 16-feature panel ----------------------
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, long long m_padded, long long n_points,
-                                                float* __restrict__ out) {
-    __shared__ float red[256][17];
-    const int panel = blockIdx.x;
-    const float* base = g + (long long)panel * m_padded * 16;
-    float acc[16];
+// One workgroup per 16-feature panel (64 for a 1024-wide layer), so each must keep a whole CU's memory pipeline busy on its
+// own.  A panel is [rows][64 B]: lane l of a wave reads the 16-byte chunk (l & 3) of row (l >> 2), so one wave instruction is
+// 1 KiB of CONTIGUOUS memory (a thread-per-row layout reads 16 B at a 64-byte stride: four quarter-filled requests per row —
+// measured 1.5 TB/s over 64 workgroups instead of this form's rate).  The row swizzle ((row >> 2) & 3) is constant per lane
+// when rows advance by multiples of 16, so every lane accumulates ONE logical chunk (4 features).  1024 threads, four rows in
+// flight per thread; fixed combination order (deterministic).
+__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ g, long long m_padded, long long n_points,
+                                                 float* __restrict__ out) {
+    __shared__ f32x4 red[1024];
+    const int panel = blockIdx.x, tid = threadIdx.x;
+    const int chunk = tid & 3, r0 = tid >> 2;                 // physical chunk, first row; rows r0 + 256 i
+    // this lane's LOGICAL chunk is chunk ^ ((r0 >> 2) & 3) for every row it visits ((256 i) >> 2 is a multiple of 4)
+    const float* base = g + (long long)panel * m_padded * 16 + chunk * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    long long m = r0;
+    for (; m + 3 * 256 < n_points; m += 4 * 256) {
+        f32x4 v[4];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
-    for (long long m = threadIdx.x; m < n_points; m += 256) {
-        const int sw = (int)(m >> 2) & 3;
-        const f32x4* row = (const f32x4*)(base + m * 16);
+        for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(base + (m + u * 256) * 16);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const f32x4 v = row[c ^ sw];
-            acc[4 * c + 0] += v.x, acc[4 * c + 1] += v.y, acc[4 * c + 2] += v.z, acc[4 * c + 3] += v.w;
-        }
+        for (int u = 0; u < 4; ++u) acc.x += v[u].x, acc.y += v[u].y, acc.z += v[u].z, acc.w += v[u].w;
     }
-#pragma unroll
-    for (int c = 0; c < 16; ++c) red[threadIdx.x][c] = acc[c];
+    for (; m < n_points; m += 256) {
+        const f32x4 v = *(const f32x4*)(base + m * 16);
+        acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+    }
+    red[tid] = acc;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s)
+    if (tid < 256) {      // threads 256 apart hold the same logical chunk
+        f32x4 t = red[tid];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) red[threadIdx.x][c] += red[threadIdx.x + s][c];
-        __syncthreads();
+        for (int u = 1; u < 4; ++u) {
+            const f32x4 v = red[tid + 256 * u];
+            t.x += v.x, t.y += v.y, t.z += v.z, t.w += v.w;
+        }
+        red[tid] = t;
     }
-    if (threadIdx.x < 16) out[panel * 16 + threadIdx.x] = red[0][threadIdx.x];
+    __syncthreads();
+    if (tid < 16) {       // feature tid = logical chunk tid >> 2, component tid & 3: the 64 of those 256 threads that hold that chunk
+        const int want = tid >> 2, comp = tid & 3;
+        float t = 0.f;
+        for (int i = 0; i < 256; ++i) {
+            const int lg = (i & 3) ^ ((i >> 4) & 3);
+            if (lg == want) t += red[i][comp];
+        }
+        out[panel * 16 + tid] = t;
+    }
 }
 
-// ---- per-ray bias gradient (view layer): out[r][n] = sum_{s<S} G[r*S+s][n]; thread per (ray, 4 features) ------
 __global__ __launch_bounds__(256) void k_colsum_rays(const float* __restrict__ g, long long m_padded, long long n_rays,
                                                      int S, int n_padded, float* __restrict__ out) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -315,7 +334,7 @@ int mofa_internal_raw_colsum(const float* d_raw, long long n_points, int off, in
 
 int mofa_bias_grad(const float* g, int64_t m_padded, int64_t n_points, int32_t n_padded, float* out, void* stream) {
     MOFA_REQUIRE(g && out && n_padded % 16 == 0 && n_points <= m_padded, "bias_grad: bad arguments");
-    hipLaunchKernelGGL(k_colsum, dim3(n_padded / 16), dim3(256), 0, (hipStream_t)stream, g, (long long)m_padded,
+    hipLaunchKernelGGL(k_colsum, dim3(n_padded / 16), dim3(1024), 0, (hipStream_t)stream, g, (long long)m_padded,
                        (long long)n_points, out);
     return check_launch("k_colsum");
 }

@@ -231,6 +231,26 @@ def _unswizzle(panels, Mp, K):
     return out
 
 
+@pytest.mark.parametrize("n_points", [1, 700, 4096, 4 * 1024 * 3 + 517, 131072])
+def test_bias_gradient_column_sums(n_points):
+    """`mofa_bias_grad` (k_colsum): column sums of a gradient panel buffer over the first n_points rows — full unrolled rounds,
+    the ragged remainder and fewer rows than threads — against fp64 sums, and run-to-run identical (fixed summation order)."""
+    rng = np.random.default_rng(31 + n_points % 7)
+    N = 128
+    Mp = (n_points + 255) // 256 * 256
+    g = dev(rng.normal(size=(Mp, N)).astype(np.float32))
+    gp = torch.empty(L().mofa_panel_floats(Mp, N), device=DEV)
+    lib.check(L().mofa_to_panels(lib.ptr(g), Mp, N, lib.ptr(gp), Mp, lib.stream()), "to_panels")
+    outs = []
+    for _ in range(2):
+        out = torch.empty(N, device=DEV)
+        lib.check(L().mofa_bias_grad(lib.ptr(gp), Mp, n_points, N, lib.ptr(out), lib.stream()), "bias_grad")
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    ref = g[:n_points].double().sum(0)
+    assert torch.allclose(outs[0].double(), ref, rtol=0, atol=2e-6 * max(1.0, float(n_points) ** 0.5) * 4)
+
+
 def test_layer0_positional_encoding_fused():
     """layer 0 = PE(o + d*z) @ W[:, :63].T + b, ReLU; compared with the oracle's PE + a torch fp64 matmul."""
     rng = np.random.default_rng(5)
