@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
 #ifdef MOFA_TIMELINE
         if (a.timeline && tid == 0) ts1 = wall_clock64(), tc1 = clock64();   // (includes the first two panels' fetch)
 #endif
-        kloop_pipelined<NI, NJ, BM, BN>(a.x1 + m0 * 16, a.x2 + m0 * 16, a.w + (long long)n0 * 16, a.m_padded * 16,
+        kloop_pipelined<NI, NJ, BM, BN>(a.x1 + m0 * 16, a.k2p ? a.x2 + m0 * 16 : nullptr, a.w + (long long)n0 * 16, a.m_padded * 16,
                                         (long long)a.n_padded * 16, a.k1p, KT, smem, tid, wave, lane, wm * (32 * NJ), wn * 64, acc);
 #ifdef MOFA_TIMELINE
         __builtin_amdgcn_s_barrier();
@@ -505,6 +505,15 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
         return;
     }
     // epilogue: bias + ReLU, one 16-B store per accumulator quad into the next layer's panels
+#ifdef MOFA_ABLATE_EPILOGUE   // timing-only ablation build (wrong results): what a free epilogue would be worth
+    float s_ = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) s_ += acc[i][j][0] + acc[i][j][7] + acc[i][j][15];
+    if (s_ == 123.456f) a.y[0] = s_;
+    return;
+#endif
     f32x4 bv[NI][4];
     store_tile<NI, NJ, PERRAY, HH>(acc, a.bias, a.bias_rows, a.bias_row_div, a.n_padded, a.y, a.m_padded, m0 + wm * (32 * NJ),
                                    n0 + wn * 64, a.relu, lane, bv);
@@ -1023,7 +1032,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
 
             if (a.pipe && !l0 && np - nbase >= BNMAX && KT >= 4 && !(KT & 1)) {
                 // full 256-feature block of an ordinary layer: the software-pipelined K loop of k_layer (bit-identical)
-                kloop_pipelined<NI, NJ, TM, BNMAX>(a.arena + l.x1_off + m0 * 16, a.arena + l.x2_off + m0 * 16, wbase + (long long)nbase * 16,
+                kloop_pipelined<NI, NJ, TM, BNMAX>(a.arena + l.x1_off + m0 * 16, l.k2p ? a.arena + l.x2_off + m0 * 16 : nullptr, wbase + (long long)nbase * 16,
                                                    a.m_padded * 16, (long long)np * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc);
                 __syncthreads();    // every wave is done reading the stages before the next block / layer requests into them
             } else {
