@@ -32,7 +32,7 @@ def stale() -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not stale():
         return OUT
-    extra = [f"-D{k}={os.environ[k]}" for k in ("MOFA_LAYER_WAVES", "MOFA_SPLIT_PIPELINED", "MOFA_SPLIT_FAKE", "MOFA_SETPRIO", "MOFA_TIMELINE", "MOFA_PIPE_GAP", "MOFA_ABLATE_EPILOGUE", "MOFA_PIPE_RGAP", "MOFA_PIPE_AGAP", "MOFA_PIPE_ORDER", "MOFA_PIPE_EPIBAR", "MOFA_PIPE_EPIPRIO") if os.environ.get(k)]
+    extra = [f"-D{k}={os.environ[k]}" for k in ("MOFA_LAYER_WAVES", "MOFA_SPLIT_PIPELINED", "MOFA_SPLIT_FAKE", "MOFA_SETPRIO", "MOFA_TIMELINE", "MOFA_PIPE_GAP", "MOFA_ABLATE_EPILOGUE", "MOFA_STAGED_EPILOGUE", "MOFA_PIPE_RGAP", "MOFA_PIPE_AGAP", "MOFA_PIPE_ORDER", "MOFA_PIPE_EPIBAR", "MOFA_PIPE_EPIPRIO") if os.environ.get(k)]
     cmd = [hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", os.environ.get("MOFA_LIB_OUT", OUT)]
     if verbose:
         print(" ".join(cmd), flush=True)
