@@ -365,6 +365,54 @@ __device__ __forceinline__ void store_tile_staged(const f32x16 (&acc)[NI][NJ], c
         }
 }
 
+// Backward-data epilogue through the same wave-private LDS window: dX = (acc [+ dX_old]) [* (saved activation > 0)].  Staging
+// first turns the accumulator fragments into 1 KiB contiguous wave rows, so the optional reads of dX_old and of the saved
+// activation are fully coalesced 1 KiB loads (all four of a slice in flight together) instead of 16 B per lane at a 64-byte
+// stride, and ACC / MASK are compile-time: no wait sits between a load and the next one.  Same arithmetic as the strided form.
+template <int NI, int NJ, bool ACC, bool MASK>
+__device__ __forceinline__ void store_tile_staged_bwd(const f32x16 (&acc)[NI][NJ], float* __restrict__ y, const float* __restrict__ mask,
+                                                      long long m_padded, long long m_first, int n_first, int lane, float* win) {
+    static_assert(NJ % 2 == 0, "row halves of 64 points");
+    const int lr = lane & 31, g = lane >> 5, msw = (lr >> 2) & 3;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh) {
+            const long long poff = ((long long)((n_first >> 4) + 2 * i + qh) * m_padded + m_first) * 16;
+#pragma unroll
+            for (int jh = 0; jh < NJ / 2; ++jh) {
+                const long long off = poff + jh * 1024 + lane * 4;
+                f32x4 old[4], act[4];
+                if constexpr (ACC) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) old[it] = *(const f32x4*)(y + off + it * 256);
+                }
+                if constexpr (MASK) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) act[it] = *(const f32x4*)(mask + off + it * 256);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const int j = 2 * jh + jj, q = 2 * qh + qq;
+                        f32x4 v;
+                        v.x = acc[i][j][4 * q + 0], v.y = acc[i][j][4 * q + 1], v.z = acc[i][j][4 * q + 2], v.w = acc[i][j][4 * q + 3];
+                        *(f32x4*)(win + (32 * jj + lr) * 16 + (((2 * qq + g) ^ msw) << 2)) = v;
+                    }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    f32x4 v = *(const f32x4*)(win + it * 256 + lane * 4);
+                    if constexpr (ACC) v.x += old[it].x, v.y += old[it].y, v.z += old[it].z, v.w += old[it].w;
+                    if constexpr (MASK)
+                        v.x = act[it].x > 0.f ? v.x : 0.f, v.y = act[it].y > 0.f ? v.y : 0.f, v.z = act[it].z > 0.f ? v.z : 0.f,
+                        v.w = act[it].w > 0.f ? v.w : 0.f;
+                    *(f32x4*)(y + off + it * 256) = v;
+                }
+            }
+        }
+}
+
 // BN: feature-tile height; L0: X tile is generated (positional encoding) instead of loaded;
 // GLDS: stage operands with LDS-DMA (true) or through registers (false; kept as the A/B arm).
 // BWD: backward-data epilogue (no bias/ReLU; optional accumulate into y and ReLU mask from the saved activation):
@@ -518,6 +566,19 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
 #endif
 
     const int lr = lane & 31, g = lane >> 5;
+    if constexpr (BWD && PIPE && MOFA_STAGED_EPILOGUE) {
+        float* win = smem + wave * 1024;
+        const long long mf = m0 + wm * (32 * NJ);
+        const int nf = n0 + wn * 64;
+        if (a.accumulate) {
+            if (a.mask) store_tile_staged_bwd<NI, NJ, true, true>(acc, a.y, a.mask, a.m_padded, mf, nf, lane, win);
+            else store_tile_staged_bwd<NI, NJ, true, false>(acc, a.y, a.mask, a.m_padded, mf, nf, lane, win);
+        } else {
+            if (a.mask) store_tile_staged_bwd<NI, NJ, false, true>(acc, a.y, a.mask, a.m_padded, mf, nf, lane, win);
+            else store_tile_staged_bwd<NI, NJ, false, false>(acc, a.y, a.mask, a.m_padded, mf, nf, lane, win);
+        }
+        return;
+    }
     if constexpr (BWD) {
         // backward-data epilogue: (acc [+ y_old]) [* (saved activation > 0)]
 #pragma unroll
