@@ -160,7 +160,7 @@ __device__ __forceinline__ void mma_panel(const float* __restrict__ Xt, const fl
 template <int NI, int NJ, int BM, int BN>
 __device__ __forceinline__ void kloop_pipelined(const float* xb, const float* x2b, const float* wb, long long xstep, long long wstep,
                                                 int k1p, int KT, float* smem, int tid, int wave, int lane, int xrow0, int wrow0,
-                                                f32x16 (&acc)[NI][NJ]) {
+                                                f32x16 (&acc)[NI][NJ], unsigned long long* pstamp = nullptr) {
     constexpr int STAGE = (BM + BN) * 16, XR = BM / 64, WR = BN / 64;
     const int lr = lane & 31, g = lane >> 5, sw = (lane >> 2) & 3;
     int pq = 0;                                  // panel xb / wb point at
@@ -215,6 +215,9 @@ __device__ __forceinline__ void kloop_pipelined(const float* xb, const float* x2
     auto sync_point = [&]() {   // my own requests have landed and my reads are done; then everybody's
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef MOFA_TIMELINE   // measurement build: one 100 MHz stamp per panel (tools/timeline_layer.py --panels), kept in LDS until the end
+        if (pstamp && tid == 0) *pstamp++ = wall_clock64();   // (a global store here would sit in front of the next vmcnt(0) wait)
+#endif
     };
     auto half_b = [&](int stage, bool do_request, bool do_read, Frag& cur, Frag& nxt) {   // MFMAs of the second half
         __builtin_amdgcn_sched_barrier(0);
@@ -244,6 +247,9 @@ __device__ __forceinline__ void kloop_pipelined(const float* xb, const float* x2
     request(1);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XR + WR) : "memory");   // panel 0 (the older requests) has landed
     __builtin_amdgcn_s_barrier();
+#ifdef MOFA_TIMELINE
+    if (pstamp && tid == 0) pstamp[63] = wall_clock64();              // slot 63 is never a panel stamp (KT <= 64): panel 0 landed
+#endif
     read(0, 0, fa);
     for (int kt = 0; kt + 2 < KT; kt += 2) {
         half_a(0, fa, fb);
@@ -541,7 +547,11 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
         if (a.timeline && tid == 0) ts1 = wall_clock64(), tc1 = clock64();   // (includes the first two panels' fetch)
 #endif
         kloop_pipelined<NI, NJ, BM, BN>(a.x1 + m0 * 16, a.k2p ? a.x2 + m0 * 16 : nullptr, a.w + (long long)n0 * 16, a.m_padded * 16,
-                                        (long long)a.n_padded * 16, a.k1p, KT, smem, tid, wave, lane, wm * (32 * NJ), wn * 64, acc);
+                                        (long long)a.n_padded * 16, a.k1p, KT, smem, tid, wave, lane, wm * (32 * NJ), wn * 64, acc
+#ifdef MOFA_TIMELINE
+                                        , (a.timeline && KT <= 64) ? (unsigned long long*)(smem + 2 * STAGE) : nullptr   // 512 B behind the stages
+#endif
+        );
 #ifdef MOFA_TIMELINE
         __builtin_amdgcn_s_barrier();
 #endif
@@ -635,6 +645,13 @@ __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs
         t[4] = __builtin_amdgcn_s_getreg(GETREG_IMMED(32 - 1, 0, HW_ID));
         t[5] = __builtin_amdgcn_s_getreg(GETREG_IMMED(4 - 1, 0, 20));        // XCC_ID
         t[6] = tc2 - tc1;                                                     // clock64() (s_memtime) ticks spent in the K loop
+        if constexpr (PIPE) {
+            if (KT <= 64) {
+                const unsigned long long* ps = (const unsigned long long*)(smem + 2 * STAGE);
+                unsigned long long* pd = a.timeline + (long long)a.total_tiles * 8 + (long long)logical * 64;
+                for (int i = 0; i < 64; ++i) pd[i] = ps[i];
+            }
+        }
     }
 #endif
 }
@@ -1674,7 +1691,10 @@ int launch_layer(LayerArgs a, hipStream_t st) {
     MOFA_REQUIRE(total > 0 && total < (1ll << 30), "layer: tile count %lld out of range", total);
     a.total_tiles = (int)total;
     const unsigned grid = (unsigned)round_up(total, 8);
-    const size_t lds = 2 * (size_t)(kRowTile + BN) * 16 * sizeof(float) + (size_t)(config().lds_pad > 0 ? config().lds_pad : 0);
+    size_t lds = 2 * (size_t)(kRowTile + BN) * 16 * sizeof(float) + (size_t)(config().lds_pad > 0 ? config().lds_pad : 0);
+#ifdef MOFA_TIMELINE
+    lds += 512;     // per-panel stamps of the measurement build
+#endif
     const bool prof = BN == 128 && !L0 && prof_enabled();
     const int pkind = BWD ? 2 : (a.bias_row_div ? 4 : 0);   // the view layer's per-ray-bias instantiation is its own kernel
     if (prof && prof_open(st, pkind) != MOFA_OK) return MOFA_EHIP;

@@ -46,7 +46,8 @@ def timed(n):
 
 timed(20)                                   # clocks and caches in steady state
 ms_plain = timed(20)                        # the same binary with the stamps off (null pointer)
-tl = torch.zeros(tiles * 8, dtype=torch.int64, device=dev)
+PAN = 64                                    # per-panel stamps of the pipelined loop follow the 8 per-tile words (builds that have them)
+tl = torch.zeros(tiles * (8 + PAN), dtype=torch.int64, device=dev)
 torch.cuda.synchronize()
 # the stamped launch sits in the MIDDLE of a back-to-back stream of launches: an isolated launch after a host synchronisation
 # runs at a reduced engine clock (measured with these very stamps: 1.9 GHz instead of 2.3-2.4) while the power state ramps up
@@ -62,7 +63,9 @@ for _ in range(5):
     lib.check(L.mofa_layer_forward(*args), "layer")
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
-t = tl.cpu().numpy().reshape(tiles, 8)
+raw = tl.cpu().numpy()
+t = raw[:tiles * 8].reshape(tiles, 8)
+pan = raw[tiles * 8:].reshape(tiles, PAN)
 assert (t[:, 0] > 0).all(), "some workgroups left no stamp"
 T0, T1 = t[:, 0].min(), t[:, 3].max()
 tick_us = ms * 1e3 / float(T1 - T0)            # the stamps span (almost) the whole launch: calibrates the 100 MHz clock
@@ -145,3 +148,41 @@ print(f"\nK loop: median {np.median(kl_all):.1f} us per tile (two workgroups sha
 tile_period = np.median(kl_all) + np.median(us(k0 - ent)) + np.median(us(end - k1)) + np.median(gaps)
 print(f"\nTile period = K loop + prologue + epilogue issue + turnaround = {tile_period:.1f} us -> 12 rounds = {12 * tile_period:.0f} us of the {ms * 1e3:.0f} us launch; "
       f"K-loop share {np.median(kl_all) / tile_period * 100:.1f} %.")
+
+if "--panels" in sys.argv and (pan[:, 0] > 0).all():
+    # How long does ONE panel of a workgroup's K loop take, by what the OTHER slot of its CU is doing at that moment?
+    npan = K // 16 - 1                                              # one stamp per workgroup barrier = per panel (slot 63: panel 0 landed)
+    pst = pan[:, :npan] - T0
+    cls_names = ["partner in its K loop", "partner fetching its first panels", "partner in its epilogue", "other slot empty"]
+    tot = np.zeros(4); cnt = np.zeros(4)
+    for c in np.unique(cu):
+        idx = np.where(cu == c)[0]
+        for i in idx:
+            others = [j for j in idx if j != i]
+            edges = np.concatenate([[k0[i]], pst[i]])
+            for a_, b_ in zip(edges[:-1], edges[1:]):
+                mid = 0.5 * (a_ + b_)
+                state = 3
+                for j in others:
+                    if ent[j] <= mid < end[j]:
+                        if mid < pst[j][0]: state = 1
+                        elif mid < k1[j]: state = 0
+                        else: state = 2
+                        break
+                tot[state] += b_ - a_
+                cnt[state] += 1
+    print("\nPer-panel time of a workgroup's K loop (16 of K; two workgroups sharing a CU at 100 %: "
+          f"{2 * 2 * 256 * 128 * 16 / (157.3e12 / 256) * 1e6:.2f} us, one alone: {2 * 256 * 128 * 16 / (157.3e12 / 256) * 1e6:.2f} us) by the state of the CU's other slot:\n")
+    print("| other slot | panels | share of K-loop time | mean us per panel |\n|---|---|---|---|")
+    for k in range(4):
+        if cnt[k]:
+            print(f"| {cls_names[k]} | {int(cnt[k])} | {tot[k] / tot.sum() * 100:.1f} % | {us(tot[k] / cnt[k]):.2f} |")
+    landed = us(pan[:, 63] - T0 - k0)
+    print(f"\nFirst fetch: K-loop entry -> panel 0 landed in every wave (barrier passed): median {np.median(landed):.2f} us, p5 {np.percentile(landed, 5):.2f}, "
+          f"p95 {np.percentile(landed, 95):.2f}; by round: " + ", ".join(f"{np.median(landed[order[r:r + 512]]):.1f}" for r in range(0, tiles, 512)))
+    first = us(pst[:, 0] - k0)
+    print(f"\nStart of a tile: K-loop entry (before the first two panel requests) -> first workgroup barrier passed (panel 0's first half computed, panel 1 landed): "
+          f"median {np.median(first):.2f} us, p5 {np.percentile(first, 5):.2f}, p95 {np.percentile(first, 95):.2f}; then per panel: "
+          + ", ".join(f"{np.median(us(pst[:, i + 1] - pst[:, i])):.2f}" for i in range(6)) + " us (medians of panels 1..6), last three: "
+          + ", ".join(f"{np.median(us(pst[:, i + 1] - pst[:, i])):.2f}" for i in range(npan - 4, npan - 1))
+          + f"; last barrier -> K loop done: median {np.median(us(k1 - pst[:, npan - 1])):.2f} us")
