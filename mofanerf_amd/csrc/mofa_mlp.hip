@@ -152,8 +152,8 @@ __device__ __forceinline__ void mma_panel(const float* __restrict__ Xt, const fl
 // K = N = 1024, interleaved A/B): 139.3 -> 145.6 TFLOP/s; reads-before-requests and a gap of 4 matter (requests first: 141).
 // Needs an even number of panels >= 4 (unrolled by two: stage addresses are compile-time constants); launch_layer checks.
 #ifndef MOFA_PIPE_GAP
-#define MOFA_PIPE_GAP 4      // MFMAs between two LDS-DMA requests
-#endif
+#define MOFA_PIPE_GAP 0      // MFMAs between two LDS-DMA requests; 0 = as many as the half panel allows after its reads
+#endif                       // (4 for the 128-feature tile: 32 MFMAs, 6 reads, 6 requests; 2 for the 64-feature tile: 16 / 4 / 5)
 // xb / x2b / wb: the tile's first panel in the two activation sources (x2b is only dereferenced when KT > k1p) and in the
 // weight pack; xstep / wstep: floats between consecutive panels; xrow0 / wrow0: this wave's first row in the staged X / W
 // tile; `wave`: index of the wave's 1 KiB slot inside each 4 KiB staging round.
@@ -232,9 +232,11 @@ __device__ __forceinline__ void kloop_pipelined(const float* xb, const float* x2
             }
         }
         if (do_request) {
+            constexpr int GAP = MOFA_PIPE_GAP > 0 ? MOFA_PIPE_GAP : (4 * NI * NJ - (NI + NJ)) / (XR + WR);
+            static_assert(GAP >= 1, "the half panel has too few MFMAs to carry its memory instructions");
 #pragma unroll
             for (int q = 0; q < XR + WR; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, MOFA_PIPE_GAP, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
@@ -429,6 +431,8 @@ __device__ __forceinline__ void store_tile_staged_bwd(const f32x16 (&acc)[NI][NJ
 template <int BN, bool L0, bool GLDS, bool BWD = false, bool HH = false, bool PERRAY = false, bool PIPE = false>
 __global__ __launch_bounds__(256, MOFA_LAYER_WAVES) void k_layer(const LayerArgs a) {
     static_assert(!PIPE || (GLDS && !L0 && BN == 128), "the pipelined K loop stages both operands by LDS-DMA at the 128-feature tile");
+    // (measured on the 64-feature tile too - 4 workgroups per CU, 16 MFMAs per half panel carrying 4 reads + 5 requests: 132 against
+    //  136 TFLOP/s for its plain loop, so that tile keeps the plain loop)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BM = kRowTile;
     constexpr int WAVES_N = BN / 64;

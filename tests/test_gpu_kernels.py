@@ -187,13 +187,18 @@ def test_pipelined_k_loop_is_bit_identical(knob):
              lambda: _layer(x, w[:128, :K].contiguous(), None, bias_rows=rows, div=S),
              lambda: _layer(x[:700], w[:128, :K].contiguous(), b[:128]),
              lambda: _layer(x[:, :64].contiguous(), w[:256, :64].contiguous(), b[:256]),
-             lambda: _layer(x[:, :48].contiguous(), w[:256, :48].contiguous(), b[:256]), bwd]
+             lambda: _layer(x[:, :48].contiguous(), w[:256, :48].contiguous(), b[:256]),
+             lambda: _layer(x, w[:192, :K].contiguous(), b[:192]),                      # 64-feature tile (width not a multiple of 128)
+             lambda: _layer(x, w[:64], b[:64], x2=x2), bwd]
     knob("MOFA_PIPE", "0")
     base = [c() for c in cases]
     knob("MOFA_PIPE", "1")
     for c, ref in zip(cases, base):
         for _ in range(2):
             assert torch.equal(c(), ref)
+    knob("MOFA_BN64", "1")                        # measurement knob: every layer on the 64-feature tile (4 workgroups per CU)
+    for c, ref in zip(cases, base):
+        assert torch.equal(c(), ref)
 
 
 def test_pipelined_weight_gradient_loop_is_bit_identical(knob):

@@ -9,9 +9,8 @@ variants = {"base(2 WG/CU)": {}}
 if len(sys.argv) > 1:
     for a in sys.argv[1:]:
         name, path = a.split("=", 1)
-        if path.startswith("env:"):                   # name=env:KEY=VALUE  (an environment knob instead of another build)
-            k, v = path[4:].split("=", 1)
-            variants[name] = {k: v}
+        if path.startswith("env:"):                   # name=env:KEY=VALUE[,KEY=VALUE...]  (environment knobs instead of another build)
+            variants[name] = dict(kv.split("=", 1) for kv in path[4:].split(","))
         else:                                         # name=path/to/lib.so[,KEY=VALUE...]  (another build, optionally with knobs)
             path, *knobs = path.split(",")
             variants[name] = {"MOFA_LIB": os.path.join(root, path), **dict(k.split("=", 1) for k in knobs)}
