@@ -14,6 +14,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-Wno-unused-function"]
 
 
+# compile-time switches of measurement / A-B builds (tools/ab_layer.py, tools/timeline_layer.py); an environment variable of the
+# same name turns into -D<name>=<value>.  The shipped library is built with none of them set.
+MEASUREMENT_DEFINES = ("MOFA_LAYER_WAVES", "MOFA_SPLIT_PIPELINED", "MOFA_SPLIT_FAKE", "MOFA_SETPRIO", "MOFA_TIMELINE", "MOFA_PIPE_GAP",
+                       "MOFA_ABLATE_EPILOGUE", "MOFA_STAGED_EPILOGUE")
+
+
 def hipcc() -> str:
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -32,7 +38,7 @@ def stale() -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not stale():
         return OUT
-    extra = [f"-D{k}={os.environ[k]}" for k in ("MOFA_LAYER_WAVES", "MOFA_SPLIT_PIPELINED", "MOFA_SPLIT_FAKE", "MOFA_SETPRIO", "MOFA_TIMELINE", "MOFA_PIPE_GAP", "MOFA_ABLATE_EPILOGUE", "MOFA_STAGED_EPILOGUE", "MOFA_PIPE_RGAP", "MOFA_PIPE_AGAP", "MOFA_PIPE_ORDER", "MOFA_PIPE_EPIBAR", "MOFA_PIPE_EPIPRIO") if os.environ.get(k)]
+    extra = [f"-D{k}={os.environ[k]}" for k in MEASUREMENT_DEFINES if os.environ.get(k)]
     cmd = [hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", os.environ.get("MOFA_LIB_OUT", OUT)]
     if verbose:
         print(" ".join(cmd), flush=True)
