@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--gemm", choices=["fp32", "bf16x6", "bf16x3", "fp16x3"], default="fp32",
                     help="fp32 (default, the headline: exact fp32 MFMA).  bf16x6 / bf16x3 = OPT-IN split-product emulation of "
                          "the fp32 products on the bf16 matrix pipe — a labelled experiment, not the headline")
+    ap.add_argument("--netchunk", type=int, default=None, help="labelled variant: points per network launch (default 196608, the reference's)")
     ap.add_argument("--size", type=int, default=512, help="image side (512 = the benchmark; smaller only for functional tests)")
     ap.add_argument("--rays", type=int, default=None, help="fit / train: N_rand per GPU (default 1024 / 4096)")
     a = ap.parse_args()
@@ -180,6 +181,8 @@ def main():
     L = lib.load()
 
     render, kw, args = build_product(dev, with_tex=(a.mode == "train"))
+    if a.netchunk:
+        render.netchunk = int(a.netchunk)
     bm, tex, exp = (t.to(dev) for t in synth.codes(0))
     K = synth.intrinsics(H, W)
     n_total = H * W
@@ -308,7 +311,7 @@ def main():
             "dtype": "f32" if a.gemm == "fp32" else f"f32 emulated by {a.gemm} split products (16-bit MFMA, fp32 accumulation) - OPT-IN EXPERIMENT",
             "data": "synthetic",
             "config": {"workload": f"{workload}, 64 coarse + 128 fine samples/ray, coarse {ARCH[1]}x{ARCH[0]} + fine {ARCH[3]}x{ARCH[2]}, "
-                                   f"chunk=netchunk=196608, seeded Xavier weights (BASELINE.json configs[{ {'render': 1, 'fit': 2, 'train': 4}[a.mode] }])",
+                                   f"chunk=196608, netchunk={int(a.netchunk) if a.netchunk else 196608}{' (VARIANT: the benchmark is netchunk=196608)' if a.netchunk and a.netchunk != 196608 else ''}, seeded Xavier weights (BASELINE.json configs[{ {'render': 1, 'fit': 2, 'train': 4}[a.mode] }])",
                        "mode": a.mode, "rays_per_step": units_per_step, "rays_per_rank_per_step": units_per_step // world,
                        "parallelism": par,
                        "gflop_per_ray_folded": round(work / 1e9, 4),
