@@ -178,9 +178,10 @@ def test_pipelined_k_loop_is_bit_identical(knob):
     mask_p = dev(rng.normal(size=(M * ko,)).astype(np.float32))
     dx0 = dev(rng.normal(size=(M * ko,)).astype(np.float32))
 
-    def bwd():
+    def bwd(accumulate=1, masked=True):
         dx = dx0.clone()
-        lib.check(L().mofa_layer_backward_data(lib.ptr(g_p), gk, lib.ptr(wt_p), lib.ptr(mask_p), 1, lib.ptr(dx), M, ko, st), "bwd")
+        lib.check(L().mofa_layer_backward_data(lib.ptr(g_p), gk, lib.ptr(wt_p), lib.ptr(mask_p) if masked else None, accumulate,
+                                               lib.ptr(dx), M, ko, st), "bwd")
         return dx
 
     cases = [lambda: _layer(x, w[:, :K].contiguous(), b), lambda: _layer(x, w, b, x2=x2),
@@ -189,7 +190,7 @@ def test_pipelined_k_loop_is_bit_identical(knob):
              lambda: _layer(x[:, :64].contiguous(), w[:256, :64].contiguous(), b[:256]),
              lambda: _layer(x[:, :48].contiguous(), w[:256, :48].contiguous(), b[:256]),
              lambda: _layer(x, w[:192, :K].contiguous(), b[:192]),                      # 64-feature tile (width not a multiple of 128)
-             lambda: _layer(x, w[:64], b[:64], x2=x2), bwd]
+             lambda: _layer(x, w[:64], b[:64], x2=x2), bwd, lambda: bwd(0, True), lambda: bwd(1, False), lambda: bwd(0, False)]
     knob("MOFA_PIPE", "0")
     base = [c() for c in cases]
     knob("MOFA_PIPE", "1")
