@@ -565,8 +565,101 @@ def g10_checkpoint():
     save("ckpt_render.npz", out)
 
 
+class _DrawLog:
+    """Record (or replace) what ``np.random.randn`` / ``np.random.choice`` hand to the reference's samplers, so that the device
+    samplers can be fed the SAME draws (``draws=`` of mofanerf_amd.rays.train_pixels / fit_pixels)."""
+
+    def __init__(self, zero_randn=False):
+        self.randn, self.choice, self.zero = [], [], zero_randn
+
+    def __enter__(self):
+        self._r, self._c = np.random.randn, np.random.choice
+
+        def randn(*shape):
+            v = self._r(*shape)
+            if self.zero:
+                v = np.zeros_like(v)
+            self.randn.append(v.copy())
+            return v
+
+        def choice(a, size=None, replace=True, p=None):
+            v = self._c(a, size=size, replace=replace, p=p)
+            self.choice.append(np.asarray(v).copy())
+            return v
+
+        np.random.randn, np.random.choice = randn, choice
+        return self
+
+    def __exit__(self, *a):
+        np.random.randn, np.random.choice = self._r, self._c
+
+
+def g14_samplers():
+    """The scripts' landmark-biased pixel samplers, run as they are: ``run_train.LMModule.sample_point`` (3D landmarks projected with
+    K and the pose, run_train.py:119-148) and ``run_fit.LMModule.sample_point`` (run_fit.py:35-82), under seeded ``np.random`` with
+    the draws recorded.  The scripts only import with stand-ins for packages this image lacks (cv2, imageio, configargparse, dlib: none
+    is touched by the samplers) and for the two numpy aliases numpy >= 1.24 removed (``np.long`` = the platform C long = int64,
+    ``np.int`` = int, what they were when the scripts were written)."""
+    for m in ("configargparse", "dlib"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    np.long, np.int = np.int64, int
+    cwd = os.getcwd()
+    os.chdir("/root/reference")          # run_fit's imports read ./configs/*.npy relative paths lazily; be where the scripts expect
+    try:
+        import run_train  # noqa: E402  (reference)
+        import run_fit  # noqa: E402  (reference)
+    finally:
+        os.chdir(cwd)
+    torch.autograd.set_detect_anomaly(False)
+    out = {}
+    # ---- training sampler: 68 synthetic 3D landmarks (stored x50, as the FaceScape table is), two identities x three expressions
+    rng = np.random.default_rng(14)
+    H = W = 512
+    K = np.array([[1200.0, 0, 256], [0, 1200.0, 256], [0, 0, 1]])
+    face = np.stack([rng.uniform(-1.6, 1.6, 68), rng.uniform(-2.0, 2.0, 68), rng.uniform(-0.3, 1.2, 68)], -1)
+    table = (face[None, None] + rng.normal(0, 0.05, (2, 3, 68, 3))) * 50.0
+    LM = object.__new__(run_train.LMModule)          # (its __init__ only loads ../data/1_975_landmarks.npy)
+    LM.landmark, LM.H = table, H
+    full = torch.reshape(torch.stack(torch.meshgrid(torch.linspace(0, H - 1, H), torch.linspace(0, W - 1, W)), -1), [-1, 2])
+    dH = dW = int(H // 2 * 0.5)
+    crop = torch.reshape(torch.stack(torch.meshgrid(torch.linspace(H // 2 - dH, H // 2 + dH - 1, 2 * dH),
+                                                    torch.linspace(W // 2 - dW, W // 2 + dW - 1, 2 * dW)), -1), [-1, 2])
+    out.update(train_K=K, train_table=table, train_H=H)
+    for tag, angle, ident, exp, coords, n in (("a", 25.0, 1, 2, full, 4096), ("b", -40.0, 0, 1, crop, 1024)):
+        pose = pose_spherical(angle, 0.0, 16.0)[:3, :4]
+        np.random.seed(140 + ord(tag))
+        with _DrawLog() as log:
+            sel = LM.sample_point(numOfPoint=n, K=K, pose=pose, id=torch.Tensor([ident]), exp=exp, coords=coords)
+        with _DrawLog(zero_randn=True) as log0:          # zero offsets: the landmark part IS the projected table, repeated
+            sel0 = LM.sample_point(numOfPoint=n, K=K, pose=pose, id=torch.Tensor([ident]), exp=exp, coords=coords)
+        p = int(n / 5 * 3 // 68)
+        lm2d = sel0[n - 68 * p:].reshape(68, p, 2)[:, 0]
+        out.update({f"train_{tag}_pose": pose, f"train_{tag}_id": ident, f"train_{tag}_exp": exp, f"train_{tag}_n": n,
+                    f"train_{tag}_precrop": 0.5 if coords is crop else 0.0, f"train_{tag}_rand": log.randn[0] * (H * 0.025),
+                    f"train_{tag}_choice": log.choice[0], f"train_{tag}_lm2d": lm2d, f"train_{tag}_select": sel})
+        print(f"train sampler {tag}: n={n} p={p} lm2d rows {int(lm2d[:, 0].min())}..{int(lm2d[:, 0].max())} cols {int(lm2d[:, 1].min())}..{int(lm2d[:, 1].max())}")
+    # ---- fitting sampler: integer 2D landmarks on a 512 grid, a half-resolution target with an empty background
+    lm512 = np.stack([np.linspace(150, 400, 68).round(), np.linspace(140, 380, 68)[::-1].round()], -1).astype(np.int64)
+    lm512 = lm512[rng.permutation(68)]
+    tgt = np.zeros((256, 256, 3), np.float32)
+    tgt[60:215, 55:205] = rng.uniform(0.05, 1.0, (155, 150, 3)).astype(np.float32)
+    small = np.zeros((256, 256, 3), np.float32)                      # almost empty target: fewer candidates than N_rand survive
+    small[70:112, 60:190] = 0.5
+    LMf = run_fit.LMModule(lm512, H=512)
+    out.update(fit_lm=lm512, fit_target=tgt, fit_target_small=small)
+    for tag, img, n in (("a", tgt, 1024), ("b", small, 1024)):
+        np.random.seed(150 + ord(tag))
+        with _DrawLog() as log:
+            sel = LMf.sample_point(numOfPoint=n, coords=None, tar_img=img, scale=2)
+        wid = 512 * 0.025 / 2
+        out.update({f"fit_{tag}_n": n, f"fit_{tag}_rand": log.randn[0] * wid, f"fit_{tag}_rand_outline": log.randn[1] * wid,
+                    f"fit_{tag}_choice": log.choice[0] if log.choice else np.zeros(0, np.int64), f"fit_{tag}_select": sel})
+        print(f"fit sampler {tag}: n={n}, outline draws {log.randn[1].shape[0]}, branch = {'choice' if log.choice else 'repeat'}")
+    save("kat_samplers.npz", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for w in which:
         {"g1": g1_kats, "g2": g2_small, "g3": g3_true, "g4": g4_grads, "g5": g5_render_tex, "g6": g6_schema, "g7": g7_config1, "g8": g8_true_grads, "g9": g9_run_network_kat,
-         "g10": g10_checkpoint, "g11": g11_envelopes, "g12": g12_pose_grads, "g13": g13_ndc}[w]()
+         "g10": g10_checkpoint, "g11": g11_envelopes, "g12": g12_pose_grads, "g13": g13_ndc, "g14": g14_samplers}[w]()
