@@ -189,7 +189,7 @@ def main():
     comm_ms = []                                                       # per-step collective time on this rank (N > 1)
 
     def timed_comm(fn):
-        if world == 1:
+        if not mdist.active():
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -249,7 +249,7 @@ def main():
                 return msteps.train_step(render, kwt, opt, bucket, H, W, K, rays_b, target, bm_n, uv, 3, chunk=n)
 
     def sync():
-        if world > 1:
+        if mdist.active():
             mdist.barrier()
         torch.cuda.synchronize()
 
@@ -325,7 +325,7 @@ def main():
                          "share_of_timed_region": round(ms[dom] * 1e-3 / dt, 4),
                          "other_mfma_kernels": others, **tinfo},
         }
-        if world > 1:
+        if mdist.active():
             out["rccl_ranks"] = world
             out["backend"] = torch.distributed.get_backend()
             out["collective"] = {"what": {"render": "all_gather_into_tensor of the [rays/N,5] fp32 tiles, written straight into the frame",
@@ -334,7 +334,7 @@ def main():
         if world == 1 and a.cpu_rays > 0:
             out["cpu_baseline"] = cpu_baseline(a.cpu_rays, backward=(a.mode == "fit"))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if mdist.active():
         mdist.barrier()
         torch.distributed.destroy_process_group()
 

@@ -23,12 +23,29 @@ def _rccl_env() -> None:
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+def force_collectives() -> bool:
+    """``MOFA_DIST_FORCE_COLLECTIVES=1``: create the process group and issue every collective even when the job has ONE rank.
+    A 1-rank job normally short-circuits (nothing to exchange); with the flag the same branches run that an N-rank job takes —
+    ``init_process_group(backend="nccl")`` (RCCL communicator creation), ``all_gather_into_tensor`` into the frame buffer,
+    the flat-bucket ``all_reduce``, ``barrier(device_ids=...)``, the max-over-ranks reduction on a device tensor — which is how
+    the RCCL path is exercised on a single-GPU box (tests/test_gpu_rccl.py, tools/rccl_world1.py).  Results are unchanged: a
+    1-rank all-gather / all-reduce / average is the identity."""
+    return os.environ.get("MOFA_DIST_FORCE_COLLECTIVES", "") not in ("", "0")
+
+
+def active(group=None) -> bool:
+    """True when collectives must be issued: a group exists and it has more than one rank (or the force flag is set)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or force_collectives()
+
+
 def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     """Initialise the default process group from torchrun's env; returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
         _rccl_env()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -61,7 +78,7 @@ def all_gather_tiles(local: torch.Tensor, n_total: int, world: int, rank: int, a
     collective.  When the blocks are equal (every benchmark shape: 512 rows over 1/2/4/8 ranks) the collective writes straight
     into the result — no padding, no copies; pass ``out`` to reuse the frame buffer across calls.  Uneven blocks are padded to
     the largest block and compacted afterwards."""
-    if world == 1:
+    if world == 1 and not active(group):
         return local
     sizes = [shard_range(n_total, r, world, align) for r in range(world)]
     mx = max(e - b for b, e in sizes)
@@ -102,7 +119,7 @@ def barrier(group=None) -> None:
 
 def barrier_max(seconds: float, device) -> float:
     """Max over ranks of a local duration (bench timing contract)."""
-    if not (dist.is_available() and dist.is_initialized()):
+    if not active():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -143,7 +160,7 @@ class GradBucket:
 
     def sync(self):
         """Average the gradients over the ranks (no-op for a single process)."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if active(self.group):
             if self.flat.is_cuda and dist.get_backend(self.group) == "gloo":   # functional-test configuration: stage via host
                 host = self.flat.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)

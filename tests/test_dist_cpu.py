@@ -71,3 +71,30 @@ def _bucket_worker(rank, world, port):
 
 def test_grad_bucket_allreduce_gloo_world2():
     mp.spawn(_bucket_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _forced_worker(rank, world, port):
+    """ONE rank with MOFA_DIST_FORCE_COLLECTIVES=1: the group is created and every collective is issued (the switch the GPU box
+    uses to run the RCCL branches on one device, tests/test_gpu_rccl.py) — here on gloo."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      MOFA_DIST_FORCE_COLLECTIVES="1")
+    r, w, _ = mdist.init_from_env("gloo")
+    assert (r, w) == (0, 1) and dist.is_initialized() and mdist.active()
+    tile = torch.arange(64 * 5, dtype=torch.float32).reshape(64, 5)
+    frame = mdist.all_gather_tiles(tile, 64, 1, 0, align=8)
+    assert frame.data_ptr() != tile.data_ptr() and torch.equal(frame, tile)          # went through the collective, not the early return
+    again = mdist.all_gather_tiles(tile + 1, 64, 1, 0, align=8, out=frame)
+    assert again.data_ptr() == frame.data_ptr() and torch.equal(again, tile + 1)
+    w0 = torch.nn.Parameter(torch.ones(7))
+    bucket = mdist.GradBucket([w0])
+    bucket.flat.fill_(3.0)
+    assert torch.equal(bucket.sync(), torch.full((7,), 3.0))
+    assert mdist.barrier_max(0.5, torch.device("cpu")) == 0.5
+    mdist.barrier()
+    dist.destroy_process_group()
+
+
+def test_forced_collectives_on_one_rank():
+    assert not mdist.active()                                                        # no group in the test process itself
+    mp.spawn(_forced_worker, args=(1, _free_port()), nprocs=1, join=True)
+    os.environ.pop("MOFA_DIST_FORCE_COLLECTIVES", None)

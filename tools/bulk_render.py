@@ -60,7 +60,7 @@ def main(argv=None):
     render.png_sink.close(); render.png_sink = None      # every file is on disk inside the timed region
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     total = torch.tensor([float(sum(done))], dtype=torch.float64)
-    if world > 1:
+    if mdist.active():
         if torch.distributed.get_backend() == "nccl":
             total = total.to(dev)                      # keep the tensor the collective reduces INTO
         torch.distributed.all_reduce(total)

@@ -60,7 +60,7 @@ def main(argv=None):
         h.update(p.detach().cpu().numpy().tobytes())
     digest = int(h.hexdigest()[:15], 16)
     same = True
-    if world > 1:
+    if mdist.active():
         t = torch.tensor([digest], dtype=torch.int64)
         if dist.get_backend() != "gloo":                      # RCCL needs every buffer — input AND outputs — on the GPU
             t = t.to(dev)
@@ -71,7 +71,7 @@ def main(argv=None):
         print(json.dumps({"world": world, "rays_per_rank": a.rays, "steps": a.steps, "ms_per_step": [round(t * 1e3, 1) for t in times],
                           "loss_rank0": [round(l, 5) for l in losses], "parameters_identical_across_ranks": bool(same),
                           "bucket_floats": bucket.numel}), flush=True)
-    if world > 1:
+    if mdist.active():
         mdist.barrier(); dist.destroy_process_group()
     assert same, "ranks diverged"
     return same
