@@ -34,7 +34,7 @@ def fold_torch(h: HipNet, exp_code: torch.Tensor, shape_code: torch.Tensor, tex_
     """Differentiable twin of ``mofa_net_fold``: same blob layout (one ``n_padded`` slice per layer in state-dict order,
     the view layer skipped, heads padded to 4).  ``detach_params``: gradients flow to the codes only (fitting without
     weight gradients) — no network parameter receives a ``.grad``."""
-    D = h.net.D
+    D = h.D
     lin = h._linears
     bim0, bim_skip, uv0, uv_skip, view = 4, 9, 4 + D, 9 + D, 4 + 2 * D
     e, s, t = exp_code.reshape(-1), shape_code.reshape(-1), tex_code.reshape(-1)

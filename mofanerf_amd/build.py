@@ -20,6 +20,22 @@ MEASUREMENT_DEFINES = ("MOFA_LAYER_WAVES", "MOFA_SPLIT_PIPELINED", "MOFA_SPLIT_F
                        "MOFA_ABLATE_EPILOGUE", "MOFA_STAGED_EPILOGUE")
 
 
+def csrc_digest() -> str:
+    """sha256 over the kernel sources (names + contents of csrc/** and the C-ABI header): identifies WHICH kernels a profile was taken
+    on (profiles/hbm_traffic.json records it; bench.py quotes those counters only for the same digest)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for root, _dirs, names in os.walk(CSRC):
+        files += [os.path.join(root, n) for n in names if n.endswith((".hip", ".h"))]
+    files.append(os.path.join(HERE, "..", "include", "mofanerf_hip.h"))
+    for f in sorted(files, key=lambda q: os.path.relpath(q, HERE)):
+        h.update(os.path.relpath(f, HERE).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def hipcc() -> str:
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):

@@ -286,6 +286,149 @@ __global__ __launch_bounds__(256) void k_composite_backward(
     }
 }
 
+// Rays with more than 256 samples: the same backward walked in passes of 256 samples (lane l owns samples [256 p + 4 l, +4) of
+// pass p).  Sweep 1 (front to back) carries the transmittance from pass to pass and leaves the value in front of every pass in LDS
+// (plus the ray sums the disp gradient needs); sweep 2 (back to front) recomputes a pass's alphas from `raw` and carries the suffix
+// sum  sum_{i > j} G_i w_i  from the passes behind it.  kMaxPasses * 256 samples per ray.
+constexpr int kMaxPasses = 64;
+__global__ __launch_bounds__(256) void k_composite_backward_long(
+    const float* __restrict__ raw, const float* __restrict__ z, long long z_row_stride, const float* __restrict__ rays_d,
+    const float* __restrict__ noise, long long n_rays, int S, int white_bkgd, const float* __restrict__ g_rgb,
+    const float* __restrict__ g_disp, const float* __restrict__ g_acc, const float* __restrict__ g_depth,
+    const float* __restrict__ g_weights, float* __restrict__ d_raw, float* __restrict__ d_rays_d) {
+    constexpr int SPL = 4;
+    __shared__ float s_carry[kWavesPerBlock][kMaxPasses];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long ray = (long long)blockIdx.x * kWavesPerBlock + wv;
+    if (ray >= n_rays) return;                              // wave-uniform; only wave-level synchronisation below
+    const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+    const float dnorm = __fsqrt_rn(dx * dx + dy * dy + dz * dz);
+    const float* zr = z + ray * z_row_stride;
+    const f32x4* rr = (const f32x4*)(raw + ray * (long long)S * 4);
+    const int passes = (S + 64 * SPL - 1) / (64 * SPL);
+
+    float zv[SPL + 1], alpha[SPL], sig[SPL], dlt[SPL], cr[SPL], cg[SPL], cb[SPL];
+    auto load_pass = [&](int pass) -> float {               // fills the per-sample arrays; returns this lane's (1 - alpha + 1e-10) product
+        const int s0 = pass * 64 * SPL + lane * SPL;
+#pragma unroll
+        for (int t = 0; t <= SPL; ++t) zv[t] = (s0 + t < S) ? zr[s0 + t] : 0.f;
+        float run = 1.0f;
+#pragma unroll
+        for (int t = 0; t < SPL; ++t) {
+            const int s = s0 + t;
+            if (s < S) {
+                const f32x4 v = rr[s];
+                dlt[t] = (s + 1 < S) ? (zv[t + 1] - zv[t]) : 1e10f;
+                float sg = v.w;
+                if (noise) sg = sg + noise[ray * (long long)S + s];
+                sig[t] = sg;
+                alpha[t] = 1.0f - expf(-relu_np(sg) * (dlt[t] * dnorm));
+                cr[t] = 1.0f / (1.0f + expf(-v.x)), cg[t] = 1.0f / (1.0f + expf(-v.y)), cb[t] = 1.0f / (1.0f + expf(-v.z));
+                run = run * ((1.0f - alpha[t]) + 1e-10f);
+            } else {
+                alpha[t] = 0.f, sig[t] = 0.f, dlt[t] = 0.f, cr[t] = cg[t] = cb[t] = 0.f;
+            }
+        }
+        return run;
+    };
+    auto lane_T0 = [&](float run, float carry, float& total) -> float {   // transmittance in front of this lane's first sample
+        float incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl = incl * up;
+        }
+        float T0 = __shfl_up(incl, 1, 64);
+        if (lane == 0) T0 = 1.0f;
+        total = __shfl(incl, 63, 64);
+        return carry * T0;
+    };
+
+    // sweep 1: carries and the ray sums
+    float carry = 1.0f, sd = 0.f, sa = 0.f;
+    for (int pass = 0; pass < passes; ++pass) {
+        const float run = load_pass(pass);
+        if (lane == 0) s_carry[wv][pass] = carry;
+        float total;
+        float T = lane_T0(run, carry, total);
+        carry = carry * total;
+        const int s0 = pass * 64 * SPL + lane * SPL;
+#pragma unroll
+        for (int t = 0; t < SPL; ++t) {
+            const float w = alpha[t] * T;
+            if (s0 + t < S) sd += w * zv[t], sa += w;
+            T = T * ((1.0f - alpha[t]) + 1e-10f);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    sd = wave_sum(sd), sa = wave_sum(sa);
+    const float gr = g_rgb[ray * 3], gg = g_rgb[ray * 3 + 1], gb = g_rgb[ray * 3 + 2];
+    float gdepth = g_depth ? g_depth[ray] : 0.f, gacc = g_acc ? g_acc[ray] : 0.f;
+    const float gdisp = g_disp ? g_disp[ray] : 0.f;
+    if (gdisp != 0.f) {
+        const float q = __fdiv_rn(sd, sa);
+        if (q > 1e-10f) gdepth += gdisp * (-sa / (sd * sd)), gacc += gdisp * (1.0f / sd);
+        else if (q != q) gdepth += q, gacc += q;
+    }
+    if (white_bkgd) gacc -= gr + gg + gb;
+
+    // sweep 2: back to front
+    float behind = 0.f, dn_acc = 0.f;                       // sum of G_i w_i over every LATER pass; d L / d |rays_d|
+    for (int pass = passes - 1; pass >= 0; --pass) {
+        const float run = load_pass(pass);
+        float total;
+        const float T0 = lane_T0(run, s_carry[wv][pass], total);
+        const int s0 = pass * 64 * SPL + lane * SPL;
+        float T = T0, w[SPL], Tt[SPL], G[SPL], local = 0.f;
+#pragma unroll
+        for (int t = 0; t < SPL; ++t) {
+            Tt[t] = T;
+            w[t] = alpha[t] * T;
+            T = T * ((1.0f - alpha[t]) + 1e-10f);
+            const int s = s0 + t;
+            G[t] = (s < S) ? ((g_weights ? g_weights[ray * (long long)S + s] : 0.f) + gr * cr[t] + gg * cg[t] + gb * cb[t] +
+                              gdepth * zv[t] + gacc)
+                           : 0.f;
+            local += G[t] * w[t];
+        }
+        float suf = local;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float dn = __shfl_down(suf, o, 64);
+            if (lane + o < 64) suf += dn;
+        }
+        float after = __shfl_down(suf, 1, 64);
+        if (lane == 63) after = 0.f;
+        after += behind;
+        behind += __shfl(suf, 0, 64);
+#pragma unroll
+        for (int t = SPL - 1; t >= 0; --t) {
+            const int s = s0 + t;
+            if (s < S) {
+                const float one_m = (1.0f - alpha[t]) + 1e-10f;
+                const float dalpha = G[t] * Tt[t] - after / one_m;
+                const float dist = dlt[t] * dnorm;
+                const float keep = 1.0f - alpha[t];
+                const float dsig = sig[t] > 0.f ? dalpha * dist * keep : 0.f;
+                const float ddist = dalpha * relu_np(sig[t]) * keep;
+                dn_acc += ddist * dlt[t];
+                f32x4 o;
+                o.x = w[t] * gr * cr[t] * (1.0f - cr[t]);
+                o.y = w[t] * gg * cg[t] * (1.0f - cg[t]);
+                o.z = w[t] * gb * cb[t] * (1.0f - cb[t]);
+                o.w = dsig;
+                *(f32x4*)(d_raw + (ray * (long long)S + s) * 4) = o;
+                after += G[t] * w[t];
+            }
+        }
+    }
+    dn_acc = wave_sum(dn_acc);
+    if (lane == 0 && d_rays_d) {
+        const float inv = dnorm > 0.f ? 1.0f / dnorm : 0.f;
+        d_rays_d[ray * 3] = dn_acc * dx * inv, d_rays_d[ray * 3 + 1] = dn_acc * dy * inv, d_rays_d[ray * 3 + 2] = dn_acc * dz * inv;
+    }
+}
+
 // ---- head bias gradient: out[c] = sum_m d_raw[m][off + c]  (single block; 4 floats per point) ------------------
 __global__ __launch_bounds__(1024) void k_raw_colsum(const float* __restrict__ d_raw, long long n_points, int off, int n,
                                                      float* __restrict__ out) {
@@ -362,7 +505,7 @@ int mofa_composite_backward(const float* raw, const float* z, int64_t z_row_stri
                             const float* g_disp, const float* g_acc, const float* g_depth, const float* g_weights,
                             float* d_raw, float* d_rays_d, void* stream) {
     MOFA_REQUIRE(raw && z && rays_d && g_rgb && d_raw, "composite_backward: null pointer");
-    MOFA_REQUIRE(n_rays > 0 && S >= 2 && S <= 256, "composite_backward: need 2 <= S <= 256 (got %d)", S);
+    MOFA_REQUIRE(n_rays > 0 && S >= 2 && S <= kMaxPasses * 256, "composite_backward: need 2 <= S <= %d (got %d)", kMaxPasses * 256, S);
     const dim3 grid(blocks_for(n_rays, kWavesPerBlock)), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define MOFA_CB(SPL)                                                                                                \
@@ -370,7 +513,10 @@ int mofa_composite_backward(const float* raw, const float* z, int64_t z_row_stri
                        (long long)n_rays, S, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_weights, d_raw, d_rays_d)
     if (S <= 64) MOFA_CB(1);
     else if (S <= 128) MOFA_CB(2);
-    else MOFA_CB(4);
+    else if (S <= 256) MOFA_CB(4);
+    else
+        hipLaunchKernelGGL(k_composite_backward_long, grid, block, 0, st, raw, z, (long long)z_row_stride, rays_d, noise, (long long)n_rays,
+                           S, white_bkgd, g_rgb, g_disp, g_acc, g_depth, g_weights, d_raw, d_rays_d);
 #undef MOFA_CB
     return check_launch("k_composite_backward");
 }

@@ -1192,6 +1192,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
 #endif
                 }
             }
+            // Another feature block of this layer follows (layers wider than 256): its first LDS-DMA requests land in stage 0, where the
+            // staged epilogue's wave-private windows live — a faster wave must not overwrite a window its neighbour is still reading.
+            if (nbase + BNMAX < np) __syncthreads();
             }   // feature blocks
             // this workgroup's stores of layer li feed its own loads of layer li+1
             __threadfence_block();

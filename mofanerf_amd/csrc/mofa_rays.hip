@@ -156,13 +156,103 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
     }
 }
 
+// Rays with more than 256 samples (the reference has no limit: N_samples / N_importance are free flags, tools/config_parser.py):
+// the same wavefront-per-ray scheme walked in PASSES of 256 samples (lane l owns samples [256 p + 4 l, +4) of pass p).  The
+// transmittance reaching a pass is carried in a register (product of every earlier (1 - alpha + 1e-10)), the five ray sums are
+// accumulated per lane across the passes and reduced once at the end.
+__global__ __launch_bounds__(256) void k_composite_long(const float* __restrict__ raw, const float* __restrict__ z,
+                                                        long long z_row_stride, const float* __restrict__ rays_d,
+                                                        const float* __restrict__ noise, long long n_rays, int S,
+                                                        int white_bkgd, float* __restrict__ rgb_out,
+                                                        float* __restrict__ disp_out, float* __restrict__ acc_out,
+                                                        float* __restrict__ depth_out, float* __restrict__ weights_out) {
+    constexpr int SPL = 4;
+    const int lane = threadIdx.x & 63;
+    const long long ray = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+    const float dnorm = __fsqrt_rn(dx * dx + dy * dy + dz * dz);
+    const float* zr = z + ray * z_row_stride;
+    const f32x4* rr = (const f32x4*)(raw + ray * (long long)S * 4);
+    float carry = 1.0f;                                   // transmittance in front of the current pass
+    float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+    for (int base = 0; base < S; base += 64 * SPL) {
+        float zv[SPL + 1], alpha[SPL], cr[SPL], cg[SPL], cb[SPL];
+        const int s0 = base + lane * SPL;
+#pragma unroll
+        for (int t = 0; t <= SPL; ++t) zv[t] = (s0 + t < S) ? zr[s0 + t] : 0.f;
+        float run = 1.0f;
+#pragma unroll
+        for (int t = 0; t < SPL; ++t) {
+            const int s = s0 + t;
+            if (s < S) {
+                const f32x4 v = rr[s];
+                float dist = (s + 1 < S) ? (zv[t + 1] - zv[t]) : 1e10f;
+                dist = dist * dnorm;
+                float sig = v.w;
+                if (noise) sig = sig + noise[ray * (long long)S + s];
+                sig = relu_np(sig);
+                alpha[t] = 1.0f - expf(-sig * dist);
+                cr[t] = 1.0f / (1.0f + expf(-v.x));
+                cg[t] = 1.0f / (1.0f + expf(-v.y));
+                cb[t] = 1.0f / (1.0f + expf(-v.z));
+                run = run * ((1.0f - alpha[t]) + 1e-10f);
+            } else {
+                alpha[t] = 0.f, cr[t] = cg[t] = cb[t] = 0.f;
+            }
+        }
+        float incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl = incl * up;
+        }
+        float T = __shfl_up(incl, 1, 64);
+        if (lane == 0) T = 1.0f;
+        T = carry * T;
+        carry = carry * __shfl(incl, 63, 64);
+#pragma unroll
+        for (int t = 0; t < SPL; ++t) {
+            const int s = s0 + t;
+            if (s < S) {
+                const float w = alpha[t] * T;
+                weights_out[ray * (long long)S + s] = w;
+                sr += w * cr[t], sg += w * cg[t], sb += w * cb[t];
+                sd += w * zv[t];
+                sa += w;
+                T = T * ((1.0f - alpha[t]) + 1e-10f);
+            }
+        }
+    }
+    sr = wave_sum(sr), sg = wave_sum(sg), sb = wave_sum(sb), sd = wave_sum(sd), sa = wave_sum(sa);
+    if (lane == 0) {
+        if (white_bkgd) {
+            const float bg = 1.0f - sa;
+            sr += bg, sg += bg, sb += bg;
+        }
+        rgb_out[ray * 3] = sr, rgb_out[ray * 3 + 1] = sg, rgb_out[ray * 3 + 2] = sb;
+        const float q = __fdiv_rn(sd, sa);
+        disp_out[ray] = (q != q) ? q : __fdiv_rn(1.0f, fmaxf(1e-10f, q));
+        acc_out[ray] = sa;
+        depth_out[ray] = sd;
+    }
+}
+
 // ---- sample_pdf + sort(cat) + std (tools/run_nerf_helpers.py:203-247; render_class.py:324-328,345) ----
 // One wavefront per ray.  B = S-1 bin edges z_mid, B-1 = S-2 interior weights.
 // cdf follows the CPU reference: cumsum accumulates in double and rounds every prefix to float.
-constexpr int kMaxS = 256, kMaxNi = 256;
+// LDS per ray (= per wavefront): S + Ni merged positions, S bin edges, S cdf entries.  The block carries as many waves (1, 2
+// or 4) as fit in 64 KiB, so the shipped 64 + 64 runs four rays per workgroup and a 4096 + 4096 ray still has a wave to itself.
+constexpr int kPdfLdsFloats = 16384;   // 64 KiB
 
 // BINS = true is the plain `sample_pdf(bins, weights, N)` entry (mofa_sample_pdf): `z` holds the B bin edges themselves
 // (S := B), `weights` the B-1 bin weights, and nothing is merged (z_fine / z_std may be NULL).
+inline long long pdf_lds_floats(int S, int Ni) { return 3ll * S + Ni; }
+inline int pdf_waves(int S, int Ni) {
+    const long long per = pdf_lds_floats(S, Ni);
+    return per * 4 <= kPdfLdsFloats ? 4 : (per * 2 <= kPdfLdsFloats ? 2 : 1);
+}
+
 template <bool BINS>
 __global__ __launch_bounds__(256) void k_sample_pdf_merge(const float* __restrict__ z, long long z_row_stride,
                                                           const float* __restrict__ weights,
@@ -170,15 +260,13 @@ __global__ __launch_bounds__(256) void k_sample_pdf_merge(const float* __restric
                                                           long long n_rays, int S, int Ni,
                                                           float* __restrict__ z_samples, float* __restrict__ z_fine,
                                                           float* __restrict__ z_std) {
-    __shared__ float s_all[kWavesPerBlock][kMaxS + kMaxNi];  // [0,S): coarse z, [S,S+Ni): new samples
-    __shared__ float s_bins[kWavesPerBlock][kMaxS];
-    __shared__ float s_cdf[kWavesPerBlock][kMaxS];
+    extern __shared__ __attribute__((aligned(16))) float s_pdf[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long ray = (long long)blockIdx.x * kWavesPerBlock + wv;
+    const long long ray = (long long)blockIdx.x * (blockDim.x >> 6) + wv;
     if (ray >= n_rays) return;  // wave-uniform; no block-level barrier is used below
-    float* all = s_all[wv];
-    float* bins = s_bins[wv];
-    float* cdf = s_cdf[wv];
+    float* all = s_pdf + (long long)wv * (3ll * S + Ni);  // [0,S): coarse z, [S,S+Ni): new samples
+    float* bins = all + S + Ni;                            // [S]
+    float* cdf = bins + S;                                 // [S]
     const float* zr = z + ray * z_row_stride;
     const int B = BINS ? S : S - 1;   // len(bins) == len(cdf)
     const int NW = B - 1;             // bin weights (the interior weights [1:-1] of the S coarse samples)
@@ -291,7 +379,7 @@ int mofa_composite_forward(const float* raw, const float* z, int64_t z_row_strid
                            const float* noise, int64_t n_rays, int32_t S, int32_t white_bkgd, float* rgb,
                            float* disp, float* acc, float* depth, float* weights, void* stream) {
     MOFA_REQUIRE(raw && z && rays_d && rgb && disp && acc && depth && weights, "composite_forward: null pointer");
-    MOFA_REQUIRE(n_rays > 0 && S >= 2 && S <= 256, "composite_forward: need 2 <= S <= 256 (got %d)", S);
+    MOFA_REQUIRE(n_rays > 0 && S >= 2, "composite_forward: need S >= 2 (got %d)", S);
     const dim3 grid(blocks_for(n_rays, kWavesPerBlock)), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define MOFA_COMPOSITE(SPL)                                                                                     \
@@ -299,7 +387,10 @@ int mofa_composite_forward(const float* raw, const float* z, int64_t z_row_strid
                        (long long)n_rays, S, white_bkgd, rgb, disp, acc, depth, weights)
     if (S <= 64) MOFA_COMPOSITE(1);
     else if (S <= 128) MOFA_COMPOSITE(2);
-    else MOFA_COMPOSITE(4);
+    else if (S <= 256) MOFA_COMPOSITE(4);
+    else
+        hipLaunchKernelGGL(k_composite_long, grid, block, 0, st, raw, z, (long long)z_row_stride, rays_d, noise, (long long)n_rays, S,
+                           white_bkgd, rgb, disp, acc, depth, weights);
 #undef MOFA_COMPOSITE
     return check_launch("k_composite");
 }
@@ -308,9 +399,11 @@ int mofa_sample_pdf_merge(const float* z, int64_t z_row_stride, const float* wei
                           int64_t u_row_stride, int64_t n_rays, int32_t S, int32_t Ni, float* z_samples,
                           float* z_fine, float* z_std, void* stream) {
     MOFA_REQUIRE(z && weights && u && z_samples && z_fine && z_std, "sample_pdf_merge: null pointer");
-    MOFA_REQUIRE(n_rays > 0 && S >= 4 && S <= kMaxS && Ni >= 1 && Ni <= kMaxNi,
-                 "sample_pdf_merge: need 4 <= S <= %d, 1 <= Ni <= %d", kMaxS, kMaxNi);
-    hipLaunchKernelGGL(k_sample_pdf_merge<false>, dim3(blocks_for(n_rays, kWavesPerBlock)), dim3(256), 0,
+    MOFA_REQUIRE(n_rays > 0 && S >= 4 && Ni >= 1 && pdf_lds_floats(S, Ni) <= kPdfLdsFloats,
+                 "sample_pdf_merge: need S >= 4, Ni >= 1 and 3 S + Ni <= %d (one ray's positions, bins and cdf live in 64 KiB of LDS); got %d, %d",
+                 kPdfLdsFloats, S, Ni);
+    const int wv = pdf_waves(S, Ni);
+    hipLaunchKernelGGL(k_sample_pdf_merge<false>, dim3(blocks_for(n_rays, wv)), dim3(64 * wv), (size_t)wv * pdf_lds_floats(S, Ni) * sizeof(float),
                        (hipStream_t)stream, z, (long long)z_row_stride, weights, u, (long long)u_row_stride,
                        (long long)n_rays, S, Ni, z_samples, z_fine, z_std);
     return check_launch("k_sample_pdf_merge");
@@ -319,9 +412,10 @@ int mofa_sample_pdf_merge(const float* z, int64_t z_row_stride, const float* wei
 int mofa_sample_pdf(const float* bins, int64_t bins_row_stride, const float* weights, const float* u, int64_t u_row_stride,
                     int64_t n_rays, int32_t n_bins, int32_t Ni, float* samples, void* stream) {
     MOFA_REQUIRE(bins && weights && u && samples, "sample_pdf: null pointer");
-    MOFA_REQUIRE(n_rays > 0 && n_bins >= 3 && n_bins <= kMaxS && Ni >= 1 && Ni <= kMaxNi,
-                 "sample_pdf: need 3 <= n_bins <= %d, 1 <= Ni <= %d", kMaxS, kMaxNi);
-    hipLaunchKernelGGL(k_sample_pdf_merge<true>, dim3(blocks_for(n_rays, kWavesPerBlock)), dim3(256), 0,
+    MOFA_REQUIRE(n_rays > 0 && n_bins >= 3 && Ni >= 1 && pdf_lds_floats(n_bins, Ni) <= kPdfLdsFloats,
+                 "sample_pdf: need n_bins >= 3, Ni >= 1 and 3 n_bins + Ni <= %d; got %d, %d", kPdfLdsFloats, n_bins, Ni);
+    const int wv = pdf_waves(n_bins, Ni);
+    hipLaunchKernelGGL(k_sample_pdf_merge<true>, dim3(blocks_for(n_rays, wv)), dim3(64 * wv), (size_t)wv * pdf_lds_floats(n_bins, Ni) * sizeof(float),
                        (hipStream_t)stream, bins, (long long)bins_row_stride, weights, u, (long long)u_row_stride,
                        (long long)n_rays, n_bins, Ni, samples, (float*)nullptr, (float*)nullptr);
     return check_launch("k_sample_pdf");

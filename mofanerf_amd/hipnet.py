@@ -6,6 +6,7 @@ current stream.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -20,10 +21,14 @@ def unwrap(net):
 
 
 class HipNet:
-    def __init__(self, net: NeRF):
+    def __init__(self, net: NeRF, weak: bool = False):
+        """``weak``: keep only a weak reference to the module (the Linear children are still held) — for caches keyed weakly on the
+        module itself (model._EMBEDDED_CACHE): a strong back-reference from the value would keep the key alive for ever."""
         if not isinstance(net, NeRF):
             raise lib.MofaError(f"expected mofanerf_amd.model.NeRF, got {type(net).__name__}")
-        self.net = net
+        self._net_strong = None if weak else net
+        self._net_weak = weakref.ref(net)
+        self.D, self.W = int(net.D), int(net.W)
         self.shape = lib.NetShape(net.D, net.W)
         self._L = lib.load()
         self._linears = net.ordered_linears()
@@ -39,6 +44,10 @@ class HipNet:
         self._split: Optional[torch.Tensor] = None
         self._split_key = None
         self._nominal, self._nominal_key = None, None
+
+    @property
+    def net(self) -> Optional[NeRF]:
+        return self._net_strong if self._net_strong is not None else self._net_weak()
 
     def invalidate(self):
         """Forget the packed / transposed / split copies of the weights (they are rebuilt on the next call).  Needed only
@@ -142,11 +151,13 @@ class HipNet:
     def _nominal_pack(self):
         """Weights packed WITHOUT folding: every input column is a per-point column, in the reference's concat order
         ([pts93], [bm50 | xyz], [bm50 | xyz | h], [tex256 | sigma], [tex256 | sigma | h], [views27 | rgbCodes])."""
-        key = self._key()
+        # the nominal pack also caches bias COPIES (padded), so its key covers the biases too — a bias-only update (a bias-only
+        # optimizer, bias.copy_(...)) must not be served stale rows; the folded path re-reads biases on every call
+        key = self._key() + tuple((l.bias.data_ptr(), l.bias._version) for l in self._linears)
         if getattr(self, "_nominal", None) is not None and self._nominal_key == key:
             return self._nominal
         L, st = self._L, lib.stream()
-        D, W = self.net.D, self.net.W
+        D, W = self.D, self.W
         Wp, Hp = (W + 63) // 64 * 64, (W // 2 + 63) // 64 * 64
         ws, bs = self._weights()
         dev = ws[0].device
@@ -191,7 +202,7 @@ class HipNet:
         (nothing is assumed constant here); the concatenations are free because a panel buffer IS a K-major concat: the
         producer of ``xyz`` / ``sigma`` / ``rgbCodes`` writes behind the code panels of one buffer.  Inference only."""
         L, st = self._L, lib.stream()
-        D, W = self.net.D, self.net.W
+        D, W = self.D, self.W
         n = int(pts93.shape[0])
         Wp, Hp = (W + 63) // 64 * 64, (W // 2 + 63) // 64 * 64
         Mp = (n + 255) // 256 * 256

@@ -99,7 +99,7 @@ class NeRF(nn.Module):
             raise lib.MofaError("NeRF.forward needs its parameters and inputs on the GPU (net.cuda()); there is no CPU path")
         h = _EMBEDDED_CACHE.get(self)        # device-side cache kept OUTSIDE the module: deepcopy / pickling of the module stay plain
         if h is None:
-            h = _EMBEDDED_CACHE[self] = HipNet(self)
+            h = _EMBEDDED_CACHE[self] = HipNet(self, weak=True)      # weak back-reference: the entry dies with the module
         return h.forward_embedded(input_pts, input_bmCodes, input_views, input_uvCodes)
 
 

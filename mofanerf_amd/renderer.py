@@ -207,11 +207,22 @@ class Renderer(torch.nn.Module):
     def batchify_rays(self, chunk=1024 * 32, **kwargs):
         """Render ``self.rays`` in chunks of ``chunk`` rays (render_class.py:111-123)."""
         all_ret: Dict[str, list] = {}
-        for i in range(0, self.rays.shape[0], chunk):
-            ret = self.render_rays([i, i + chunk], **kwargs)
-            for k, v in ret.items():
-                all_ret.setdefault(k, []).append(v)
+        direct = getattr(self, "_rays_ref", None) is not self.rays
+        if direct:      # called on a caller-built self.rays: fold the per-call codes ONCE for all chunks (render_rays alone folds per call)
+            self._fold_direct(kwargs.get("network_fn"), kwargs.get("network_fine"))
+            self._folds_hoisted = True
+        try:
+            for i in range(0, self.rays.shape[0], chunk):
+                ret = self.render_rays([i, i + chunk], **kwargs)
+                for k, v in ret.items():
+                    all_ret.setdefault(k, []).append(v)
+        finally:
+            self._folds_hoisted = False
         return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in all_ret.items()}
+
+    def _fold_direct(self, network_fn, network_fine):
+        self._folded_coarse = self._fold_codes(network_fn, self.decoding_texCodes).clone()
+        self._folded_fine = self._fold_codes(network_fine, self.decoding_texCodes).clone() if network_fine is not None else None
 
     # ------------------------------------------------------------------------------------------------
     def render_rays(self, ray_batch, network_fn, N_samples, retraw=False, lindisp=False, perturb=0., N_importance=0,
@@ -224,14 +235,14 @@ class Renderer(torch.nn.Module):
         if rays.shape[-1] <= 8:
             raise NotImplementedError(_NO_VIEWDIRS)
         rays_o, rays_d, vd = (rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous(), rays[:, 8:11].contiguous())
-        S = int(N_samples)
-        if S > 256 or (N_importance > 0 and S + int(N_importance) > 256):
-            raise NotImplementedError(f"the compositing / resampling kernels hold one ray per wavefront with at most 4 samples per "
-                                      f"lane: N_samples and N_samples + N_importance must be <= 256 (got {S}, {S + int(N_importance)})")
+        S = int(N_samples)      # any count: up to 256 samples a ray is one pass of its wavefront, beyond that the kernels walk passes
         st = lib.stream()
         # near / far: the scalar fast path when render()/render_fitting() set them for THIS self.rays; otherwise (per-ray
         # bounds, or batchify_rays()/render_rays() called directly on a caller-built self.rays) they are read from columns 6:8
-        scalar_bounds = getattr(self, "_rays_ref", None) is self.rays and self._near is not None
+        # (an in-place edit of self.rays after render() — e.g. per-ray bounds written into columns 6:8 — bumps its version counter and
+        #  drops the scalar fast path: the columns are what the reference's render_rays reads, models/render_class.py:262-264)
+        scalar_bounds = (getattr(self, "_rays_ref", None) is self.rays and self._near is not None
+                         and self.rays._version == getattr(self, "_rays_version", -1))
         t_row = self._const_row(("t", S), lambda: torch.linspace(0., 1., steps=S), dev)
         if scalar_bounds:
             near, far = self._near, self._far
@@ -316,12 +327,10 @@ class Renderer(torch.nn.Module):
                 main.wait_stream(s_)
             return raw
 
-        if getattr(self, "_rays_ref", None) is not self.rays:
+        if getattr(self, "_rays_ref", None) is not self.rays and not getattr(self, "_folds_hoisted", False):
             # called directly on a caller-built self.rays (the reference documents batchify_rays / render_rays as callable once
-            # self.rays, shapeCodes, expType and decoding_texCodes are set): fold the per-call codes here
-            self._folded_coarse = self._fold_codes(network_fn, self.decoding_texCodes).clone()
-            self._folded_fine = (self._fold_codes(network_fine, self.decoding_texCodes).clone()
-                                 if network_fine is not None else None)
+            # self.rays, shapeCodes, expType and decoding_texCodes are set): fold the per-call codes here (batchify_rays hoists it)
+            self._fold_direct(network_fn, network_fine)
         raw = network(network_fn, self._folded_coarse, z, z_stride, S)
         c = composite(raw, z, z_stride, S, noise_for(S))
         ret = {"rgb_map": c["rgb"], "disp_map": c["disp"], "acc_map": c["acc"]}
@@ -406,6 +415,7 @@ class Renderer(torch.nn.Module):
             self._near = self._far = None
         self.rays = torch.cat([rays_o, rays_d, ncol, fcol, viewdirs], -1)
         self._rays_ref = self.rays          # (a reference, not an id: ids are reused after garbage collection)
+        self._rays_version = self.rays._version
         self.decoding_texCodes = tex_code
         # inference (torch.no_grad(), as the reference's render-only call sites run): pure HIP, nothing recorded;
         # with autograd enabled (fitting / training) the tape-keeping forward + HIP backward path is used

@@ -147,6 +147,9 @@ def render_pair(H, K, angle, arch, chunk, netchunk, device="cuda", seed=0, n_ray
     return hip, ref, env
 
 
+ABS_CAP = 0.05     # absolute per-ray sanity cap on |rgb| / |acc| differences, envelope or not (largest legitimate move measured: 3.1e-2)
+
+
 def envelope_stats(err, env, tol=1e-4, what="rgb"):
     """Is an implementation's per-ray error INSIDE the reference's own envelope?
 
@@ -155,11 +158,14 @@ def envelope_stats(err, env, tol=1e-4, what="rgb"):
     resampling is discontinuous (tools/run_nerf_helpers.py:243) and the positional encoding amplifies a 1-ulp move of a sample
     by 2^9, so a small set of rays moves by up to 1e-2 in the REFERENCE ITSELF; which rays, and by how much, is what the
     envelope records.  Asserted, with R rays (slack = 3 rays):
-      * frame level — fraction of rays over ``tol`` <= 2x the worst draw's; mean error <= 2x the worst draw's mean;
-        max error <= 1.5x the envelope's max;
-      * per ray — err[r] <= max(tol, 1.5 * max_k env[k, r]) for >= 97 % of the rays (a flip the K draws did not sample is an
-        outlier, and outliers are budgeted, not waved through: each must still be below 1.5x the envelope's max);
+      * frame level — fraction of rays over ``tol`` <= 1.4x the worst draw's; mean error <= 1.3x the worst draw's mean;
+        max error <= 1.25x the envelope's max (+ tol) and, whatever the envelope says, <= ``ABS_CAP`` for EVERY ray;
+      * per ray — err[r] <= max(tol, 1.5 * max_k env[k, r]) for >= 98.5 % of the rays (a flip the K draws did not sample is an
+        outlier, and outliers are budgeted, not waved through: each is still below 1.25x the envelope's max);
       * rays that no draw moves by more than 1e-5 ("stable", the large majority) exceed ``tol`` in <= 2 % of the cases.
+    The multipliers sit just above what the shipped kernels measure on MI355X against the committed reference fixtures
+    (config 1, 4,096 rays: 1.26x / 1.18x / 1.00x / 98.9 %; every other fixture: <= 1.13x / <= 1.05x / <= 1.0x / >= 98.8 %), so that a
+    regression which doubled the resampler's flip rate fails (round-2 gates were 2x / 2x / 1.5x / 97 %).
     Returns the measured numbers."""
     err, env = np.asarray(err, np.float64), np.asarray(env, np.float64)
     R = err.shape[0]
@@ -172,21 +178,23 @@ def envelope_stats(err, env, tol=1e-4, what="rgb"):
           "ref_max": float(env.max()), "inside": float(inside.mean()), "stable": float(stable.mean()),
           "stable_over": float((err[stable] > tol).mean()) if stable.any() else 0.0}
     msg = f"{what}: {st}"
-    assert st["frac_over"] <= 2 * st["ref_frac_over"] + slack, msg
-    assert st["mean"] <= 2 * st["ref_mean"] + 2e-6, msg
-    assert st["max"] <= 1.5 * st["ref_max"] + tol, msg
-    assert st["inside"] >= 0.97 - slack, msg
+    assert st["frac_over"] <= 1.4 * st["ref_frac_over"] + slack, msg
+    assert st["mean"] <= 1.3 * st["ref_mean"] + 2e-6, msg
+    assert st["max"] <= 1.25 * st["ref_max"] + tol and st["max"] <= ABS_CAP, msg
+    assert st["inside"] >= 0.985 - slack, msg
     assert st["stable_over"] <= 0.02 + slack, msg
     return st
 
 
-def compare_render(hip, ref, env, u=None, tol=1e-4, verbose=True):
+def compare_render(hip, ref, env, u=None, tol=1e-4, verbose=True, expect_ab=None):
     """Parity of a coarse+fine render (dicts of numpy arrays, rays flat).
 
     * coarse outputs (rgb0/acc0/disp0, coarse weights): every ray, ``tol``;
     * resampled positions: every disagreement must be EXPLAINED (see :func:`classify_samples`), and the fraction of rays
-      whose 64 new positions all agree within a few ulp must be at least half of what the reference shows against ITSELF under
-      ulp-level noise (``env["pert_agree"]``);
+      whose 64 new positions all agree within a few ulp (tiers A + B) must be at least 0.6x what the reference shows against
+      ITSELF under ulp-level noise (``env["pert_agree"]``; measured 0.65x - 1.0x) and, for the committed reference fixtures, must
+      not drop below the number measured on MI355X with the shipped kernels (``expect_ab``, deterministic across boxes) by more
+      than 0.03;
     * fine outputs (rgb/acc/disp/z_std), by how the ray's 64 new sample positions compare:
         A  bit-identical positions ......... ``tol`` (1e-4; only MLP/composite rounding is left)
         B  all within a few ulp of z ....... 1e-3: the reference amplifies a 1-ulp position change by 2^9*|d| in the
@@ -215,7 +223,9 @@ def compare_render(hip, ref, env, u=None, tol=1e-4, verbose=True):
     tier_b = agree.all(-1).numpy() & ~tier_a
     out["frac_A_B_rest"] = [round(float(t.mean()), 3) for t in (tier_a, tier_b, ~(tier_a | tier_b))]
     out["ref_self_agree"] = round(float(np.asarray(env["pert_agree"]).mean(1).min()), 3)
-    assert (tier_a | tier_b).mean() >= 0.5 * out["ref_self_agree"] - 3.0 / zr.shape[0], out
+    assert (tier_a | tier_b).mean() >= 0.6 * out["ref_self_agree"] - 3.0 / zr.shape[0], out
+    if expect_ab is not None:
+        assert (tier_a | tier_b).mean() >= expect_ab - 0.03, (out, expect_ab)
     for name, mask, t in (("A", tier_a, tol), ("B", tier_b, 1e-3)):
         if not mask.any():
             continue

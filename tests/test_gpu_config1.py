@@ -88,7 +88,7 @@ def test_config1_end_to_end_inside_reference_envelope(golden):
     torch.cuda.synchronize()
     hip = to_np(dict(rgb=rgb, disp=disp, acc=acc, rgb0=ex["rgb0"], disp0=ex["disp0"], acc0=ex["acc0"], z_std=ex["z_std"],
                      z_samples=ex["_z_samples"], z_fine=ex["_z_fine"], weights_coarse=ex["_weights0"]))
-    out = compare_render(hip, g, g)
+    out = compare_render(hip, g, g, expect_ab=0.710)          # 71 % of the rays resample within a few ulp (the reference against itself: 75 %)
     assert out["psnr_db"] >= 70.0, out                       # the reference against itself under ulp noise: 74.7 - 76.5 dB
     assert (np.diff(hip["z_fine"].reshape(H * H, -1), axis=-1) >= 0).all()
 

@@ -27,7 +27,7 @@ def _codes():
     return [t.to(DEV) for t in synth.codes(0)]
 
 
-@pytest.mark.parametrize("Ns,Ni", [(32, 16), (64, 0), (48, 80), (16, 128)])
+@pytest.mark.parametrize("Ns,Ni", [(32, 16), (64, 0), (48, 80), (16, 128), (256, 256), (300, 212), (520, 0)])
 def test_ragged_sample_counts_and_coarse_only(Ns, Ni):
     render, kw, _ = make_product(ARCH, 0, 4096, DEV, N_samples=Ns, N_importance=Ni)
     K, ro, rd = _rays(8)

@@ -21,8 +21,11 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-@pytest.mark.parametrize("S,white,use_noise", [(64, False, False), (128, True, True), (37, False, True), (200, True, False)])
+@pytest.mark.parametrize("S,white,use_noise", [(64, False, False), (128, True, True), (37, False, True), (200, True, False),
+                                               (257, False, True), (300, True, True), (1000, False, False)])
 def test_composite_backward_vs_autograd(S, white, use_noise):
+    """S > 256: the multi-pass kernels (k_composite_long / k_composite_backward_long; transmittance and suffix sums carried across
+    passes of 256 samples) — the reference has no sample limit (models/render_class.py:291-335)."""
     rng = np.random.default_rng(S)
     R = 33
     raw = T(rng.normal(0, 1.2, (R, S, 4)).astype(np.float32))
@@ -46,6 +49,9 @@ def test_composite_backward_vs_autograd(S, white, use_noise):
     o = CompositeFn.apply(rg, z.to(DEV), S, dg, None if noise is None else noise.to(DEV).contiguous(), white)
     loss_of(*o).backward()
     torch.cuda.synchronize()
+    for name, got, want in zip(("rgb", "acc", "depth", "weights"), (o[0], o[2], o[3], o[4]), (rgb, acc, depth, w)):   # the forward itself
+        assert rel_err(got.detach().cpu(), want.detach()) < 5e-6, name
+    nan_equal_close(o[1].detach().cpu().numpy(), disp.detach().float().numpy(), 1e-6, 1e-5)
     assert rel_err(rg.grad.cpu(), r64.grad) < 2e-5
     # row 0 (acc == 0): torch's autograd returns NaN for d|rays_d| through where(isnan(disp), 0, disp) (0 * NaN); the HIP
     # backward returns the finite value 0 — compare the other rows, and require finiteness of ours

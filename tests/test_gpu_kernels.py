@@ -585,10 +585,12 @@ def test_layer_pipeline_race_screen_full_size():
     nan_equal_close(yr.cpu().numpy(), want.cpu().numpy(), 3e-5)
 
 
-@pytest.mark.parametrize("D,W,R,S", [(8, 256, 40, 64), (10, 96, 9, 128), (8, 64, 130, 64), (8, 192, 17, 32)])
+@pytest.mark.parametrize("D,W,R,S", [(8, 256, 40, 64), (10, 96, 9, 128), (8, 64, 130, 64), (8, 192, 17, 32), (10, 512, 300, 64), (8, 320, 150, 64)])
 def test_persistent_fused_network_is_bit_identical_to_per_layer_launches(D, W, R, S, knob):
     """Widths <= 256 run the whole MLP as ONE persistent launch (k_mlp_fused); it must reproduce the per-layer path
-    bit for bit, in inference mode (recycled buffers) and in tape mode (every layer output kept)."""
+    bit for bit, in inference mode (recycled buffers) and in tape mode (every layer output kept).  Widths 512 / 320: several
+    256-feature blocks per layer inside one workgroup (MOFA_FUSED=1 forces the persistent kernel there) — the epilogue's LDS
+    windows of one block must not be overwritten by the next block's first operand fetch."""
     from mofanerf_amd.autograd import NetFn, fold_torch, view_bias_torch
     from mofanerf_amd.hipnet import HipNet
     from mofanerf_amd.model import NeRF

@@ -30,14 +30,14 @@ def _fit(g, **over):
     return out
 
 
-def _check(g, out, env, u=None, tol=1e-4):
+def _check(g, out, env, u=None, tol=1e-4, expect_ab=None):
     rgb, disp, acc, ex = out
     H = int(g["H"])
     assert rgb.shape == (H, H, 3) and disp.shape == (H, H) and ex["rgb0"].shape == (H, H, 3)
     assert ex["losses"] == 0
     hip = to_np(dict(rgb=rgb, disp=disp, acc=acc, rgb0=ex["rgb0"], disp0=ex["disp0"], acc0=ex["acc0"], z_std=ex["z_std"],
                      z_samples=ex["_z_samples"], z_fine=ex["_z_fine"], weights_coarse=ex["_weights0"]))
-    errs = compare_render(hip, g, env, u=u, tol=tol)
+    errs = compare_render(hip, g, env, u=u, tol=tol, expect_ab=expect_ab)
     zf = hip["z_fine"].reshape(H * H, -1)
     assert (np.diff(zf, axis=-1) >= 0).all()                   # merged sample positions are sorted
     return errs
@@ -46,13 +46,13 @@ def _check(g, out, env, u=None, tol=1e-4):
 def test_render_fitting_small_golden(golden):
     """256 rays, coarse 8x64 + fine 10x128, chunk 96 (3 ragged chunks), rays generated on the device."""
     g = golden("e2e_small.npz")
-    _check(g, _fit(g), golden("e2e_small_env.npz"))
+    _check(g, _fit(g), golden("e2e_small_env.npz"), expect_ab=0.434)      # rays with all 64 resampled positions within a few ulp (MI355X, round 2/3)
 
 
 def test_render_fitting_true_size_golden(golden):
     """64 rays through the SHIPPED network sizes (coarse 256x8, fine 1024x10)."""
     g = golden("e2e_true.npz")
-    _check(g, _fit(g), golden("e2e_true_env.npz"))
+    _check(g, _fit(g), golden("e2e_true_env.npz"), expect_ab=0.687)
 
 
 def test_render_fitting_stochastic_golden(golden):
@@ -61,7 +61,7 @@ def test_render_fitting_stochastic_golden(golden):
     np.random.seed(0)
     u = torch.Tensor(np.random.rand(int(g["H"]) ** 2, 64))
     _check(g, _fit(g, perturb=1.0, raw_noise_std=float(g["noise"]), white_bkgd=True, pytest=True),
-           golden("e2e_small_stoch_env.npz"), u=u)
+           golden("e2e_small_stoch_env.npz"), u=u, expect_ab=0.422)
 
 
 def test_render_with_texture_encoder_golden(golden):

@@ -215,3 +215,23 @@ print('REFERENCE_LOADED', float(fine.rgb_linear.weight.sum()))
     assert out.returncode == 0 and "REFERENCE_LOADED" in out.stdout, out.stderr[-1500:]
     got = float(out.stdout.split("REFERENCE_LOADED")[1].split()[0])
     assert abs(got - float(kw["network_fine"].rgb_linear.weight.detach().sum())) < 1e-5
+
+
+def test_embedded_forward_cache_does_not_keep_modules_alive():
+    """model._EMBEDDED_CACHE maps NeRF -> HipNet weakly; the HipNet it stores holds only a WEAK back-reference to the module
+    (HipNet(net, weak=True)), so dropping the module drops the entry and its packed device panels."""
+    import gc
+    import weakref
+    from mofanerf_amd.hipnet import HipNet
+    from mofanerf_amd.model import NeRF, _EMBEDDED_CACHE
+    n0 = len(_EMBEDDED_CACHE)
+    net = NeRF(D=8, W=64, input_ch=93, input_ch_views=27, input_ch_textureCodes=256, input_ch_shapeCodes=50, use_viewdirs=True)
+    h = _EMBEDDED_CACHE[net] = HipNet(net, weak=True)
+    assert h.net is net and (h.D, h.W) == (8, 64)
+    ref = weakref.ref(net)
+    del net, h
+    gc.collect()
+    assert ref() is None and len(_EMBEDDED_CACHE) == n0
+    strong = HipNet(NeRF(D=8, W=64, input_ch=93, input_ch_views=27, input_ch_textureCodes=256, input_ch_shapeCodes=50, use_viewdirs=True))
+    gc.collect()
+    assert strong.net is not None                     # the renderer's own HipNets keep their module (default: strong)
