@@ -359,6 +359,7 @@ class Renderer(torch.nn.Module):
                    "disp0": c["disp"], "acc0": c["acc"], "z_std": z_std}
             if verbose:
                 ret["_z_samples"], ret["_z_fine"], ret["_weights0"] = z_samples, z_fine, c["weights"]
+                ret["_z_coarse"] = z if z_stride else z[None, :].expand(R, S)
         if retraw:
             ret["raw"] = raw
         return ret
