@@ -46,11 +46,11 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Pe
 H = W = 512
 ARCH = (8, 256, 10, 1024)
 N_SAMPLES, N_IMPORTANCE = 64, 64
-KERNELS = ["mofa::k_layer<128,false,true,false,false,false,true> (fp32 MFMA Linear+bias+ReLU, software-pipelined K loop)",
+KERNELS = ["mofa::k_layer<128,false,false,false,false,true,mofa::ShippedPolicy> (fp32 MFMA Linear+bias+ReLU, software-pipelined K loop; template = <BN,L0,BWD,HH,PERRAY,PIPE,policy>)",
            "mofa::k_mlp_fused (persistent fp32-MFMA network kernel, widths <= 256)",
-           "mofa::k_layer<128,false,true,BWD=true,false,false,true> (fp32 MFMA backward-data GEMM + ReLU mask, the same K loop)",
+           "mofa::k_layer<128,false,true,false,false,true,mofa::ShippedPolicy> (BWD: fp32 MFMA backward-data GEMM + ReLU mask, the same K loop)",
            "mofa::k_wgrad<128,256> (fp32 MFMA weight-gradient GEMM, contraction over points)",
-           "mofa::k_layer<128,false,true,false,false,true,true> (the same kernel with the view layer's per-ray bias)"]
+           "mofa::k_layer<128,false,false,false,true,true,mofa::ShippedPolicy> (PERRAY: the same kernel with the view layer's per-ray bias)"]
 
 
 def pose_spherical(phi_deg, theta_deg, radius):

@@ -30,6 +30,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden; everything declared in this header — and nothing else — is exported. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define MOFA_ABI_VERSION 1
 #define MOFA_OK 0
@@ -243,6 +247,9 @@ int mofa_sample_pdf_merge(const float* z, int64_t z_row_stride, const float* wei
 int mofa_sample_pdf(const float* bins, int64_t bins_row_stride, const float* weights, const float* u, int64_t u_row_stride,
                     int64_t n_rays, int32_t n_bins, int32_t Ni, float* samples, void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -9,15 +9,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmofanerf_hip.so")
-SOURCES = ["mofa_mlp.hip", "mofa_rays.hip", "mofa_bwd.hip", "mofa_net.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
+SOURCES = ["mofa_mlp.hip", "mofa_split.hip", "mofa_rays.hip", "mofa_bwd.hip", "mofa_net.hip"]
+# -fvisibility=hidden: the library exports exactly the C ABI of include/mofanerf_hip.h (declared under a visibility pragma there);
+# the mofa_internal_* hand-offs between the translation units stay out of the dynamic symbol table
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden", "-Wall",
          "-Wno-unused-function"]
-
-
-# compile-time switches of measurement / A-B builds (tools/ab_layer.py, tools/timeline_layer.py); an environment variable of the
-# same name turns into -D<name>=<value>.  The shipped library is built with none of them set.
-MEASUREMENT_DEFINES = ("MOFA_LAYER_WAVES", "MOFA_SPLIT_PIPELINED", "MOFA_SPLIT_FAKE", "MOFA_SETPRIO", "MOFA_TIMELINE", "MOFA_PIPE_GAP",
-                       "MOFA_ABLATE_EPILOGUE", "MOFA_STAGED_EPILOGUE")
 
 
 def csrc_digest() -> str:
@@ -47,15 +43,14 @@ def stale() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "mofanerf_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [os.path.join(HERE, "..", "include", "mofanerf_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not stale():
         return OUT
-    extra = [f"-D{k}={os.environ[k]}" for k in MEASUREMENT_DEFINES if os.environ.get(k)]
-    cmd = [hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", os.environ.get("MOFA_LIB_OUT", OUT)]
+    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -1,0 +1,474 @@
+// MEASUREMENT-ONLY translation unit (gfx950).  Built by tools/build_measure.py into build_arms/libmofanerf_measure.so — never into
+// libmofanerf_hip.so, never loaded by the product (mofanerf_amd/lib.py does not know it exists).  It instantiates the SAME layer
+// kernel source as the product (../mofa_layer.h) under other policies, plus the scheduling arms earlier rounds measured and
+// rejected, so that their numbers stay reproducible (DESIGN.md section 9 has the results):
+//   shipped            k_layer<128,..,PIPE> with ShippedPolicy (the control: must reproduce the product bit for bit)
+//   plain              the plain K loop (what MOFA_PIPE=0 selects in the product)
+//   bn64               the 64-feature tile forced for every width (4 workgroups per CU)
+//   unstaged           strided 16-byte epilogue stores instead of the LDS-window epilogue
+//   gap2 / gap3        2 / 3 MFMAs between two LDS-DMA requests of the pipelined loop (shipped: derived, 4)
+//   setprio1/3         s_setprio around every MFMA block of the plain loop
+//   waves3             __launch_bounds__(256, 3) (three workgroups per CU, spills)
+//   ring3              3-stage LDS ring twin of the plain loop (k_layer_ring3)
+//   persist / persist_dephase   persistent per-layer twin walking the tiles (k_layer_persist)
+//   timeline           per-workgroup / per-panel time stamps (mofa_measure_set_timeline)
+//   sink_epilogue      WRONG RESULTS BY DESIGN: the tile is discarded instead of stored — what a free epilogue would be worth
+// and k_mfma_peak_probe (what the fp32 matrix pipe sustains with no memory traffic at all).
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+
+#include "../mofa_layer.h"
+
+namespace mofa {
+
+// the host-side helpers of mofa_common.h, local to this library (the product's live in mofa_net.hip and are not exported)
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return MOFA_EHIP;
+    }
+    return MOFA_OK;
+}
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev < kMaxDevices ? dev : kMaxDevices - 1;
+}
+int compute_units(int device) {
+    hipDeviceProp_t prop;
+    return (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+}
+const Config& config() {
+    static const Config c{};
+    return c;
+}
+
+namespace {
+
+// ---- policies ----------------------------------------------------------------------------------------------------------------
+struct UnstagedPolicy : ShippedPolicy {
+    static constexpr bool kStagedEpilogue = false;
+};
+template <int GAP>
+struct GapPolicy : ShippedPolicy {
+    static constexpr int kPipeGap = GAP;
+};
+template <int PRIO>
+struct SetPrioPolicy : ShippedPolicy {
+    static constexpr int kSetPrio = PRIO;
+};
+struct Waves3Policy : ShippedPolicy {
+    static constexpr int kMinWaves = 3;
+};
+struct SinkPolicy : ShippedPolicy {       // timing only: results are NOT computed
+    static constexpr bool kSinkEpilogue = true;
+    template <class Acc>
+    static __device__ __forceinline__ void sink(const Acc& acc, float* y) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < (int)(sizeof(acc[0]) / sizeof(acc[0][0])); ++j) s_ += acc[i][j][0] + acc[i][j][7] + acc[i][j][15];
+        if (s_ == 123.456f) y[0] = s_;      // keeps the accumulators (and with them the K loop) alive
+    }
+};
+
+// per-workgroup stamps [tiles][8] u64 = {entry, first panel landed (K loop starts), K loop done, stores issued, HW_ID, XCC_ID, clock64
+// ticks in the K loop, -} followed by [tiles][64] per-panel stamps of the pipelined loop (kept in LDS until the end: a global store
+// at a sync point would sit in front of the next vmcnt(0) wait).  wall_clock64() = the 100 MHz constant clock.
+__device__ unsigned long long* g_timeline_dev = nullptr;
+struct TimelinePolicy : ShippedPolicy {
+    static constexpr int kExtraLds = 512;
+    struct Probe {
+        unsigned long long* tl;
+        unsigned long long* pstamp;
+        unsigned long long* pbase;
+        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tc1 = 0, tc2 = 0;
+        int logical, total, tid;
+        __device__ __forceinline__ Probe(const LayerArgs& a, int logical_, int tid_, float* lds_behind_stages, int KT)
+            : tl(g_timeline_dev), logical(logical_), total(a.total_tiles), tid(tid_) {
+            pbase = (tl && KT <= 64) ? (unsigned long long*)lds_behind_stages : nullptr;
+            pstamp = pbase;
+        }
+        __device__ __forceinline__ void entry() {
+            if (tl && tid == 0) ts0 = wall_clock64();
+        }
+        __device__ __forceinline__ void kloop_begin() {
+            if (tl && tid == 0) ts1 = wall_clock64(), tc1 = clock64();
+        }
+        __device__ __forceinline__ void panel() {
+            if (pstamp && tid == 0) *pstamp++ = wall_clock64();
+        }
+        __device__ __forceinline__ void first_panel_landed() {
+            if (pbase && tid == 0) pbase[63] = wall_clock64();      // slot 63 is never a panel stamp (KT <= 64)
+        }
+        __device__ __forceinline__ void kloop_end() {
+            if (tl) __builtin_amdgcn_s_barrier();                   // all four waves are out of the K loop
+            if (tl && tid == 0) ts2 = wall_clock64(), tc2 = clock64();
+        }
+        __device__ __forceinline__ void stores_issued() {           // wave 0: its 32 stores per lane are ISSUED (not acknowledged)
+            if (!(tl && tid == 0)) return;
+            unsigned long long* t = tl + (long long)logical * 8;
+            t[0] = ts0, t[1] = ts1, t[2] = ts2, t[3] = wall_clock64();
+            t[4] = __builtin_amdgcn_s_getreg(GETREG_IMMED(32 - 1, 0, HW_ID));
+            t[5] = __builtin_amdgcn_s_getreg(GETREG_IMMED(4 - 1, 0, 20));        // XCC_ID
+            t[6] = tc2 - tc1;
+            if (pbase) {
+                unsigned long long* pd = tl + (long long)total * 8 + (long long)logical * 64;
+                for (int i = 0; i < 64; ++i) pd[i] = pbase[i];
+            }
+        }
+    };
+};
+
+// ---- 3-stage-ring twin of k_layer<128,false,true> (MOFA_RING3=1; A/B arm) --------------------------------------------------
+// The timeline says a workgroup that is ALONE in its K loop drives the pipe at 75 %, a pair at 94 %.  In k_layer
+// the next panel's LDS-DMA is requested half a panel (2,048 MFMA cycles of ONE wave) before the barrier that waits for it; alone
+// on its SIMD a wave then sits out the rest of an L2 round trip every panel.  Here the ring has three stages (72 KiB per
+// workgroup, still two per CU): panel kt+2 is requested at the top of panel kt and waited for two panels later with a COUNTED
+// vmcnt (panel kt+1's loads may stay in flight across the barrier), one barrier per panel.  Same tiles, same arithmetic order,
+// bit-identical results.
+template <bool PERRAY>
+__global__ __launch_bounds__(256, 2) void k_layer_ring3(const LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BN = 128, BM = kRowTile, NI = 2, NJ = 4;
+    constexpr int STAGE = (BM + BN) * 16, XR = BM / 64, WR = BN / 64, LOADS = XR + WR;
+    const int per_xcd = gridDim.x >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= a.total_tiles) return;
+    const int mt = logical / a.n_tiles, nt = logical - mt * a.n_tiles;
+    const long long m0 = (long long)mt * BM;
+    const int n0 = nt * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    const int KT = a.k1p + a.k2p;
+
+    auto stage_issue = [&](int buf, int kt) {
+        float* xs = smem + buf * STAGE;
+        float* ws = xs + BM * 16;
+        const float* base = kt < a.k1p ? a.x1 : a.x2;
+        const int kk = kt < a.k1p ? kt : kt - a.k1p;
+        const float* src = base + ((long long)kk * a.m_padded + m0) * 16;
+#pragma unroll
+        for (int r = 0; r < XR; ++r) glds16(src + (r * 256 + tid) * 4, xs + (r * 256 + wave * 64) * 4);
+        const float* wsrc = a.w + ((long long)kt * a.n_padded + n0) * 16;
+#pragma unroll
+        for (int r = 0; r < WR; ++r) glds16(wsrc + (r * 256 + tid) * 4, ws + (r * 256 + wave * 64) * 4);
+    };
+
+    f32x16 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    stage_issue(0, 0);
+    if (KT > 1) stage_issue(1, 1);
+    int cur = 0, nxt2 = 2;                                  // ring positions of panel kt and of panel kt + 2
+    for (int kt = 0; kt < KT; ++kt) {
+        // this wave's loads of panel kt have landed once at most the LOADS newer ones (panel kt + 1) are still in flight
+        if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // ... and every other wave's; also: everyone is done reading panel kt - 1
+        if (kt + 2 < KT) stage_issue(nxt2, kt + 2);         // refill the stage panel kt - 1 just vacated
+        const float* xs = smem + cur * STAGE;
+        mma_panel<NI, NJ>(xs, xs + BM * 16, wm * (32 * NJ), wn * 64, lane, acc);
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+    }
+    f32x4 bv[NI][4];
+    store_tile<NI, NJ, PERRAY, false>(acc, a.bias, a.bias_rows, a.bias_row_div, a.n_padded, a.y, a.m_padded, m0 + wm * (32 * NJ),
+                                      n0 + wn * 64, a.relu, lane, bv);
+}
+
+
+// ---- persistent twin of k_layer<128,false,true> (MOFA_PERSIST=1; A/B arm) ------------------------------
+// Same tile, same panels, same K loop, same epilogue, bit-identical results.  What changes is the SCHEDULE: the grid is
+// 2 workgroups per CU and every workgroup WALKS its share of the tiles instead of exiting after one, so that
+//   (a) the 5-7 us a freed slot waits for the dispatcher's next workgroup disappears (12 rounds per 196,608-point launch),
+//   (b) the next tile's first operand panel is requested BEFORE the epilogue's 32 stores per lane are issued, so its
+//       ~2.6 us first-fetch latency overlaps the store burst instead of following it,
+//   (c) optionally (MOFA_DEPHASE=1) the 8 feature-tile workgroups of one point tile start late together by a
+//       group-specific fraction of a tile time, so that the chip's workgroups are no longer all in their epilogue at once.
+// XCD-aware walk: block b runs on XCD b % 8; XCD x owns the contiguous logical tile range [x*per, (x+1)*per) and its
+// G/8 workgroups sweep it side by side, so the 8 feature tiles of a point tile are in flight together in ONE L2.
+__global__ __launch_bounds__(256, 2) void k_layer_persist(const LayerArgs a, int per_xcd_tiles, int dephase) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BN = 128, BM = kRowTile, NI = 2, NJ = 4;
+    constexpr int STAGE = (BM + BN) * 16, XR = BM / 64, WR = BN / 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    const int KT = a.k1p + a.k2p;
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
+
+    auto tile_of = [&](int it, long long& m0, int& n0) -> bool {
+        const int local = w + it * wg_per_xcd;
+        const int logical = xcd * per_xcd_tiles + local;
+        if (local >= per_xcd_tiles || logical >= a.total_tiles) return false;
+        const int mt = logical / a.n_tiles;
+        m0 = (long long)mt * BM, n0 = (logical - mt * a.n_tiles) * BN;
+        return true;
+    };
+    auto stage_issue = [&](int buf, int kt, long long m0, int n0) {
+        float* xs = smem + buf * STAGE;
+        float* ws = xs + BM * 16;
+        const float* base = kt < a.k1p ? a.x1 : a.x2;
+        const int kk = kt < a.k1p ? kt : kt - a.k1p;
+        const float* src = base + ((long long)kk * a.m_padded + m0) * 16;
+#pragma unroll
+        for (int r = 0; r < XR; ++r) glds16(src + (r * 256 + tid) * 4, xs + (r * 256 + wave * 64) * 4);
+        const float* wsrc = a.w + ((long long)kt * a.n_padded + n0) * 16;
+#pragma unroll
+        for (int r = 0; r < WR; ++r) glds16(wsrc + (r * 256 + tid) * 4, ws + (r * 256 + wave * 64) * 4);
+    };
+
+    long long m0 = 0;
+    int n0 = 0;
+    if (!tile_of(0, m0, n0)) return;
+    if (dephase) {
+        // the workgroups of one point tile (consecutive w) share a phase; 64 groups chip-wide -> phases k/64 of a tile time
+        const int grp = (w / a.n_tiles) * 8 + xcd;
+        const int units = ((grp * 37) & 63) * KT / 64;          // one unit = s_sleep 127 = 8128 cycles ~ one K panel of a shared SIMD
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    stage_issue(0, 0, m0, n0);
+    for (int it = 0;; ++it) {
+        f32x16 acc[NI][NJ];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        // Panel 0 of this tile has landed?  It was requested BEFORE the previous tile's NI*NJ*4 = 32 stores per lane, and on
+        // gfx9 vector-memory operations of one wave retire IN ORDER (loads and stores share vmcnt; hipcc itself emits
+        // vmcnt(N > 0) across younger stores), so vmcnt(32) = "everything older than the last 32 stores" = the panel, WITHOUT
+        // waiting for the store acknowledgements of the chip-wide write burst (a plain __syncthreads() would: vmcnt(0)).
+        if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < KT) stage_issue(cur ^ 1, kt + 1, m0, n0);
+            const float* xs = smem + cur * STAGE;
+            mma_panel<NI, NJ>(xs, xs + BM * 16, wm * (32 * NJ), wn * 64, lane, acc);
+            __syncthreads();
+        }
+        // (1) bias + ReLU applied IN PLACE to the accumulators (the wait for the bias happens here, before anything else is in
+        // flight), (2) request the next tile's first panel, (3) this tile's 32 stores per lane, which need no wait at all.
+        // (No wave reads LDS any more: the K loop ended on a barrier.)
+        const bool perray = a.bias_row_div != 0;
+        if (!perray) {
+            f32x4 bv[NI][4];
+            bias_fetch<NI>(a.bias, n0 + wn * 64, lane, bv);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = acc[i][j][4 * q + e] + bv[i][q][e];
+                            acc[i][j][4 * q + e] = a.relu ? relu_np(v) : v;
+                        }
+        }
+        long long m1 = 0;
+        int n1 = 0;
+        const bool more = tile_of(it + 1, m1, n1);
+        if (more) stage_issue(0, 0, m1, n1);
+        if (perray) {
+            f32x4 bv[NI][4];
+            store_tile<NI, NJ, true, false>(acc, a.bias, a.bias_rows, a.bias_row_div, a.n_padded, a.y, a.m_padded,
+                                            m0 + wm * (32 * NJ), n0 + wn * 64, a.relu, lane, bv);
+        } else {
+            const int lr = lane & 31, g = lane >> 5;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const long long m = m0 + wm * (32 * NJ) + 32 * j + lr;
+                const int msw = (int)(m >> 2) & 3;
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n0 + wn * 64 + 32 * i + 8 * q + 4 * g;
+                        f32x4 v;
+                        v.x = acc[i][j][4 * q + 0], v.y = acc[i][j][4 * q + 1], v.z = acc[i][j][4 * q + 2], v.w = acc[i][j][4 * q + 3];
+                        *(f32x4*)(a.y + (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
+                    }
+            }
+        }
+        if (!more) break;
+        m0 = m1, n0 = n1;
+    }
+}
+
+// ---- measurement aid: what the fp32 matrix pipe sustains with NO memory traffic, barriers or epilogue -----------------------
+// 8 independent 32x32 accumulators per wave (the layer kernel's register blocking), iters x 64 MFMAs each.
+// tools/microbench_layer.py --peak turns the time into TFLOP/s: 156 = 99 % of 157.3, with one OR two waves per SIMD.
+__global__ __launch_bounds__(256, 2) void k_mfma_peak_probe(float* __restrict__ out, int iters, int random_operands) {
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // random_operands: every lane gets its own pseudo-random operand values (|v| ~ 1e-3 .. 1) and their mantissa bits are
+    // re-scrambled with integer ops once per 64 MFMAs, so that the multiplier inputs toggle like real data instead of sitting
+    // at two constants - the question being whether the pipe's sustained rate depends on the data
+    unsigned h = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u + 12345u);
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h = h * 1664525u + 1013904223u;
+        a[e] = random_operands ? __uint_as_float(0x3A000000u | (h & 0x05FFFFFFu) | ((h >> 3) & 0x80000000u)) : (float)threadIdx.x * 1e-3f;
+        h = h * 1664525u + 1013904223u;
+        b[e] = random_operands ? __uint_as_float(0x3A000000u | (h & 0x05FFFFFFu) | ((h >> 5) & 0x80000000u)) : (float)blockIdx.x * 1e-3f;
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[(e + i) & 7], acc[i], 0, 0, 0);
+        }
+        if (random_operands) {
+            // random_operands == 2: the control - identical instruction stream, but the scramble keeps only bits that are
+            // already set (mask 0), so the operands stay what they were
+            const unsigned keep = random_operands == 2 ? 0u : 0x007FFFFFu;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                h = h * 1664525u + 1013904223u;
+                a[e] = __uint_as_float((__float_as_uint(a[e]) & ~keep) | (h & keep));
+                b[e] = __uint_as_float((__float_as_uint(b[e]) & ~keep) | (((h >> 7) | (h << 3)) & keep));
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(a[e]), "+v"(b[e]));
+        }
+    }
+    float s_ = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_ += acc[i][r];
+    if (s_ == 123.456f) out[0] = s_;   // keeps the accumulators alive
+}
+
+template <class P, bool PIPE, int BN = 128>
+int launch_policy(LayerArgs a, hipStream_t st) {
+    a.n_tiles = a.n_padded / BN;
+    const long long total = (a.m_padded / kRowTile) * a.n_tiles;
+    MOFA_REQUIRE(total > 0 && total < (1ll << 30), "measure: tile count %lld out of range", total);
+    a.total_tiles = (int)total;
+    const dim3 grid((unsigned)round_up(total, 8)), block(256);
+    const size_t lds = 2 * (size_t)(kRowTile + BN) * 16 * sizeof(float) + P::kExtraLds;
+    if (a.bias_row_div) hipLaunchKernelGGL((k_layer<BN, false, false, false, true, PIPE, P>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((k_layer<BN, false, false, false, false, PIPE, P>), grid, block, lds, st, a);
+    return check_launch("k_layer(measure)");
+}
+
+int launch_ring3(LayerArgs a, hipStream_t st) {
+    constexpr int BN = 128;
+    a.n_tiles = a.n_padded / BN;
+    const long long total = (a.m_padded / kRowTile) * a.n_tiles;
+    a.total_tiles = (int)total;
+    const size_t lds3 = 3 * (size_t)(kRowTile + BN) * 16 * sizeof(float);
+    static std::atomic<bool> attr3[kMaxDevices];
+    const int dev = current_device();
+    if (!attr3[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute((const void*)k_layer_ring3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_layer_ring3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess)
+            return check_launch("hipFuncSetAttribute(k_layer_ring3)");
+        attr3[dev].store(true, std::memory_order_release);
+    }
+    const dim3 grid((unsigned)round_up(total, 8)), block(256);
+    if (a.bias_row_div) hipLaunchKernelGGL((k_layer_ring3<true>), grid, block, lds3, st, a);
+    else hipLaunchKernelGGL((k_layer_ring3<false>), grid, block, lds3, st, a);
+    return check_launch("k_layer_ring3");
+}
+
+int launch_persist(LayerArgs a, int dephase, hipStream_t st) {
+    constexpr int BN = 128;
+    a.n_tiles = a.n_padded / BN;
+    const long long total = (a.m_padded / kRowTile) * a.n_tiles;
+    a.total_tiles = (int)total;
+    const size_t lds = 2 * (size_t)(kRowTile + BN) * 16 * sizeof(float);
+    const int cus = compute_units(current_device());
+    long long G = 2LL * cus / 8 * 8;                                  // two resident workgroups per CU, multiple of 8 XCDs
+    const int per_xcd_tiles = (int)((total + 7) / 8);
+    if (G > 8LL * per_xcd_tiles) G = 8LL * per_xcd_tiles;
+    hipLaunchKernelGGL(k_layer_persist, dim3((unsigned)G), dim3(256), lds, st, a, per_xcd_tiles, dephase);
+    return check_launch("k_layer_persist");
+}
+
+}  // namespace
+}  // namespace mofa
+
+using namespace mofa;
+
+#define MOFA_MEASURE_API extern "C" __attribute__((visibility("default")))
+
+MOFA_MEASURE_API const char* mofa_measure_arms(void) {
+    return "shipped,plain,bn64,unstaged,gap2,gap3,setprio1,setprio3,waves3,ring3,persist,persist_dephase,timeline,sink_epilogue";
+}
+MOFA_MEASURE_API const char* mofa_measure_last_error(void) { return g_err; }
+
+/* mofa_layer_forward's arguments behind the name of an arm (see the list at the top of this file) */
+MOFA_MEASURE_API int mofa_measure_layer_forward(const char* arm, const float* x1, int32_t k1, const float* x2, int32_t k2,
+                                                const float* w_packed, const float* bias, int32_t bias_row_div, int64_t bias_rows, float* y,
+                                                int64_t m_padded, int32_t n_padded, int32_t relu, void* stream) {
+    MOFA_REQUIRE(arm && x1 && w_packed && bias && y, "measure_layer_forward: null pointer");
+    MOFA_REQUIRE(k1 > 0 && k1 % 16 == 0 && k2 >= 0 && k2 % 16 == 0 && (k2 == 0 || x2), "measure_layer_forward: bad K");
+    MOFA_REQUIRE(m_padded > 0 && m_padded % kRowTile == 0 && n_padded > 0 && n_padded % 64 == 0, "measure_layer_forward: bad M / N");
+    LayerArgs a{};
+    a.x1 = x1, a.x2 = x2, a.w = w_packed, a.bias = bias, a.y = y;
+    a.k1p = k1 / 16, a.k2p = k2 / 16, a.n_padded = n_padded, a.m_padded = m_padded;
+    a.bias_row_div = bias_row_div, a.bias_rows = bias_rows, a.relu = relu;
+    hipStream_t st = (hipStream_t)stream;
+    const int KT = a.k1p + a.k2p;
+    const bool pipe_ok = KT >= 4 && (KT & 1) == 0;
+    if (!strcmp(arm, "bn64")) return launch_policy<ShippedPolicy, false, 64>(a, st);
+    MOFA_REQUIRE(n_padded % 128 == 0, "measure_layer_forward: arm %s needs n_padded %% 128 == 0", arm);
+    if (!strcmp(arm, "plain")) return launch_policy<ShippedPolicy, false>(a, st);
+    if (!strcmp(arm, "setprio1")) return launch_policy<SetPrioPolicy<1>, false>(a, st);
+    if (!strcmp(arm, "setprio3")) return launch_policy<SetPrioPolicy<3>, false>(a, st);
+    if (!strcmp(arm, "ring3")) return launch_ring3(a, st);
+    if (!strcmp(arm, "persist")) return launch_persist(a, 0, st);
+    if (!strcmp(arm, "persist_dephase")) return launch_persist(a, 1, st);
+    MOFA_REQUIRE(pipe_ok, "measure_layer_forward: arm %s runs the pipelined loop: needs an even number of K panels >= 4 (got %d)", arm, KT);
+    if (!strcmp(arm, "shipped")) return launch_policy<ShippedPolicy, true>(a, st);
+    if (!strcmp(arm, "unstaged")) return launch_policy<UnstagedPolicy, true>(a, st);
+    if (!strcmp(arm, "gap2")) return launch_policy<GapPolicy<2>, true>(a, st);
+    if (!strcmp(arm, "gap3")) return launch_policy<GapPolicy<3>, true>(a, st);
+    if (!strcmp(arm, "waves3")) return launch_policy<Waves3Policy, true>(a, st);
+    if (!strcmp(arm, "timeline")) return launch_policy<TimelinePolicy, true>(a, st);
+    if (!strcmp(arm, "sink_epilogue")) return launch_policy<SinkPolicy, true>(a, st);
+    set_error("measure_layer_forward: unknown arm '%s' (have: %s)", arm, mofa_measure_arms());
+    return MOFA_EINVAL;
+}
+
+/* the stamp buffer of the "timeline" arm: [tiles][8] + [tiles][64] u64 on the device, or NULL = stamps off */
+MOFA_MEASURE_API int mofa_measure_set_timeline(unsigned long long* buf) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_timeline_dev), &buf, sizeof(buf)) != hipSuccess) return check_launch("hipMemcpyToSymbol(g_timeline_dev)");
+    return MOFA_OK;
+}
+
+/* `blocks` workgroups of 4 waves running iters x 64 fp32 MFMAs each (tools/microbench_layer.py --peak) */
+MOFA_MEASURE_API int mofa_measure_mfma_peak_probe(float* out, int32_t blocks, int32_t iters, int32_t random_operands, void* stream) {
+    hipLaunchKernelGGL(k_mfma_peak_probe, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, iters, random_operands);
+    return check_launch("k_mfma_peak_probe");
+}

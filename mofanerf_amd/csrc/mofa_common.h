@@ -45,20 +45,16 @@ __device__ __forceinline__ float relu_np(float v) { return __builtin_elementwise
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
-// Measurement / A-B knobs.  The environment is read ONCE (at library load, and again only when the host calls
-// mofa_config_reload()) into an immutable snapshot, so no launch path calls getenv and concurrent host threads see one
-// consistent configuration.  -1 = "not set: use the built-in heuristic".
+// Run-time knobs.  Every one of them selects between forms that produce CORRECT results (the plain and the pipelined K loop
+// are bit-identical, so are the persistent and the per-layer network path); measurement arms live in csrc/measure/, not here.
+// The environment is read ONCE (at library load, and again only when the host calls mofa_config_reload()) into an immutable
+// snapshot, so no launch path calls getenv and concurrent host threads see one consistent configuration.
+// -1 = "not set: use the built-in heuristic".
 struct Config {
-    int stage_glds = 1;   // MOFA_STAGE=reg -> 0: register-staged A/B arm of k_layer
     int split_v = 2;      // MOFA_SPLIT_V=1 -> pre-split weight planes for the opt-in bf16 modes
-    int bn64 = 0;         // MOFA_BN64: force the 64-feature tile (tools/microbench_layer.py)
     int fused = -1;       // MOFA_FUSED=0/1: persistent whole-network kernel off / on
     int split_hh = -1;    // MOFA_SPLIT_HH=0/1: fp16 piece panels off / on (opt-in fp16x3 mode)
-    int persist = -1;     // MOFA_PERSIST=0/1: persistent per-layer kernel (k_layer_persist) off / on
-    int dephase = 0;      // MOFA_DEPHASE=1: per-workgroup start offset in k_layer_persist (A/B arm)
-    int ring3 = -1;       // MOFA_RING3=0/1: 3-stage LDS ring twin of the layer kernel (k_layer_ring3) off / on
-    int pipe = -1;        // MOFA_PIPE=0/1: software-pipelined twin of the layer kernel (k_layer_pipe) off / on
-    int lds_pad = 0;      // MOFA_LDS_PAD=bytes: extra dynamic LDS per workgroup of the layer kernel (occupancy A/B: 8192 -> 2 per CU)
+    int pipe = -1;        // MOFA_PIPE=0: the plain K loops (layer kernel, persistent kernel, weight gradient) instead of the pipelined ones
 };
 const Config& config();
 

@@ -1,0 +1,602 @@
+// The fp32-MFMA layer kernel of the MoFaNeRF hot path and its building blocks (gfx950 only), shared by every translation
+// unit that launches it: mofa_mlp.hip (the product: per-layer launches + the persistent whole-network kernel), mofa_split.hip
+// (the opt-in split-product experiment reuses the argument block, the LDS-DMA helper and the fp16 piece store) and
+// measure/mofa_measure.hip (measurement builds — time stamps, ablations, scheduling arms — built only by tools/).
+//
+// Replaces run_network/batchify/NeRF.forward of the reference (models/render_class.py:69-109, models/model.py:121-137, :202-230):
+// every Linear+bias+ReLU is one launch of k_layer, an LDS-tiled fp32 MFMA (v_mfma_f32_32x32x2_f32 — exact fp32, bitwise an
+// fmaf chain) GEMM whose operands arrive as ready-made, bank-swizzled LDS images ("panels") by direct global->LDS DMA.
+//
+// Formulation.  For a tile of 256 points (rows m) and BN output features (rows n):
+//     D[n][m] = sum_k Wp[n][k] * X[m][k]          (weights are the MFMA "A" operand, points "B")
+// so each lane ends up with 4 CONSECUTIVE features of ONE point per accumulator quad — one 16-byte store per quad straight
+// into the next layer's panel layout (bias + ReLU fused).
+//
+// Work decomposition: workgroup = 4 waves (256 threads), tile 256 (m) x BN (n); BN = 128 -> waves 2(n) x 2(m), wave tile
+// 64 x 128 (8 accumulators of 32x32); BN = 64 -> waves 1 x 4, wave tile 64 x 64.  K is walked in 16-wide panels,
+// double-buffered in LDS (24 KiB / stage at BN=128 => 48 KiB / workgroup, 2 workgroups per CU so one's epilogue hides under
+// the other's MFMAs).  blockIdx -> tile is XCD-aware: block b runs on XCD b%8, and each XCD walks a contiguous range of point
+// tiles across all feature tiles, so the 8 feature tiles of a point tile share ONE L2 for the activation tile (PMC: the L2
+// hit rate of the K = N = 1024 launch is 7/8 on that stream; what passes the L2s a second time is the 4 MiB weight slab
+// cycling through them out of the 256 MiB Infinity Cache — profiles/hbm_traffic.json, control_n128).
+//
+// Policy.  The kernel and its K loop take a class `P` that fixes the handful of compile-time choices measurement builds vary
+// (minimum waves per SIMD, MFMAs between two LDS-DMA requests, wave priority around MFMA blocks, the staged epilogue) and two
+// hooks (time stamps, an epilogue sink).  The product instantiates ONLY ShippedPolicy — every hook is an empty inline, every
+// constant the shipped value; nothing in libmofanerf_hip.so can select anything else.
+#pragma once
+#include "mofa_common.h"
+
+namespace mofa {
+namespace {
+
+struct LayerArgs {
+    const float* x1;      // panels [k1p][m_padded][16]
+    const float* x2;      // optional second source (skip concat [x | h]), panels [k2p][m_padded][16]
+    const float* w;       // packed weights, panels [(k1p+k2p)][n_padded][16]
+    const float* bias;    // [bias_rows][n_padded]
+    float* y;             // panels [n_padded/16][m_padded][16]
+    const float* mask;    // backward epilogue: saved forward activation with y's geometry; y *= (mask > 0)
+    int accumulate;       // backward epilogue: y = (y_old + acc) [* mask]
+    // layer-0 (positional encoding prologue) inputs
+    const float* rays_o;
+    const float* rays_d;
+    const float* z;
+    const float* pts;
+    long long z_row_stride;
+    long long n_points;
+    long long m_padded;
+    long long bias_rows;
+    int k1p, k2p;         // number of 16-wide K panels per source
+    int n_padded;
+    int bias_row_div;     // 0: one bias row; else bias row = m / bias_row_div (per-ray bias)
+    int relu;
+    int S;
+    int n_tiles;          // n_padded / BN
+    int total_tiles;
+    int y_hh;             // opt-in fp16x3 mode only: write y as pre-split fp16 piece panels (store_quad_hh)
+    // layer-0 camera mode (mofa_layer0_forward_cam): rays are built in the prologue from (K, c2w, pixel) instead of being read
+    const float* cam_c2w;   // 12 floats [3,4] (device) or NULL = read rays_o / rays_d
+    const int* cam_pix;     // flat pixel index per ray, or NULL = pixel cam_pix0 + ray
+    long long cam_pix0;
+    float fx, fy, cx, cy;
+    int cam_w;
+};
+
+// The shipped compile-time configuration of the layer kernel (see "Policy" above).
+struct ShippedPolicy {
+    static constexpr int kMinWaves = 2;            // min waves per SIMD the register allocator must leave room for (= workgroups per CU)
+    static constexpr int kPipeGap = 0;             // MFMAs between two LDS-DMA requests; 0 = as many as the half panel allows after its reads
+    static constexpr int kSetPrio = 0;             // s_setprio level around every MFMA block of the plain loop (0 = none)
+    static constexpr bool kStagedEpilogue = true;  // contiguous-store epilogue through a wave-private LDS window
+    static constexpr bool kSinkEpilogue = false;   // true: discard the tile instead of storing it (timing-only ablation; never shipped)
+    static constexpr int kExtraLds = 0;            // bytes of dynamic LDS the hooks use behind the two stages
+    struct Probe {                                 // time-stamp hooks: empty
+        __device__ __forceinline__ Probe(const LayerArgs&, int /*logical tile*/, int /*tid*/, float* /*LDS behind the stages*/, int /*KT*/) {}
+        __device__ __forceinline__ void entry() {}
+        __device__ __forceinline__ void kloop_begin() {}
+        __device__ __forceinline__ void panel() {}
+        __device__ __forceinline__ void first_panel_landed() {}
+        __device__ __forceinline__ void kloop_end() {}
+        __device__ __forceinline__ void stores_issued() {}
+    };
+    template <class Acc>
+    static __device__ __forceinline__ void sink(const Acc&, float*) {}
+};
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// "hh" activation panels (opt-in fp16x3 mode): same bytes and swizzle as an fp32 panel row (64 B = four
+// 16-B chunks per point and 16 features), but the chunks hold PRE-SPLIT fp16 pieces: chunk 2G = h1 of features 8G..8G+7,
+// chunk 2G+1 = h2 of the same features (x = h1 + h2 + O(2^-23 |x|), both round-to-nearest).  The consuming kernel's
+// operand fragment is then exactly the two 16-B reads it already makes - no conversion work per use.
+// `v` = features n..n+3 (n % 4 == 0) of point m; msw = (m >> 2) & 3.
+__device__ __forceinline__ void store_quad_hh(float* __restrict__ y, long long m_padded, int n, long long m, int msw,
+                                              const f32x4 v) {
+    f16x4 h1, h2;
+    h1.x = (_Float16)v.x, h1.y = (_Float16)v.y, h1.z = (_Float16)v.z, h1.w = (_Float16)v.w;
+    h2.x = (_Float16)(v.x - (float)h1.x), h2.y = (_Float16)(v.y - (float)h1.y);
+    h2.z = (_Float16)(v.z - (float)h1.z), h2.w = (_Float16)(v.w - (float)h1.w);
+    const int G = (n >> 3) & 1, half = (n >> 2) & 1;
+    float* row = y + (long long)(n >> 4) * m_padded * 16 + m * 16 + half * 2;
+    *(f16x4*)(row + (((2 * G) ^ msw) << 2)) = h1;
+    *(f16x4*)(row + (((2 * G + 1) ^ msw) << 2)) = h2;
+}
+
+__device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
+    // 16 B per lane, LDS destination = wave-uniform base + lane*16 (LDS-DMA, no VGPR round trip)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// positional-encoding feature k of a 3-vector: [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...]
+// (models/model.py:24-45; frequency-major blocks of 3).  k is wave-uniform => no divergence.
+__device__ __forceinline__ float pe_feature(int k, float x0, float x1, float x2, int nfeat) {
+    if (k >= nfeat) return 0.0f;
+    if (k < 3) return k == 0 ? x0 : (k == 1 ? x1 : x2);
+    const int j = k - 3;
+    const int f = j / 6;
+    const int r = j - 6 * f;
+    const int d = r >= 3 ? r - 3 : r;
+    const float x = d == 0 ? x0 : (d == 1 ? x1 : x2);
+    const float arg = x * (float)(1 << f);  // exact (power of two), like x * freq in the reference
+    return r < 3 ? sinf(arg) : cosf(arg);
+}
+
+template <int NI, int NJ, class P = ShippedPolicy>
+__device__ __forceinline__ void mma_panel(const float* __restrict__ Xt, const float* __restrict__ Wt, int xrow0,
+                                          int wrow0, int lane, f32x16 (&acc)[NI][NJ]) {
+    const int lr = lane & 31, g = lane >> 5, sw = (lane >> 2) & 3;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int p = ((2 * h + g) ^ sw) << 2;  // swizzled 16-B chunk holding k = 8h + 4g .. +3
+        f32x4 a[NI], b[NJ];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) a[i] = *(const f32x4*)(Wt + (wrow0 + 32 * i + lr) * 16 + p);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j] = *(const f32x4*)(Xt + (xrow0 + 32 * j + lr) * 16 + p);
+        if constexpr (P::kSetPrio > 0) __builtin_amdgcn_s_setprio(P::kSetPrio);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        if constexpr (P::kSetPrio > 0) __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// ---- software-pipelined K loop (k_layer<.., PIPE = true>) ----------------------------------------------------------------
+// Same tile, same two LDS stages, same MFMA order as the plain loop (bit-identical results) - only the PLACEMENT of the
+// loop's memory instructions differs.  For the plain loop hipcc emits, per 16-wide panel and wave: one block of ~30 SALU + 6
+// LDS-DMA requests with no MFMA in flight, 6 fragment reads followed by a full lgkmcnt(0) wait, 32 MFMAs, 6 fragment reads
+// + wait + barrier, 32 MFMAs; the LDS-DMA of panel kt+1 is requested half a panel before the barrier that waits for it.  An
+// LDS-DMA request costs 60-185 issue cycles (MI355X micro-architecture guide), so a wave that is alone on its SIMD leaves
+// the matrix pipe idle for ~10 % of every panel.  Here every half panel (32 MFMAs) carries the memory instructions of the
+// NEXT one in its shadow (`sched_group_barrier` pins the interleaving):
+//   half A(kt):  fragment reads of the second half of panel kt            between the MFMAs of its first half
+//   wait + barrier: panel kt+1 has landed everywhere, everyone is done reading panel kt's stage
+//   half B(kt):  fragment reads of the first half of panel kt+1, THEN the LDS-DMA requests of panel kt+2 (into panel kt's
+//                stage), one per GAP MFMAs                                 between the MFMAs of the second half
+// so a request is waited for a full panel after it was made and nothing sits between two MFMA blocks.  Measured (M = 196608,
+// K = N = 1024, interleaved A/B): 139.3 -> 145.6 TFLOP/s; reads-before-requests and a gap of 4 matter (requests first: 141).
+// Needs an even number of panels >= 4 (unrolled by two: stage addresses are compile-time constants); launch_layer checks.
+// (GAP: 4 for the 128-feature tile: 32 MFMAs, 6 reads, 6 requests; 2 for the 64-feature tile: 16 / 4 / 5.)
+// xb / x2b / wb: the tile's first panel in the two activation sources (x2b is only dereferenced when KT > k1p) and in the
+// weight pack; xstep / wstep: floats between consecutive panels; xrow0 / wrow0: this wave's first row in the staged X / W
+// tile; `wave`: index of the wave's 1 KiB slot inside each 4 KiB staging round.
+template <int NI, int NJ, int BM, int BN, class P = ShippedPolicy>
+__device__ __forceinline__ void kloop_pipelined(const float* xb, const float* x2b, const float* wb, long long xstep, long long wstep,
+                                                int k1p, int KT, float* smem, int tid, int wave, int lane, int xrow0, int wrow0,
+                                                f32x16 (&acc)[NI][NJ], typename P::Probe& probe) {
+    constexpr int STAGE = (BM + BN) * 16, XR = BM / 64, WR = BN / 64;
+    const int lr = lane & 31, g = lane >> 5, sw = (lane >> 2) & 3;
+    int pq = 0;                                  // panel xb / wb point at
+    const unsigned toff = (unsigned)tid * 4u;
+    float* const lds_wave = smem + wave * 256;   // this wave's 1 KiB slot inside each 4 KiB round
+
+    struct Frag {
+        f32x4 a[NI], b[NJ];
+    };
+    auto request = [&](int stage) {              // LDS-DMA of panel pq into `stage`, then step to panel pq + 1
+        float* xs = lds_wave + stage * STAGE;
+        float* ws = xs + BM * 16;
+#pragma unroll
+        for (int r = 0; r < XR; ++r) glds16(xb + (r * 1024u + toff), xs + r * 1024);
+#pragma unroll
+        for (int r = 0; r < WR; ++r) glds16(wb + (r * 1024u + toff), ws + r * 1024);
+        ++pq;
+        wb += wstep;
+        xb = pq == k1p ? x2b : xb + xstep;
+    };
+    auto read = [&](int stage, int h, Frag& f) {
+        const float* Xt = smem + stage * STAGE;
+        const float* Wt = Xt + BM * 16;
+        const int p = ((2 * h + g) ^ sw) << 2;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) f.a[i] = *(const f32x4*)(Wt + (wrow0 + 32 * i + lr) * 16 + p);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) f.b[j] = *(const f32x4*)(Xt + (xrow0 + 32 * j + lr) * 16 + p);
+    };
+    auto mfma_half = [&](const Frag& f) {       // the same (e, i, j) order as mma_panel
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[j][e], acc[i][j], 0, 0, 0);
+    };
+    // scheduling masks: 0x008 MFMA, 0x100 LDS read, 0x020 VMEM read (the LDS-DMA request)
+    auto half_a = [&](int stage, Frag& cur, Frag& nxt) {       // MFMAs of the first half, reads of the second
+        __builtin_amdgcn_sched_barrier(0);
+        read(stage, 1, nxt);
+        mfma_half(cur);
+#pragma unroll
+        for (int q = 0; q < NI + NJ; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NI * NJ, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto sync_point = [&]() {   // my own requests have landed and my reads are done; then everybody's
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        probe.panel();
+    };
+    auto half_b = [&](int stage, bool do_request, bool do_read, Frag& cur, Frag& nxt) {   // MFMAs of the second half
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_read) read(stage ^ 1, 0, nxt);
+        if (do_request) request(stage);
+        mfma_half(cur);
+        if (do_read) {
+#pragma unroll
+            for (int q = 0; q < NI + NJ; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        if (do_request) {
+            constexpr int GAP = P::kPipeGap > 0 ? P::kPipeGap : (4 * NI * NJ - (NI + NJ)) / (XR + WR);
+            static_assert(GAP >= 1, "the half panel has too few MFMAs to carry its memory instructions");
+#pragma unroll
+            for (int q = 0; q < XR + WR; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NI * NJ, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    Frag fa, fb;
+    request(0);
+    request(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XR + WR) : "memory");   // panel 0 (the older requests) has landed
+    __builtin_amdgcn_s_barrier();
+    probe.first_panel_landed();
+    read(0, 0, fa);
+    for (int kt = 0; kt + 2 < KT; kt += 2) {
+        half_a(0, fa, fb);
+        sync_point();
+        half_b(0, true, true, fb, fa);
+        half_a(1, fa, fb);
+        sync_point();
+        half_b(1, true, true, fb, fa);
+    }
+    half_a(0, fa, fb);
+    sync_point();
+    half_b(0, false, true, fb, fa);
+    half_a(1, fa, fb);
+    half_b(1, false, false, fb, fa);
+}
+
+// Forward epilogue of one wave tile (NI x NJ accumulators of 32x32): bias + ReLU, one 16-byte store per accumulator quad
+// straight into the next layer's panels.  PERRAY (the view layer: bias row = ray of the point) is a TEMPLATE parameter on
+// purpose: with the per-ray bias loads inside the point loop under a RUN-TIME `if`, hipcc must assume at the join that the
+// loads may still be in flight and brackets every store with `s_waitcnt vmcnt(7)` — and because loads and stores share the
+// in-order vmcnt on gfx9, that also limits every wave of the ordinary layers to 7 stores in flight: the 32 stores per lane
+// of a tile then take 4-5 store-acknowledge round trips instead of being fire-and-forget.  With PERRAY = false the bias is
+// fetched once, waited for once, and the 32 stores issue back to back with no wait between them.
+template <int NI>
+__device__ __forceinline__ void bias_fetch(const float* __restrict__ bias_base, int n_first, int lane, f32x4 (&bv)[NI][4]) {
+    int boff = n_first + 4 * (lane >> 5);
+    asm volatile("" : "+v"(boff));  // opaque AFTER the K loop: keeps hipcc from hoisting the 8 bias loads (32 VGPRs) above it
+#pragma unroll
+    for (int i = 0; i < NI; ++i)    // one bias row for every point: fetch it once, all 8 loads in flight together
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(bias_base + boff + 32 * i + 8 * q);
+}
+
+template <int NI, int NJ, bool PERRAY, bool HH>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[NI][NJ], const float* __restrict__ bias_base, long long bias_rows,
+                                           int bias_row_div, int n_padded, float* __restrict__ y, long long m_padded,
+                                           long long m_first, int n_first, int relu, int lane, f32x4 (&bv)[NI][4]) {
+    const int lr = lane & 31, g = lane >> 5;
+    int boff = n_first + 4 * g;
+    if constexpr (!PERRAY) bias_fetch<NI>(bias_base, n_first, lane, bv);
+    if constexpr (PERRAY) asm volatile("" : "+v"(boff));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const long long m = m_first + 32 * j + lr;
+        if constexpr (PERRAY) {     // per-ray bias (view layer): row = ray of this point
+            long long brow = m / bias_row_div;
+            if (brow >= bias_rows) brow = bias_rows - 1;
+            const float* bias = bias_base + brow * n_padded + boff;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(bias + 32 * i + 8 * q);
+        }
+        const int msw = (int)(m >> 2) & 3;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n_first + 32 * i + 8 * q + 4 * g;
+                f32x4 v;
+                v.x = acc[i][j][4 * q + 0] + bv[i][q].x;
+                v.y = acc[i][j][4 * q + 1] + bv[i][q].y;
+                v.z = acc[i][j][4 * q + 2] + bv[i][q].z;
+                v.w = acc[i][j][4 * q + 3] + bv[i][q].w;
+                if (relu) {
+                    v.x = relu_np(v.x), v.y = relu_np(v.y), v.z = relu_np(v.z), v.w = relu_np(v.w);
+                }
+                if constexpr (HH) store_quad_hh(y, m_padded, n, m, msw, v);
+                else *(f32x4*)(y + (long long)(n >> 4) * m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
+            }
+        }
+    }
+}
+
+// The forward epilogue of the ordinary layers (one bias row, fp32 panels) with CONTIGUOUS stores.  In store_tile a wave-store is 64 lanes x 16 B at a
+// 64-byte stride (a lane owns a point), which the memory pipeline issues at ~7 B/clk/CU (store-issue-bound); here every wave
+// passes its tile through a PRIVATE 4 KiB LDS window in the panels' own (swizzled) row layout — 64 rows x 64 B per slice, written
+// as 16-byte fragments, read back as 1 KiB contiguous wave rows — so that each global store is 1 KiB of consecutive bytes.
+// No barrier: the window is wave-private and a wave's LDS operations execute in order.  `win` must not be read or written by
+// anyone else (the pipelined K loop's stage 0 is free for all waves after its last barrier).  Same values as store_tile
+// (bit-identical).  Measured against it (interleaved A/B): +0.4 % at K = N = 1024, +4 % at 256, k_mlp_fused 133.2 -> 135.5 TFLOP/s.
+template <int NI, int NJ, bool RELU>
+__device__ __forceinline__ void store_tile_staged(const f32x16 (&acc)[NI][NJ], const float* __restrict__ bias, float* __restrict__ y,
+                                                  long long m_padded, long long m_first, int n_first, int lane, float* win) {
+    static_assert(NJ % 2 == 0, "row halves of 64 points");
+    const int lr = lane & 31, g = lane >> 5, msw = (lr >> 2) & 3;   // m_first + 32 j is a multiple of 32: the row swizzle is the lane's
+    f32x4 bv[NI][4];
+    bias_fetch<NI>(bias, n_first, lane, bv);
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh) {
+            float* __restrict__ panel = y + ((long long)((n_first >> 4) + 2 * i + qh) * m_padded + m_first) * 16;
+#pragma unroll
+            for (int jh = 0; jh < NJ / 2; ++jh) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const int j = 2 * jh + jj, q = 2 * qh + qq;
+                        f32x4 v;
+                        v.x = acc[i][j][4 * q + 0] + bv[i][q].x, v.y = acc[i][j][4 * q + 1] + bv[i][q].y;
+                        v.z = acc[i][j][4 * q + 2] + bv[i][q].z, v.w = acc[i][j][4 * q + 3] + bv[i][q].w;
+                        if constexpr (RELU) v.x = relu_np(v.x), v.y = relu_np(v.y), v.z = relu_np(v.z), v.w = relu_np(v.w);
+                        *(f32x4*)(win + (32 * jj + lr) * 16 + (((2 * qq + g) ^ msw) << 2)) = v;     // logical chunk 2 qq + g
+                    }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const f32x4 v = *(const f32x4*)(win + it * 256 + lane * 4);
+                    *(f32x4*)(panel + jh * 1024 + it * 256 + lane * 4) = v;
+                }
+            }
+        }
+}
+
+// Backward-data epilogue through the same wave-private LDS window: dX = (acc [+ dX_old]) [* (saved activation > 0)].  Staging
+// first turns the accumulator fragments into 1 KiB contiguous wave rows, so the optional reads of dX_old and of the saved
+// activation are fully coalesced 1 KiB loads (all four of a slice in flight together) instead of 16 B per lane at a 64-byte
+// stride, and ACC / MASK are compile-time: no wait sits between a load and the next one.  Same arithmetic as the strided form.
+template <int NI, int NJ, bool ACC, bool MASK>
+__device__ __forceinline__ void store_tile_staged_bwd(const f32x16 (&acc)[NI][NJ], float* __restrict__ y, const float* __restrict__ mask,
+                                                      long long m_padded, long long m_first, int n_first, int lane, float* win) {
+    static_assert(NJ % 2 == 0, "row halves of 64 points");
+    const int lr = lane & 31, g = lane >> 5, msw = (lr >> 2) & 3;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh) {
+            const long long poff = ((long long)((n_first >> 4) + 2 * i + qh) * m_padded + m_first) * 16;
+#pragma unroll
+            for (int jh = 0; jh < NJ / 2; ++jh) {
+                const long long off = poff + jh * 1024 + lane * 4;
+                f32x4 old[4], act[4];
+                if constexpr (ACC) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) old[it] = *(const f32x4*)(y + off + it * 256);
+                }
+                if constexpr (MASK) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) act[it] = *(const f32x4*)(mask + off + it * 256);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const int j = 2 * jh + jj, q = 2 * qh + qq;
+                        f32x4 v;
+                        v.x = acc[i][j][4 * q + 0], v.y = acc[i][j][4 * q + 1], v.z = acc[i][j][4 * q + 2], v.w = acc[i][j][4 * q + 3];
+                        *(f32x4*)(win + (32 * jj + lr) * 16 + (((2 * qq + g) ^ msw) << 2)) = v;
+                    }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    f32x4 v = *(const f32x4*)(win + it * 256 + lane * 4);
+                    if constexpr (ACC) v.x += old[it].x, v.y += old[it].y, v.z += old[it].z, v.w += old[it].w;
+                    if constexpr (MASK)
+                        v.x = act[it].x > 0.f ? v.x : 0.f, v.y = act[it].y > 0.f ? v.y : 0.f, v.z = act[it].z > 0.f ? v.z : 0.f,
+                        v.w = act[it].w > 0.f ? v.w : 0.f;
+                    *(f32x4*)(y + off + it * 256) = v;
+                }
+            }
+        }
+}
+
+// BN: feature-tile height; L0: X tile is generated (positional encoding) instead of loaded; operands are staged by LDS-DMA.
+// BWD: backward-data epilogue (no bias/ReLU; optional accumulate into y and ReLU mask from the saved activation):
+//      dX[m][k] = sum_n G[m][n] * W[n][k]  is the same GEMM with the transposed weight pack as "Wp".
+// HH: write y as fp16 piece panels (opt-in fp16x3 mode).  PERRAY: per-ray bias rows (the view layer).
+// PIPE: the software-pipelined K loop (128-feature tile, >= 4 and an even number of panels); otherwise the plain loop.
+template <int BN, bool L0, bool BWD = false, bool HH = false, bool PERRAY = false, bool PIPE = false, class P = ShippedPolicy>
+__global__ __launch_bounds__(256, P::kMinWaves) void k_layer(const LayerArgs a) {
+    static_assert(!PIPE || (!L0 && BN == 128), "the pipelined K loop stages both operands by LDS-DMA at the 128-feature tile");
+    // (measured on the 64-feature tile too - 4 workgroups per CU, 16 MFMAs per half panel carrying 4 reads + 5 requests: 132 against
+    //  136 TFLOP/s for its plain loop, so that tile keeps the plain loop)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BM = kRowTile;
+    constexpr int WAVES_N = BN / 64;
+    constexpr int WAVES_M = 4 / WAVES_N;
+    constexpr int NI = 2;
+    constexpr int NJ = (BM / WAVES_M) / 32;
+    constexpr int STAGE = (BM + BN) * 16;  // floats per pipeline stage
+    constexpr int XR = BM / 64;            // 4 KiB rounds per X stage
+    constexpr int WR = BN / 64;
+
+    // XCD-aware tile order (block b -> XCD b % 8; grid is padded to a multiple of 8)
+    const int per_xcd = gridDim.x >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= a.total_tiles) return;
+    const int mt = logical / a.n_tiles, nt = logical - mt * a.n_tiles;
+    const long long m0 = (long long)mt * BM;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WAVES_N, wm = wave / WAVES_N;
+    const int KT = a.k1p + a.k2p;
+    typename P::Probe probe(a, logical, tid, smem + 2 * STAGE, KT);
+
+    // layer 0: this thread owns point row m0+tid
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if constexpr (L0) {
+        long long m = m0 + tid;
+        if (m >= a.n_points) m = a.n_points - 1;
+        if (a.pts) {
+            px = a.pts[m * 3 + 0], py = a.pts[m * 3 + 1], pz = a.pts[m * 3 + 2];
+        } else {
+            const long long r = m / a.S;
+            const int s = (int)(m - r * a.S);
+            const float zz = a.z[r * a.z_row_stride + s];
+            float ro[3], rd[3];
+            if (a.cam_c2w) {   // the ray itself comes from (K, c2w, pixel): get_rays folded into the prologue
+                const long long pix = a.cam_pix ? (long long)a.cam_pix[r] : a.cam_pix0 + r;
+                const int pj = (int)(pix / a.cam_w), pi = (int)(pix - (long long)pj * a.cam_w);
+                pinhole_ray(pi, pj, a.fx, a.fy, a.cx, a.cy, a.cam_c2w, ro, rd);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ro[c] = a.rays_o[r * 3 + c], rd[c] = a.rays_d[r * 3 + c];
+            }
+            // pts = o + d * z with a separately rounded multiply and add (render_class.py:315)
+            px = __fadd_rn(ro[0], __fmul_rn(rd[0], zz));
+            py = __fadd_rn(ro[1], __fmul_rn(rd[1], zz));
+            pz = __fadd_rn(ro[2], __fmul_rn(rd[2], zz));
+        }
+    }
+
+    auto x_src = [&](int kt) -> const float* {
+        const float* base = kt < a.k1p ? a.x1 : a.x2;
+        const int kk = kt < a.k1p ? kt : kt - a.k1p;
+        return base + ((long long)kk * a.m_padded + m0) * 16;
+    };
+    auto w_src = [&](int kt) -> const float* { return a.w + ((long long)kt * a.n_padded + n0) * 16; };
+
+    auto stage_issue = [&](int buf, int kt) {
+        float* xs = smem + buf * STAGE;
+        float* ws = xs + BM * 16;
+        if constexpr (L0) {
+            const int swz = (tid >> 2) & 3;
+#pragma unroll 1
+            for (int kk = 0; kk < 16; ++kk) {
+                const float v = pe_feature(kt * 16 + kk, px, py, pz, 3 + 6 * MOFA_PE_POINT_FREQS);
+                xs[tid * 16 + ((((kk >> 2) & 3) ^ swz) << 2) + (kk & 3)] = v;
+            }
+        } else {
+            const float* src = x_src(kt);
+#pragma unroll
+            for (int r = 0; r < XR; ++r) glds16(src + (r * 256 + tid) * 4, xs + (r * 256 + wave * 64) * 4);
+        }
+        const float* wsrc = w_src(kt);
+#pragma unroll
+        for (int r = 0; r < WR; ++r) glds16(wsrc + (r * 256 + tid) * 4, ws + (r * 256 + wave * 64) * 4);
+    };
+
+    f32x16 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    probe.entry();
+    if constexpr (PIPE) {
+        probe.kloop_begin();                     // (includes the first two panels' fetch)
+        kloop_pipelined<NI, NJ, BM, BN, P>(a.x1 + m0 * 16, a.k2p ? a.x2 + m0 * 16 : nullptr, a.w + (long long)n0 * 16, a.m_padded * 16,
+                                           (long long)a.n_padded * 16, a.k1p, KT, smem, tid, wave, lane, wm * (32 * NJ), wn * 64, acc, probe);
+    } else {
+        stage_issue(0, 0);
+        __syncthreads();
+        probe.kloop_begin();                     // first operand panel has landed: the K loop starts
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < KT) stage_issue(cur ^ 1, kt + 1);
+            const float* xs = smem + cur * STAGE;
+            mma_panel<NI, NJ, P>(xs, xs + BM * 16, wm * (32 * NJ), wn * 64, lane, acc);
+            __syncthreads();
+        }
+    }
+    probe.kloop_end();                           // K loop done: the epilogue starts
+
+    const int lr = lane & 31, g = lane >> 5;
+    if constexpr (P::kSinkEpilogue) {            // timing-only measurement policy: what a free epilogue would be worth
+        P::sink(acc, a.y);
+        return;
+    }
+    if constexpr (BWD && PIPE && P::kStagedEpilogue) {
+        float* win = smem + wave * 1024;
+        const long long mf = m0 + wm * (32 * NJ);
+        const int nf = n0 + wn * 64;
+        if (a.accumulate) {
+            if (a.mask) store_tile_staged_bwd<NI, NJ, true, true>(acc, a.y, a.mask, a.m_padded, mf, nf, lane, win);
+            else store_tile_staged_bwd<NI, NJ, true, false>(acc, a.y, a.mask, a.m_padded, mf, nf, lane, win);
+        } else {
+            if (a.mask) store_tile_staged_bwd<NI, NJ, false, true>(acc, a.y, a.mask, a.m_padded, mf, nf, lane, win);
+            else store_tile_staged_bwd<NI, NJ, false, false>(acc, a.y, a.mask, a.m_padded, mf, nf, lane, win);
+        }
+        return;
+    }
+    if constexpr (BWD) {
+        // backward-data epilogue: (acc [+ y_old]) [* (saved activation > 0)]
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const long long m = m0 + wm * (32 * NJ) + 32 * j + lr;
+            const int msw = (int)(m >> 2) & 3;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + 32 * i + 8 * q + 4 * g;
+                    const long long off = (long long)(n >> 4) * a.m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2);
+                    f32x4 v;
+                    v.x = acc[i][j][4 * q + 0], v.y = acc[i][j][4 * q + 1], v.z = acc[i][j][4 * q + 2],
+                    v.w = acc[i][j][4 * q + 3];
+                    if (a.accumulate) {
+                        const f32x4 o = *(const f32x4*)(a.y + off);
+                        v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+                    }
+                    if (a.mask) {
+                        const f32x4 k = *(const f32x4*)(a.mask + off);
+                        v.x = k.x > 0.f ? v.x : 0.f, v.y = k.y > 0.f ? v.y : 0.f, v.z = k.z > 0.f ? v.z : 0.f,
+                        v.w = k.w > 0.f ? v.w : 0.f;
+                    }
+                    *(f32x4*)(a.y + off) = v;
+                }
+            }
+        }
+        return;
+    }
+    // forward epilogue: bias + ReLU, into the next layer's panels
+    if constexpr (P::kStagedEpilogue && PIPE && !PERRAY && !HH) {
+        float* win = smem + wave * 1024;      // 4 KiB per wave inside stage 0 (free for everybody after the K loop's last barrier)
+        if (a.relu) store_tile_staged<NI, NJ, true>(acc, a.bias, a.y, a.m_padded, m0 + wm * (32 * NJ), n0 + wn * 64, lane, win);
+        else store_tile_staged<NI, NJ, false>(acc, a.bias, a.y, a.m_padded, m0 + wm * (32 * NJ), n0 + wn * 64, lane, win);
+    } else {
+        f32x4 bv[NI][4];
+        store_tile<NI, NJ, PERRAY, HH>(acc, a.bias, a.bias_rows, a.bias_row_div, a.n_padded, a.y, a.m_padded, m0 + wm * (32 * NJ),
+                                       n0 + wn * 64, a.relu, lane, bv);
+    }
+    probe.stores_issued();
+}
+
+}  // namespace
+}  // namespace mofa

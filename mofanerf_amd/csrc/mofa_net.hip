@@ -77,12 +77,8 @@ Config read_env() {
     Config c;
     auto tri = [](const char* name) { const char* e = getenv(name); return e ? (e[0] == '1' ? 1 : 0) : -1; };
     const char* e;
-    if ((e = getenv("MOFA_STAGE")) && e[0] == 'r') c.stage_glds = 0;
     if ((e = getenv("MOFA_SPLIT_V")) && e[0] == '1') c.split_v = 1;
-    c.bn64 = getenv("MOFA_BN64") != nullptr;
-    c.fused = tri("MOFA_FUSED"), c.split_hh = tri("MOFA_SPLIT_HH"), c.persist = tri("MOFA_PERSIST"), c.ring3 = tri("MOFA_RING3"), c.pipe = tri("MOFA_PIPE");
-    c.dephase = tri("MOFA_DEPHASE") == 1;
-    if ((e = getenv("MOFA_LDS_PAD"))) c.lds_pad = atoi(e);
+    c.fused = tri("MOFA_FUSED"), c.split_hh = tri("MOFA_SPLIT_HH"), c.pipe = tri("MOFA_PIPE");
     return c;
 }
 // two slots + an atomic index: readers never see a half-written snapshot, reload is rare and host-side only

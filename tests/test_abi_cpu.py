@@ -25,6 +25,23 @@ def test_library_exports_every_declared_symbol():
     assert sorted(lib.SIGNATURES) == syms, "python binding and header disagree"
 
 
+def test_library_exports_nothing_but_the_declared_abi():
+    """Built with -fvisibility=hidden: the dynamic symbol table holds exactly the functions of include/mofanerf_hip.h — no
+    mofa_internal_* hand-offs between translation units, no measurement entry points (those live in build_arms/libmofanerf_measure.so,
+    tools/build_measure.py), and the product sources carry no measurement arms."""
+    import subprocess
+    so = build.build()
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    funcs = sorted(l.split()[-1] for l in out.splitlines() if l.split()[1] in ("T", "W"))
+    assert funcs == header_symbols(), sorted(set(funcs) ^ set(header_symbols()))
+    csrc = os.path.join(ROOT, "mofanerf_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            src = open(os.path.join(csrc, f)).read()
+            for arm in ("MOFA_TIMELINE", "MOFA_ABLATE", "MOFA_SPLIT_FAKE", "MOFA_SETPRIO", "k_layer_persist", "k_layer_ring3", "k_mfma_peak_probe"):
+                assert arm not in src, (f, arm)
+
+
 def test_plan_sizes_and_argument_validation():
     L = lib.load()
     assert L.mofa_abi_version() == 1
@@ -41,7 +58,10 @@ def test_plan_sizes_and_argument_validation():
     assert L.mofa_layer_forward(None, 16, None, 0, None, None, 0, 1, None, 256, 64, 1, None) == -1
     assert b"null pointer" in L.mofa_last_error()
     assert L.mofa_composite_forward(1, 1, 0, 1, None, 4, 1, 0, 1, 1, 1, 1, 1, None) == -1
-    assert b"S" in L.mofa_last_error()
+    assert b"S >= 2" in L.mofa_last_error()
+    assert L.mofa_sample_pdf_merge(1, 0, 1, 1, 0, 4, 5000, 5000, 1, 1, 1, None) == -1      # 3 S + Ni floats of LDS per ray: 64 KiB
+    assert b"3 S + Ni" in L.mofa_last_error()
+    assert L.mofa_composite_backward(1, 1, 0, 1, None, 4, 20000, 0, 1, None, None, None, None, 1, None, None) == -1
 
 
 def test_product_never_imports_the_oracle():

@@ -201,8 +201,10 @@ def test_unsupported_flags_fail_loudly():
     with pytest.raises(RuntimeError, match="inference-only"):      # NeRF.forward (embedded inputs) refuses to drop gradients silently
         kw["network_fn"](torch.zeros(1, 93, device=DEV), torch.zeros(1, 50, device=DEV), torch.zeros(1, 27, device=DEV),
                          torch.zeros(1, 256, device=DEV))
-    with pytest.raises(lib.MofaError):
-        lib.check(lib.load().mofa_composite_forward(1, 1, 0, 1, None, 4, 300, 0, 1, 1, 1, 1, 1, None), "composite S=300")
+    with pytest.raises(lib.MofaError, match="S >= 2"):            # argument checks return before anything is launched
+        lib.check(lib.load().mofa_composite_forward(1, 1, 0, 1, None, 4, 1, 0, 1, 1, 1, 1, 1, None), "composite S=1")
+    with pytest.raises(lib.MofaError, match="3 S \\+ Ni"):        # one ray's positions, bins and cdf must fit 64 KiB of LDS
+        lib.check(lib.load().mofa_sample_pdf_merge(1, 0, 1, 1, 0, 4, 5000, 5000, 1, 1, 1, None), "sample_pdf_merge S=Ni=5000")
 
 
 def test_bulk_render_tool_and_ray_helpers(tmp_path):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the MFMA layer kernel through the C ABI: TFLOP/s of mofa_layer_forward at the shipped
-shapes, for both operand-staging arms (MOFA_STAGE=glds|reg).  Prints one line per case."""
+"""Micro-benchmark of the MFMA layer kernel through the C ABI: TFLOP/s of mofa_layer_forward at the shipped shapes (product
+library), and of the measurement arms of build_arms/libmofanerf_measure.so (tools/build_measure.py; `run(..., arm="ring3")`,
+`--arms`, `--persist`, `--peak`).  Prints one line per case."""
 import os
 import sys
 
@@ -39,11 +40,8 @@ def run_split(M, K, N, pieces, iters=10, version=2):
 def run_split_hh(M, K, N, iters=10):
     """fp16x3 with pre-split activation panels (net-internal entry point): time a layer whose INPUT is a real piece-panel
     tensor (the output of a first call), so operand statistics are those of the running network."""
-    import ctypes as C
-    f = L.mofa_internal_layer_split_hh
-    f.restype = C.c_int
-    f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p,
-                  C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
+    sys.exit("the net-internal piece-panel entry point is no longer exported (the library exports the C ABI only): time the mode "
+             "end to end with `python bench.py --gemm fp16x3` instead")
     w = torch.randn(N, K, device=dev) * (2.0 / K) ** 0.5
     b = torch.randn(N, device=dev) * 0.1
     ws = torch.empty(2 * N * K, dtype=torch.int16, device=dev)
@@ -71,7 +69,20 @@ def run_split_hh(M, K, N, iters=10):
     return ms, 2.0 * M * K * N / (ms * 1e-3) / 1e12
 
 
-def run(M, K, N, k2=0, iters=10):
+_measure = None
+
+
+def measure_lib():
+    global _measure
+    if _measure is None:
+        import build_measure
+        build_measure.build(verbose=False)
+        _measure = build_measure.load()
+    return _measure
+
+
+def run(M, K, N, k2=0, iters=10, arm=None):
+    """`arm` = None: the product's mofa_layer_forward; otherwise the named arm of the measurement library."""
     x = torch.randn(M * K, device=dev)
     x2 = torch.randn(M * k2, device=dev) if k2 else None
     w = torch.randn(N * (K + k2), device=dev) * 0.03
@@ -79,13 +90,19 @@ def run(M, K, N, k2=0, iters=10):
     y = torch.empty(M * N, device=dev)
     st = lib.stream()
     args = (lib.ptr(x), K, lib.ptr(x2), k2, lib.ptr(w), lib.ptr(b), 0, 1, lib.ptr(y), M, N, 1, st)
+    if arm is None:
+        launch = lambda: lib.check(L.mofa_layer_forward(*args), "layer")
+    else:
+        import build_measure
+        Lm = measure_lib()
+        launch = lambda: build_measure.check(Lm, Lm.mofa_measure_layer_forward(arm.encode(), *args), arm)
     for _ in range(3):
-        lib.check(L.mofa_layer_forward(*args), "layer")
+        launch()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        lib.check(L.mofa_layer_forward(*args), "layer")
+        launch()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
@@ -114,10 +131,7 @@ def run_bwd(M, K, N, iters=10):
 
 
 if __name__ == "__main__" and "--peak" in sys.argv:
-    import ctypes as C
-    f = L.mofa_internal_mfma_peak_probe
-    f.restype = C.c_int
-    f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    f = measure_lib().mofa_measure_mfma_peak_probe
     out = torch.zeros(16, device=dev)
     iters = 4096
     for blocks, rnd, label in ((512, 0, "constant operands, 2 waves/SIMD (512 workgroups = one round)"), (256, 0, "constant operands, 1 wave/SIMD"),
@@ -141,23 +155,27 @@ if __name__ == "__main__" and "--peak" in sys.argv:
               f"({flops / (ms * 1e-3) / 1e12 / 157.3 * 100:5.1f}% of 157.3)", flush=True)
     sys.exit(0)
 
-if __name__ == "__main__" and "--persist" in sys.argv:
-    # A/B of the persistent twin of the layer kernel (MOFA_PERSIST / MOFA_DEPHASE), interleaved rounds in ONE process
-    arms = [("per-tile workgroups (shipped)", {"MOFA_PERSIST": "0", "MOFA_DEPHASE": "0"}),
-            ("persistent", {"MOFA_PERSIST": "1", "MOFA_DEPHASE": "0"}),
-            ("persistent + dephase", {"MOFA_PERSIST": "1", "MOFA_DEPHASE": "1"})]
-    for (M, K, N, k2) in ((196608, 1024, 1024, 0), (196608, 1024, 1024, 1024), (196608, 256, 256, 0), (131072, 1024, 1024, 0)):
-        res = {name: [] for name, _ in arms}
-        for rnd in range(3):
-            for name, env in arms:
-                os.environ.update(env)
-                lib.reload_env()
-                ms, tf = run(M, K, N, k2, iters=20)
-                res[name].append(tf)
-        for name, _ in arms:
-            v = res[name]
-            print(f"M={M:7d} K={K + k2:5d} N={N:5d} {name:32s}: " + " ".join(f"{t:7.2f}" for t in v) +
+def ab(arms, cases, rounds=3, iters=20):
+    """Interleaved A/B in ONE process: every round runs every arm once, so that clock / thermal drift hits all of them alike."""
+    for (M, K, N, k2) in cases:
+        res = {a: [] for a in arms}
+        for _ in range(rounds):
+            for a in arms:
+                res[a].append(run(M, K, N, k2, iters=iters, arm=None if a == "product" else a)[1])
+        for a in arms:
+            v = res[a]
+            print(f"M={M:7d} K={K + k2:5d} N={N:5d} {a:18s}: " + " ".join(f"{t:7.2f}" for t in v) +
                   f"  TFLOP/s (best {max(v):7.2f} = {max(v) / 157.3 * 100:5.1f}% of fp32 MFMA peak)", flush=True)
+
+
+if __name__ == "__main__" and "--persist" in sys.argv:
+    ab(["product", "plain", "persist", "persist_dephase"], ((196608, 1024, 1024, 0), (196608, 1024, 1024, 1024), (196608, 256, 256, 0), (131072, 1024, 1024, 0)))
+    sys.exit(0)
+
+if __name__ == "__main__" and "--arms" in sys.argv:
+    i = sys.argv.index("--arms")
+    names = sys.argv[i + 1].split(",") if len(sys.argv) > i + 1 else measure_lib().mofa_measure_arms().decode().split(",")
+    ab(["product"] + [n for n in names if n != "timeline"], ((196608, 1024, 1024, 0), (196608, 256, 256, 0), (32768, 1024, 1024, 0)))
     sys.exit(0)
 
 if __name__ == "__main__" and "--split-hh" in sys.argv:
@@ -183,10 +201,8 @@ if __name__ == "__main__" and "--split" in sys.argv:
 if __name__ == "__main__":
     cases = [(196608, 1024, 1024, 0), (196608, 1024, 1024, 1024), (196608, 1024, 512, 0), (196608, 256, 256, 0),
              (196608, 256, 256, 256), (32768, 1024, 1024, 0), (65536, 64, 64, 0)]
-    for stage in ("glds", "reg"):
-        os.environ["MOFA_STAGE"] = stage
-        lib.reload_env()
-        for (M, K, N, k2) in cases:
-            ms, tf = run(M, K, N, k2)
-            print(f"stage={stage:4s} M={M:7d} K={K + k2:5d} N={N:5d}: {ms:8.3f} ms  {tf:7.2f} TFLOP/s  "
-                  f"({tf / 157.3 * 100:5.1f}% of fp32 MFMA peak)", flush=True)
+    for (M, K, N, k2) in cases:
+        ms, tf = run(M, K, N, k2)
+        print(f"M={M:7d} K={K + k2:5d} N={N:5d}: {ms:8.3f} ms  {tf:7.2f} TFLOP/s  ({tf / 157.3 * 100:5.1f}% of fp32 MFMA peak)", flush=True)
+    ms, tf = run_bwd(196608, 1024, 1024)
+    print(f"backward-data M=196608 K=N=1024: {ms:8.3f} ms  {tf:7.2f} TFLOP/s", flush=True)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-workgroup TIMELINE of the dominant kernel (measurement build: `MOFA_TIMELINE=1 MOFA_LIB_OUT=build_arms/timeline.so
-python -m mofanerf_amd.build --force`, then `MOFA_LIB=build_arms/timeline.so python tools/timeline_layer.py`).
+"""Per-workgroup TIMELINE of the dominant kernel: the "timeline" arm of the measurement library (the shipped layer kernel source
+under a policy whose hooks write time stamps; `python tools/build_measure.py`, then `python tools/timeline_layer.py`).
 
 Every workgroup of one launch of `k_layer<128,false,true>` at the shipped fine-network shape (M = 196608 points, K = N = 1024:
 6,144 tiles = 12 rounds of the 512 resident workgroups) records four `wall_clock64()` stamps (100 MHz) — entry, first operand
@@ -21,10 +21,16 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mofanerf_amd import lib  # noqa: E402
 
-L = lib.load()
-if not hasattr(L, "mofa_internal_set_timeline"):
-    sys.exit("this needs the measurement build: MOFA_LIB=build_arms/timeline.so (see the docstring)")
-L.mofa_internal_set_timeline.restype, L.mofa_internal_set_timeline.argtypes = C.c_int, [C.c_void_p]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import build_measure  # noqa: E402
+
+build_measure.build(verbose=False)
+Lm = build_measure.load()
+
+
+def layer(*a):
+    """the stamped kernel (stamps are written only while a buffer is set)"""
+    return Lm.mofa_measure_layer_forward(b"timeline", *a)
 
 M, K, N = 196608, 1024, 1024
 tiles = (M // 256) * (N // 128)
@@ -38,7 +44,7 @@ def timed(n):
     a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a0.record()
     for _ in range(n):
-        lib.check(L.mofa_layer_forward(*args), "layer")
+        build_measure.check(Lm, layer(*args), "timeline layer")
     a1.record()
     torch.cuda.synchronize()
     return a0.elapsed_time(a1) / n
@@ -52,15 +58,15 @@ torch.cuda.synchronize()
 # the stamped launch sits in the MIDDLE of a back-to-back stream of launches: an isolated launch after a host synchronisation
 # runs at a reduced engine clock (measured with these very stamps: 1.9 GHz instead of 2.3-2.4) while the power state ramps up
 for _ in range(20):
-    lib.check(L.mofa_layer_forward(*args), "layer")
-L.mofa_internal_set_timeline(C.c_void_p(tl.data_ptr()))      # host-side switch, read at launch time
+    build_measure.check(Lm, layer(*args), "timeline layer")
+Lm.mofa_measure_set_timeline(C.c_void_p(tl.data_ptr()))      # host-side switch, read at launch time
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-lib.check(L.mofa_layer_forward(*args), "layer")
+build_measure.check(Lm, layer(*args), "timeline layer")
 e1.record()
-L.mofa_internal_set_timeline(None)
+Lm.mofa_measure_set_timeline(None)
 for _ in range(5):
-    lib.check(L.mofa_layer_forward(*args), "layer")
+    build_measure.check(Lm, layer(*args), "timeline layer")
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
 raw = tl.cpu().numpy()
