@@ -46,11 +46,12 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Pe
 H = W = 512
 ARCH = (8, 256, 10, 1024)
 N_SAMPLES, N_IMPORTANCE = 64, 64
-KERNELS = ["mofa::k_layer<128,false,false,false,false,true,mofa::ShippedPolicy> (fp32 MFMA Linear+bias+ReLU, software-pipelined K loop; template = <BN,L0,BWD,HH,PERRAY,PIPE,policy>)",
-           "mofa::k_mlp_fused (persistent fp32-MFMA network kernel, widths <= 256)",
-           "mofa::k_layer<128,false,true,false,false,true,mofa::ShippedPolicy> (BWD: fp32 MFMA backward-data GEMM + ReLU mask, the same K loop)",
-           "mofa::k_wgrad<128,256> (fp32 MFMA weight-gradient GEMM, contraction over points)",
-           "mofa::k_layer<128,false,false,false,true,true,mofa::ShippedPolicy> (PERRAY: the same kernel with the view layer's per-ray bias)"]
+# (symbol, role, description) per profiler kind of libmofanerf_hip.so; k_layer's template = <BN, L0, BWD, HH, PERRAY, PIPE, policy>
+KERNELS = [("mofa::k_layer<128,false,false,false,false,true,mofa::ShippedPolicy>", "forward", "fp32 MFMA Linear+bias+ReLU, software-pipelined K loop"),
+           ("mofa::k_mlp_fused", "forward, persistent", "persistent fp32-MFMA network kernel, widths <= 256"),
+           ("mofa::k_layer<128,false,true,false,false,true,mofa::ShippedPolicy>", "BWD backward-data", "fp32 MFMA backward-data GEMM + ReLU mask, the same K loop"),
+           ("mofa::k_wgrad<128,256>", "weight gradient", "fp32 MFMA weight-gradient GEMM, contraction over points"),
+           ("mofa::k_layer<128,false,false,false,true,true,mofa::ShippedPolicy>", "forward, PERRAY view layer", "the same kernel with the view layer's per-ray bias")]
 
 
 def pose_spherical(phi_deg, theta_deg, radius):
@@ -354,10 +355,11 @@ def main():
         # launches; at the benchmark sizes nothing is padded (K, N multiples of 64, M a multiple of 256), except layer 0's
         # K = 63 -> 64 inside the persistent kernel (0.1 %).
         dom = max(range(NK), key=lambda k: ms[k])
-        kname = KERNELS[dom]
+        ksym, krole, kdesc = KERNELS[dom]
         if a.gemm != "fp32" and dom == 0:
-            kname = (f"mofa::k_layer_split<128,{3 if a.gemm == 'bf16x6' else 2}> ({a.gemm} split products on the 16-bit matrix "
-                     "pipe; peak quoted = fp32 MFMA)")
+            ksym, kdesc = (f"mofa::k_layer_split<128,{3 if a.gemm == 'bf16x6' else 2}>",
+                           f"{a.gemm} split products on the 16-bit matrix pipe; peak quoted = fp32 MFMA")
+        kname = f"{ksym} ({kdesc})"
         achieved = pflops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         traffic, tinfo = None, {}
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")       # PMC-derived bytes/launch (separate --pmc passes)
@@ -377,7 +379,7 @@ def main():
             else:
                 tinfo = {"traffic_source": f"null: profiles/hbm_traffic.json was taken on kernel sources {str(tj.get('csrc_sha256'))[:16]} / "
                                            f"{tj.get('kernel')}, this build is {digest[:16]} / {kname.split(' ')[0]} — re-run tools/gpu_profile_round.sh"}
-        others = [{"kernel": KERNELS[k].split(" ")[0], "launches": int(launches[k]), "total_ms": round(ms[k], 2),
+        others = [{"kernel": KERNELS[k][0], "role": KERNELS[k][1], "launches": int(launches[k]), "total_ms": round(ms[k], 2),
                    "tflops": round(pflops[k] / (ms[k] * 1e-3) / 1e12, 2)} for k in range(NK) if k != dom and ms[k] > 0]
         fwd = flops_per_ray(True)
         work = {"render": fwd, "fit": 2 * fwd, "train": 3 * fwd}[a.mode]    # + backward-data (+ weight gradients)
@@ -402,7 +404,7 @@ def main():
                        "gflop_per_ray_folded": round(work / 1e9, 4),
                        "gflop_per_ray_nominal": round(work / fwd * flops_per_ray(False) / 1e9, 4)},
             "whole_path_tflops": round(work * units_per_s / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": kname,
+            "roofline": {"bound": "mfma", "kernel": kname, "role": krole,
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "launches": int(launches[dom]), "avg_launch_ms": round(ms[dom] / max(1, launches[dom]), 4),

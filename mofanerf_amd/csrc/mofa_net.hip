@@ -457,6 +457,15 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
                 MOFA_TRY(mofa_internal_layer_split_hh(st.x1, l.k_padded[0], st.x2, st.x2 ? l.k_padded[1] : 0,
                                                       packed_split + l.split_elems_off * 2, view ? view_bias_rows : folded + l.folded_off,
                                                       view ? S : 0, view ? n_rays : 1, st.y, Mp, l.n_padded, 1, stream));
+            } else if (!st.x1 && !pts && l.n_padded % 128 == 0 && l.n_padded >= 512 && st.y != t1 && config().pipe != 0) {
+                // Wide first layer: the 63 encoding features of every point are computed ONCE into panels (t1 is free until layer 1
+                // writes it) and the layer runs as an ordinary K = 64 launch of the pipelined kernel.  The generated-operand kernel
+                // (k_layer<.., L0>) re-derives them in each of the n_padded / 128 feature-tile workgroups of a point tile — 8 times
+                // at width 1024, which bounded that launch at 62 TFLOP/s (414 us per 196,608 points).  Same
+                // features (pe_feature's formula, separately rounded o + d z), same MFMA order, same epilogue: bit-identical.
+                MOFA_TRY(mofa_pe_panels(rays_o, rays_d, z, z_row_stride, M, S, Mp, t1, stream));
+                MOFA_TRY(mofa_layer_forward(t1, 64, nullptr, 0, packed + l.packed_off, folded + l.folded_off, 0, 1, st.y, Mp, l.n_padded,
+                                            1, stream));
             } else if (!st.x1) {
                 MOFA_TRY(mofa_layer0_forward(rays_o, rays_d, z, z_row_stride, pts, M, S, packed + l.packed_off,
                                              folded + l.folded_off, st.y, Mp, l.n_padded, stream));

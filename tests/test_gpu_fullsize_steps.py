@@ -89,7 +89,7 @@ def test_config2_fit_step_1024_rays_gradient_parity():
 
     def oracle_grads(dtype):
         o = _oracle(dtype)
-        c2 = c2w0.to(dtype).requires_grad_(True)
+        c2 = c2w0.to(dtype).clone().requires_grad_(True)        # (clone: .to() of an fp32 tensor to fp32 is the tensor itself)
         b_, t_, e_ = [t.to(dtype).clone().requires_grad_(True) for t in (bm0, tex0, exp0)]
         li = torch.full((1,), 1.1, dtype=dtype, requires_grad=True)
         o.exp_sigma.append(e_)

@@ -585,6 +585,38 @@ def test_persistent_fused_network_is_bit_identical_to_per_layer_launches(D, W, R
     nan_equal_close(tapes["1"].cpu().numpy(), outs["1"].cpu().numpy(), 2e-5)
 
 
+@pytest.mark.parametrize("D,W,R,S", [(10, 1024, 70, 128), (8, 512, 33, 64)])
+def test_wide_first_layer_through_encoding_panels_is_bit_identical(D, W, R, S, knob):
+    """Widths >= 512: the first layer's encoding features are computed once into panels (`mofa_pe_panels`) and the layer runs as a
+    K = 64 launch of the pipelined kernel, instead of every feature-tile workgroup regenerating them (k_layer<.., L0>).  MOFA_PIPE=0
+    keeps the generated-operand kernel (and the plain loops): the whole network — inference and tape — must agree bit for bit."""
+    from mofanerf_amd.autograd import NetFn, view_bias_torch
+    from mofanerf_amd.hipnet import HipNet
+    from mofanerf_amd.model import NeRF
+    rng = np.random.default_rng(D + W)
+    net = NeRF(D=D, W=W, input_ch=93, input_ch_views=27, input_ch_textureCodes=256, input_ch_shapeCodes=50, use_viewdirs=True)
+    net.load_state_dict(synth.nerf_state(D, W, 1))
+    h = HipNet(net.to(DEV))
+    o = dev(rng.uniform(-2, 2, (R, 3)).astype(np.float32))
+    d = dev(rng.normal(0, 0.3, (R, 3)).astype(np.float32))
+    z = dev(np.sort(rng.uniform(8, 26, (R, S)).astype(np.float32), -1))
+    vd = torch.nn.functional.normalize(d, dim=-1).contiguous()
+    bm, tex, e = synth.codes(3)
+    folded = h.fold(e.to(DEV), bm.to(DEV), tex.to(DEV)).clone()
+    outs, tapes = {}, {}
+    for mode in ("0", "1"):
+        knob("MOFA_PIPE", mode)
+        raw = torch.full((R, S, 4), float("nan"), device=DEV)
+        h.forward_rays(o, d, z, S, vd, S, raw, folded)
+        outs[mode] = raw.clone()
+        with torch.enable_grad():
+            tapes[mode] = NetFn.apply(h, o, d, z, S, S, folded, view_bias_torch(h, vd).detach()).detach().clone()
+        torch.cuda.synchronize()
+    assert torch.equal(outs["0"], outs["1"]) and torch.isfinite(outs["1"]).all()
+    assert torch.equal(tapes["0"], tapes["1"])
+    nan_equal_close(tapes["1"].cpu().numpy(), outs["1"].cpu().numpy(), 2e-5)      # (tape mode takes torch's per-ray view-bias rows)
+
+
 @pytest.mark.parametrize("version", [1, 2])
 @pytest.mark.parametrize("pieces,tol", [(3, 1.5e-5), (2, 2e-3), (-2, 2e-5)])
 @pytest.mark.parametrize("M,K,N,k2", [(512, 128, 128, 0), (1024, 1024, 256, 0), (777, 256, 128, 256), (256, 16, 128, 0)])

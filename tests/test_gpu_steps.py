@@ -156,7 +156,7 @@ def test_bench_fit_and_train_modes_emit_contract_lines(mode):
         assert k in j, k
     assert j["config"]["mode"] == mode and j["scaling"] == "weak" and j["value"] > 0 and j["config"]["rays_per_step"] == 512
     assert j["roofline"]["bound"] == "mfma" and j["roofline"]["achieved"] > 0 and j["roofline"]["launches"] > 0
-    kinds = [j["roofline"]["kernel"]] + [o["kernel"] for o in j["roofline"]["other_mfma_kernels"]]
+    kinds = [j["roofline"]["role"] + " " + j["roofline"]["kernel"]] + [o["role"] + " " + o["kernel"] for o in j["roofline"]["other_mfma_kernels"]]
     assert any("BWD" in k for k in kinds) and (mode == "fit" or any("k_wgrad" in k for k in kinds))
 
 

@@ -22,7 +22,7 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LD
   rm -rf /tmp/pmc_$n
   rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$n -o pmc -- python tools/pmc_layer.py > /dev/null 2> gpurun_out/$tag/pmc_$n.err
   f=$(find /tmp/pmc_$n -name '*counter_collection.csv' | head -1)
-  [ -n "$f" ] && grep -E "Kernel_Name|k_layer" "$f" | cut -c1-400 | head -40 > gpurun_out/$tag/pmc_$n.csv
+  [ -n "$f" ] && grep -E "Kernel_Name|k_layer" "$f" | cut -c1-400 | head -80 > gpurun_out/$tag/pmc_$n.csv
 done
 python tools/make_traffic_json.py gpurun_out/$tag gpurun_out/$tag/hbm_traffic.json > /dev/null 2> gpurun_out/$tag/hbm_traffic.err
 python tools/kernel_resources.py mofanerf_amd/libmofanerf_hip.so gpurun_out/$tag/kernel_resources.md
@@ -31,4 +31,10 @@ rm -rf /tmp/prof_rccl
 rocprofv3 --kernel-trace --stats -d /tmp/prof_rccl -o rccl -- python tools/rccl_world1.py > gpurun_out/$tag/rccl_world1.json 2> gpurun_out/$tag/rccl_world1.err
 db=$(find /tmp/prof_rccl -name '*.db' | head -1)
 [ -n "$db" ] && python tools/rocpd_stats.py "$db" gpurun_out/$tag/kernel_stats_rccl_world1.md "rocprofv3 --kernel-trace --stats -- python tools/rccl_world1.py"
+# the round's plain bench lines (no profiler attached), with the PMC traffic of THIS build next to the live roofline figure
+cp gpurun_out/$tag/hbm_traffic.json profiles/hbm_traffic.json
+python bench.py > gpurun_out/$tag/bench_n1.json 2> gpurun_out/$tag/bench_n1.err
+python bench.py --mode fit > gpurun_out/$tag/bench_fit_n1.json 2> gpurun_out/$tag/bench_fit_n1.err
+python bench.py --mode train > gpurun_out/$tag/bench_train_n1.json 2> gpurun_out/$tag/bench_train_n1.err
+python bench.py --arch 8 256 8 256 --cpu-rays 0 --parity-rays 0 > gpurun_out/$tag/bench_n1_variant_fine256x8.json 2> /dev/null
 ls -la gpurun_out/$tag

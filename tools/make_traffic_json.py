@@ -56,11 +56,16 @@ out = {
             "16-B/lane streams); WRITE_SIZE uncalibrated per the guide (compare with algorithmic_write_bytes); mfma_busy_fraction = "
             "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); cross-check: TCC_MISS_sum x 128 B",
 }
-try:      # control: N = 128 (one feature tile per point tile): past-L2 reads with the weights out of the picture
-    f128, _ = mean(rows("FETCH_SIZE"), "FETCH_SIZE", grid=(M // 256) * 256)
-    w128, _ = mean(rows("WRITE_SIZE"), "WRITE_SIZE", grid=(M // 256) * 256)
-    out["control_n128"] = {"fetch_size_corrected_x2_bytes": int(f128 * 2048), "write_size_bytes": int(w128 * 1024),
-                           "algorithmic_read_bytes": (M * K + 128 * K + 128) * 4, "algorithmic_write_bytes": M * 128 * 4}
+try:      # controls: N = 512 / 256 / 128 (4 / 2 / 1 feature tiles per point tile): the same activation read, smaller weight slabs
+    ctl = {}
+    for n_ in (512, 256, 128):
+        g_ = (M // 256) * (n_ // 128) * 256
+        f_, _ = mean(rows("FETCH_SIZE"), "FETCH_SIZE", grid=g_)
+        w_, _ = mean(rows("WRITE_SIZE"), "WRITE_SIZE", grid=g_)
+        ctl[f"n{n_}"] = {"fetch_size_corrected_x2_bytes": int(f_ * 2048), "write_size_bytes": int(w_ * 1024),
+                         "algorithmic_read_bytes": (M * K + n_ * K + n_) * 4, "algorithmic_write_bytes": M * n_ * 4,
+                         "weight_slab_bytes": n_ * K * 4}
+    out["controls_same_activations_narrower_layers"] = ctl
 except (OSError, SystemExit):
     pass
 try:
