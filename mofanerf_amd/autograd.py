@@ -66,7 +66,24 @@ def view_bias_torch(h: HipNet, viewdirs: torch.Tensor, detach_params: bool = Fal
 
 
 class NetFn(torch.autograd.Function):
-    """raw[R,S,4] = NeRF(PE(o + d z), folded biases, per-ray view bias) with a HIP backward."""
+    """raw[R,S,4] = NeRF(PE(o + d z), folded biases, per-ray view bias) with a HIP backward.
+
+    ``h.tape_recompute`` (set through ``Renderer.tape_recompute``): the forward keeps NO tape — it is the inference launch, four recycled
+    activation buffers — and the backward first re-runs the forward of its sub-batch in tape mode, then walks it.  Same kernels, same
+    values bit for bit (the two forward modes differ only in where layer outputs land); the saved state of a training step drops from
+    98 KiB per fine-network point for EVERY sub-batch (52.6 GB at N_rand = 4096) to one sub-batch's tape at a time (bounded by netchunk,
+    not by N_rand), for one extra forward pass per step."""
+
+    @staticmethod
+    def _forward(h: HipNet, ro, rd, zc, z_row_stride, S, fo, vb, tape):
+        L = h._L
+        R = ro.shape[0]
+        raw = torch.empty(R, S, 4, dtype=torch.float32, device=ro.device)
+        ws = h.workspace(R * S, R, ro.device)
+        lib.check(L.mofa_net_forward(h.shape, lib.ptr(h.packed()), lib.ptr(fo), None, None, lib.ptr(ro), lib.ptr(rd),
+                                     lib.ptr(zc), z_row_stride, None, None, R, S, lib.ptr(ws), lib.ptr(raw), lib.ptr(tape),
+                                     lib.ptr(vb), None, 0, lib.stream()), "mofa_net_forward(tape)" if tape is not None else "mofa_net_forward")
+        return raw
 
     @staticmethod
     def forward(ctx, h: HipNet, rays_o, rays_d, z, z_row_stride: int, S: int, folded, vbias, *weights):
@@ -79,14 +96,16 @@ class NetFn(torch.autograd.Function):
         ro, rd = rays_o.detach().contiguous(), rays_d.detach().contiguous()
         zc = z.detach().contiguous()
         fo, vb = folded.detach().contiguous(), vbias.detach().contiguous()
-        raw = torch.empty(R, S, 4, dtype=torch.float32, device=dev)
-        tape = torch.empty(L.mofa_net_tape_floats(h.shape, R * S), dtype=torch.float32, device=dev)
-        ws = h.workspace(R * S, R, dev)
-        lib.check(L.mofa_net_forward(h.shape, lib.ptr(h.packed()), lib.ptr(fo), None, None, lib.ptr(ro), lib.ptr(rd),
-                                     lib.ptr(zc), z_row_stride, None, None, R, S, lib.ptr(ws), lib.ptr(raw), lib.ptr(tape),
-                                     lib.ptr(vb), None, 0, lib.stream()), "mofa_net_forward(tape)")
+        recompute = bool(getattr(h, "tape_recompute", False))
+        tape = None if recompute else torch.empty(L.mofa_net_tape_floats(h.shape, R * S), dtype=torch.float32, device=dev)
+        raw = NetFn._forward(h, ro, rd, zc, z_row_stride, S, fo, vb, tape)
         ctx.h, ctx.S, ctx.z_row_stride = h, S, z_row_stride
-        ctx.save_for_backward(ro, rd, zc, tape)
+        if recompute:
+            ctx.save_for_backward(ro, rd, zc, fo, vb)
+            ctx.key = h._key()                      # the weights the forward ran on: the recomputation must see the same ones
+        else:
+            ctx.save_for_backward(ro, rd, zc, tape)
+        ctx.recompute = recompute
         ctx.n_folded, ctx.vb_shape = fo.numel(), tuple(vb.shape)
         ctx.w_shapes = [tuple(w.shape) for w in weights]
         return raw
@@ -95,7 +114,15 @@ class NetFn(torch.autograd.Function):
     def backward(ctx, d_raw):
         h, S = ctx.h, ctx.S
         L = h._L
-        ro, rd, zc, tape = ctx.saved_tensors
+        if ctx.recompute:
+            ro, rd, zc, fo, vb = ctx.saved_tensors
+            if h._key() != ctx.key:
+                raise lib.MofaError("tape_recompute: a network weight changed between forward and backward (the forward pass cannot be "
+                                    "reproduced); step the optimizer after backward, or switch tape_recompute off")
+            tape = torch.empty(L.mofa_net_tape_floats(h.shape, ro.shape[0] * S), dtype=torch.float32, device=ro.device)
+            NetFn._forward(h, ro, rd, zc, ctx.z_row_stride, S, fo, vb, tape)
+        else:
+            ro, rd, zc, tape = ctx.saved_tensors
         R, dev = ro.shape[0], ro.device
         d_raw = d_raw.contiguous()
         d_folded = torch.empty(ctx.n_folded, dtype=torch.float32, device=dev)
@@ -107,6 +134,7 @@ class NetFn(torch.autograd.Function):
                                       lib.ptr(ro), lib.ptr(rd), lib.ptr(zc), ctx.z_row_stride, R, S, lib.ptr(ws),
                                       lib.ptr(d_folded), lib.ptr(d_vb), lib.ptr(d_o), lib.ptr(d_d),
                                       lib.ptr_array(dws) if dws else None, lib.stream()), "mofa_net_backward")
+        del tape
         return (None, d_o, d_d, None, None, None, d_folded, d_vb, *dws)
 
 

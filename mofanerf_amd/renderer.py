@@ -91,6 +91,11 @@ class Renderer(torch.nn.Module):
         self._weight_grads = False
         self._tex_cache = None
         self._cache: Dict[tuple, torch.Tensor] = {}
+        # training / fitting memory: False (default) keeps every layer output of every sub-batch for the backward (nothing is
+        # recomputed: 98 KiB per fine-network point, 52.6 GB at N_rand = 4096 — sized for 288 GB); True keeps only the inputs and
+        # re-runs each sub-batch's forward inside its backward (autograd.NetFn): one sub-batch's tape at a time, bit-identical gradients,
+        # one extra forward pass per step.  MOFA_TAPE=recompute sets it for every renderer.
+        self.tape_recompute = os.environ.get("MOFA_TAPE", "") == "recompute"
         self.n_streams = int(os.environ.get("MOFA_STREAMS", "1"))   # concurrent sub-batches of the inference path (render_rays)
         self._streams = {}
         self.png_sink = None      # optional mofanerf_amd.io.PngSink shared by consecutive render_path calls (bulk renders)
@@ -297,6 +302,7 @@ class Renderer(torch.nn.Module):
             h = self._hip(net)
             rays_per = max(1, int(self.netchunk) // n_s)
             if grad:     # tape-keeping forward per sub-batch; the per-ray view bias is a differentiable torch expression
+                h.tape_recompute = bool(self.tape_recompute)
                 vb = view_bias_torch(h, vd, detach_params=not self._weight_grads)
                 wts = [l.weight for l in h._linears] if self._weight_grads else []
                 parts = [NetFn.apply(h, rays_o[i:i + rays_per], rays_d[i:i + rays_per],

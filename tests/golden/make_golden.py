@@ -170,24 +170,26 @@ def g1_kats():
     save("kat.npz", out)
 
 
-def _case_setup(H, K, angle, Dc, Wc, Df, Wf, chunk, netchunk, perturb=0.0, noise=0.0, white=False, pytest=False, seed=0):
+def _case_setup(H, K, angle, Dc, Wc, Df, Wf, chunk, netchunk, perturb=0.0, noise=0.0, white=False, pytest=False, seed=0,
+                N_samples=64, N_importance=64):
     r = mk_renderer(netchunk, seed)
     coarse, fine = mk_nerf(Dc, Wc, seed, "coarse"), mk_nerf(Df, Wf, seed, "fine")
-    kw = kwargs_for(r, coarse, fine, perturb, noise, white)
+    kw = kwargs_for(r, coarse, fine, perturb, noise, white, N_samples, N_importance)
     if pytest:
         kw["pytest"] = True
     bm, tex, exp = synth.codes(seed)
     c2w = pose_spherical(angle, 0.0, 16.0)[:3, :4]
     meta = dict(c2w=c2w, K=K, bm=bm, tex=tex, exp=exp, H=H, chunk=chunk, netchunk=netchunk,
-                arch=np.array([Dc, Wc, Df, Wf]), seed=seed, perturb=perturb, noise=noise, white=int(white))
+                arch=np.array([Dc, Wc, Df, Wf]), seed=seed, perturb=perturb, noise=noise, white=int(white),
+                N_samples=N_samples, N_importance=N_importance)
     call = lambda: r.render_fitting(H, H, K, chunk=chunk, c2w=c2w, shapeCodes=bm, uvCodes=tex, expType=20, expCodes=exp,
                                     retraw=True, **kw)
     return call, meta
 
 
 def _render_case(name, H, K, angle, Dc, Wc, Df, Wf, chunk, netchunk, perturb=0.0, noise=0.0, white=False,
-                 pytest=False, intermediates=True, seed=0):
-    call, out = _case_setup(H, K, angle, Dc, Wc, Df, Wf, chunk, netchunk, perturb, noise, white, pytest, seed)
+                 pytest=False, intermediates=True, seed=0, N_samples=64, N_importance=64):
+    call, out = _case_setup(H, K, angle, Dc, Wc, Df, Wf, chunk, netchunk, perturb, noise, white, pytest, seed, N_samples, N_importance)
     with torch.no_grad(), Recorder() as rec:
         rgb, disp, acc, ex = call()
     out.update(rgb=rgb, disp=disp, acc=acc, rgb0=ex["rgb0"], disp0=ex["disp0"], acc0=ex["acc0"], z_std=ex["z_std"])
@@ -565,6 +567,13 @@ def g10_checkpoint():
     save("ckpt_render.npz", out)
 
 
+def g15_long_rays():
+    """More than 256 samples per ray (the reference has no limit: N_samples / N_importance are free flags): 36 rays with 300 coarse +
+    212 importance samples — pins the oracle, and through it the multi-pass compositing / resampling kernels, at that size."""
+    K6 = np.array([[14.0625, 0, 3.0], [0, 14.0625, 3.0], [0, 0, 1]])       # 6x6 image, focal 1200 * 6 / 512
+    _render_case("e2e_long.npz", 6, K6, 35.0, 8, 64, 10, 64, chunk=20, netchunk=4096, N_samples=300, N_importance=212)
+
+
 class _DrawLog:
     """Record (or replace) what ``np.random.randn`` / ``np.random.choice`` hand to the reference's samplers, so that the device
     samplers can be fed the SAME draws (``draws=`` of mofanerf_amd.rays.train_pixels / fit_pixels)."""
@@ -659,7 +668,7 @@ def g14_samplers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for w in which:
         {"g1": g1_kats, "g2": g2_small, "g3": g3_true, "g4": g4_grads, "g5": g5_render_tex, "g6": g6_schema, "g7": g7_config1, "g8": g8_true_grads, "g9": g9_run_network_kat,
-         "g10": g10_checkpoint, "g11": g11_envelopes, "g12": g12_pose_grads, "g13": g13_ndc, "g14": g14_samplers}[w]()
+         "g10": g10_checkpoint, "g11": g11_envelopes, "g12": g12_pose_grads, "g13": g13_ndc, "g14": g14_samplers, "g15": g15_long_rays}[w]()

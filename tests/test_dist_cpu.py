@@ -98,3 +98,9 @@ def test_forced_collectives_on_one_rank():
     assert not mdist.active()                                                        # no group in the test process itself
     mp.spawn(_forced_worker, args=(1, _free_port()), nprocs=1, join=True)
     os.environ.pop("MOFA_DIST_FORCE_COLLECTIVES", None)
+
+
+def test_all_gather_tiles_gloo_world8_benchmark_frame_shape():
+    """The shape the 8-GPU run takes: a 512 x 512 frame split into eight 64-row blocks, ONE all-gather written straight into the
+    frame (equal blocks: no padding path), max-over-ranks timing — on gloo / CPU."""
+    mp.spawn(_worker, args=(8, _free_port(), 512 * 512, 512), nprocs=8, join=True)

@@ -106,7 +106,8 @@ def _teacher_forced(g, tol=1e-4):
         render.expCodes_Sigma.append(T(g["exp"]).to(DEV))
     R = H * H
     outs = {}
-    for tag, net, S in (("coarse", kw["network_fn"], 64), ("fine", kw["network_fine"], 128)):
+    Ns, Ni = (int(g["N_samples"]), int(g["N_importance"])) if "N_samples" in g else (64, 64)
+    for tag, net, S in (("coarse", kw["network_fn"], Ns), ("fine", kw["network_fine"], Ns + Ni)):
         with torch.no_grad():
             folded = render._fold_codes(net, T(g["tex"]).to(DEV))
         z = T(g[f"z_{tag}"]).contiguous().to(DEV)
@@ -131,6 +132,35 @@ def _teacher_forced(g, tol=1e-4):
 
 def test_fine_pass_teacher_forced_small(golden):
     _teacher_forced(golden("e2e_small.npz"))
+
+
+def test_long_rays_teacher_forced_and_end_to_end(golden):
+    """Fixture written by the reference with 300 coarse + 212 importance samples per ray (no sample limit there; on the device these
+    rays take the multi-pass compositing kernels and the 2-rays-per-block resampler): teacher-forced coarse and fine passes within
+    1e-4 on every ray, and the end-to-end call — coarse outputs 1e-4, every resampled position agreeing or explained, merged
+    positions sorted."""
+    from harness import classify_samples
+    g = golden("e2e_long.npz")
+    _teacher_forced(g)
+    Ns, Ni = int(g["N_samples"]), int(g["N_importance"])
+    render, kw, _ = make_product(tuple(int(v) for v in g["arch"]), int(g["seed"]), int(g["netchunk"]), DEV, N_samples=Ns, N_importance=Ni)
+    H = int(g["H"])
+    with torch.no_grad():
+        rgb, disp, acc, ex = render.render_fitting(H, H, g["K"], chunk=int(g["chunk"]), c2w=T(g["c2w"]), shapeCodes=T(g["bm"]).to(DEV),
+                                                   uvCodes=T(g["tex"]).to(DEV), expType=20, expCodes=T(g["exp"]).to(DEV), verbose=True, **kw)
+    torch.cuda.synchronize()
+    R = H * H
+    nan_equal_close(ex["rgb0"].reshape(R, 3).cpu().numpy(), g["rgb0"].reshape(R, 3), 1e-4)
+    nan_equal_close(ex["acc0"].reshape(R).cpu().numpy(), g["acc0"].reshape(R), 1e-4)
+    w_err = float((ex["_weights0"].cpu() - T(g["weights_coarse"])).abs().max())
+    assert w_err < 2e-5
+    agree, expl = classify_samples(g["z_coarse"], g["weights_coarse"], torch.linspace(0., 1., Ni), ex["_z_samples"].cpu(), g["z_samples"], w_err=w_err)
+    assert (agree | expl).all()
+    clean = agree.all(-1).numpy()
+    assert clean.any()
+    nan_equal_close(rgb.reshape(R, 3).cpu().numpy()[clean], g["rgb"].reshape(R, 3)[clean], 1e-3)
+    zf = ex["_z_fine"].cpu().numpy()
+    assert zf.shape == (R, Ns + Ni) and (np.diff(zf, axis=-1) >= 0).all()
 
 
 def test_fine_pass_teacher_forced_true_size(golden):

@@ -223,3 +223,42 @@ def test_backward_is_deterministic():
         else:
             assert torch.allclose(a, b, rtol=1e-3, atol=1e-6 + 1e-4 * float(a.abs().max())), f"encoder-side parameter {i}"
     assert n_set == n_net
+
+
+def test_tape_recompute_gives_bit_identical_gradients_with_less_memory():
+    """`render.tape_recompute = True`: the forward keeps no tape and each sub-batch's backward re-runs its forward in tape mode first.
+    Same kernels on the same inputs, so every gradient the HIP path computes is BIT-identical to the tape-keeping default, while the
+    saved state no longer grows with the number of sub-batches (here 6 sub-batches of a 768-ray training batch)."""
+    render, _, kw_train = make_product((8, 128, 10, 256), 0, 128 * 128, DEV, with_tex=True)       # netchunk 16,384 points = 128 rays of the fine pass
+    render.train()
+    kw = dict(kw_train, perturb=0.0)
+    params = list(kw["network_fn"].parameters()) + list(kw["network_fine"].parameters()) + list(render.grad_parameter())
+    K, rays = _rays(32, 768, angle=-15.0, seed=6)
+    rng = np.random.default_rng(8)
+    uv = torch.from_numpy(rng.uniform(0, 1, (512, 512, 3)).astype(np.float32)).to(DEV)
+    target = torch.from_numpy(rng.uniform(0, 1, (768, 3)).astype(np.float32)).to(DEV)
+    bm = synth.codes(0)[0].to(DEV).expand(768, -1)
+    n_net = len(list(kw["network_fn"].parameters())) + len(list(kw["network_fine"].parameters()))
+    grads, peaks, losses = [], [], []
+    for recompute in (False, True):
+        render.tape_recompute = recompute
+        for p in params:
+            p.grad = None
+        render._tex_cache = None
+        torch.cuda.synchronize(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        rgb, _, _, ex = render.render(32, 32, K, chunk=768, rays=rays, shapeCodes=bm, uvMap=uv, expType=3, **kw)
+        loss = ((rgb - target) ** 2).mean() + ((ex["rgb0"] - target) ** 2).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        peaks.append(torch.cuda.max_memory_allocated() - base)
+        losses.append(float(loss.detach()))
+        grads.append([None if p.grad is None else p.grad.detach().clone() for p in params[:n_net]])
+        del rgb, ex, loss
+    assert losses[0] == losses[1]
+    for i, (a, b) in enumerate(zip(*grads)):
+        assert a is not None and torch.equal(a, b), f"network parameter {i}"
+    tape_all = 768 * 128 * (2 * 10 + 4) * 256 * 4                                  # every fine-pass layer output of every sub-batch, roughly
+    print(f"peak extra memory: tape kept {peaks[0] / 2**20:.0f} MiB, recomputed {peaks[1] / 2**20:.0f} MiB")
+    assert peaks[1] < 0.5 * peaks[0] and peaks[0] > 0.5 * tape_all
+    render.tape_recompute = False

@@ -92,13 +92,14 @@ def _check_e2e(g, kw, tol):
     H = int(g["H"])
     ro, rd = orc.get_rays(H, H, g["K"], T(g["c2w"]))
     with torch.no_grad():
+        Ns, Ni = (int(g["N_samples"]), int(g["N_importance"])) if "N_samples" in g else (64, 64)
         rgb, disp, acc, ex = r.render(ro, rd, int(g["chunk"]), T(g["bm"]), 20, 8.0, 26.0, tex_code=T(g["tex"]),
-                                      exp_codes=T(g["exp"]), N_samples=64, N_importance=64, retraw=True, **kw)
+                                      exp_codes=T(g["exp"]), N_samples=Ns, N_importance=Ni, retraw=True, **kw)
     errs = {}
     for n, v in (("rgb", rgb), ("disp", disp), ("acc", acc), ("rgb0", ex["rgb0"]), ("disp0", ex["disp0"]),
                  ("acc0", ex["acc0"]), ("z_std", ex["z_std"])):
         errs[n] = nan_equal_close(v.numpy(), g[n], tol, tol)
-    nan_equal_close(ex["raw"].reshape(-1, 128, 4).numpy(), g["raw_fine"], 10 * tol, tol)
+    nan_equal_close(ex["raw"].reshape(-1, Ns + Ni, 4).numpy(), g["raw_fine"], 10 * tol, tol)
     assert ex["losses"] == 0
     return errs
 
@@ -115,6 +116,11 @@ def test_e2e_small_stochastic(golden):
     np.random.seed(0); n0 = torch.Tensor(np.random.rand(R, 64) * float(g["noise"]))
     np.random.seed(0); n1 = torch.Tensor(np.random.rand(R, 128) * float(g["noise"]))
     _check_e2e(g, dict(perturb=1.0, white_bkgd=True, t_rand=t_rand, u=u, noise0=n0, noise1=n1), 2e-6)
+
+
+def test_e2e_long_rays(golden):
+    """300 coarse + 212 importance samples per ray (beyond the 256 one wavefront pass holds on the device)."""
+    _check_e2e(golden("e2e_long.npz"), {}, 2e-6)
 
 
 def test_e2e_true_size(golden):
