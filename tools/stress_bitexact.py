@@ -80,4 +80,24 @@ with torch.no_grad():
     for _ in range(n):
         mism += int(not torch.equal(frame(), ref))
 report("k_mlp_fused (128x128 frame, 256x8 + 256x8)", n, mism)
+
+# the same kernel walking SEVERAL 256-feature blocks per layer (MOFA_FUSED=1 at width 512: the epilogue's LDS windows of one block
+# against the next block's first operand fetch — the barrier added in round 3), and the shipped fine net with its first layer
+# through encoding panels
+os.environ["MOFA_FUSED"] = "1"
+lib.reload_env()
+bench.ARCH = (8, 256, 10, 512)
+render, kw, _ = bench.build_product(torch.device(dev))
+with torch.no_grad():
+    ref = frame()
+    mism = sum(int(not torch.equal(frame(), ref)) for _ in range(n))
+report("k_mlp_fused, four/two feature blocks per layer (128x128 frame, 256x8 + 512x10, MOFA_FUSED=1)", n, mism)
+del os.environ["MOFA_FUSED"]
+lib.reload_env()
+bench.ARCH = (8, 256, 10, 1024)
+render, kw, _ = bench.build_product(torch.device(dev))
+with torch.no_grad():
+    ref = frame()
+    mism = sum(int(not torch.equal(frame(), ref)) for _ in range(max(1, n // 3)))
+report("shipped sizes (128x128 frame, 256x8 + 1024x10: encoding panels + K = 64 first layer, per-layer launches)", max(1, n // 3), mism)
 sys.exit(1 if bad else 0)
