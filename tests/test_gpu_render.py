@@ -152,15 +152,16 @@ def test_long_rays_teacher_forced_and_end_to_end(golden):
     R = H * H
     nan_equal_close(ex["rgb0"].reshape(R, 3).cpu().numpy(), g["rgb0"].reshape(R, 3), 1e-4)
     nan_equal_close(ex["acc0"].reshape(R).cpu().numpy(), g["acc0"].reshape(R), 1e-4)
-    w_err = float((ex["_weights0"].cpu() - T(g["weights_coarse"])).abs().max())
+    w_err = float((ex["_weights0"].reshape(R, Ns).cpu() - T(g["weights_coarse"])).abs().max())
     assert w_err < 2e-5
-    agree, expl = classify_samples(g["z_coarse"], g["weights_coarse"], torch.linspace(0., 1., Ni), ex["_z_samples"].cpu(), g["z_samples"], w_err=w_err)
+    agree, expl = classify_samples(g["z_coarse"], g["weights_coarse"], torch.linspace(0., 1., Ni), ex["_z_samples"].reshape(R, Ni).cpu(),
+                                   g["z_samples"], w_err=w_err)
     assert (agree | expl).all()
     clean = agree.all(-1).numpy()
     assert clean.any()
     nan_equal_close(rgb.reshape(R, 3).cpu().numpy()[clean], g["rgb"].reshape(R, 3)[clean], 1e-3)
-    zf = ex["_z_fine"].cpu().numpy()
-    assert zf.shape == (R, Ns + Ni) and (np.diff(zf, axis=-1) >= 0).all()
+    zf = ex["_z_fine"].reshape(R, Ns + Ni).cpu().numpy()
+    assert (np.diff(zf, axis=-1) >= 0).all()
 
 
 def test_fine_pass_teacher_forced_true_size(golden):
