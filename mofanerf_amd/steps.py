@@ -11,6 +11,30 @@ import torch
 from . import dist as mdist
 
 
+def sample_train_batch(K, c2w: torch.Tensor, lm3d: torch.Tensor, target: torch.Tensor, n_rand: int, precrop_frac: float = 0.0,
+                       generator=None, draws=None):
+    """The batch construction of run_train.py:306-330 without leaving the device and without the H x W ray grid: 3D landmarks ->
+    pixel table (`rays.project_landmarks`), landmark-biased + uniform pixel choice (`rays.train_pixels`), rays through exactly those
+    pixels (`rays.rays_at_pixels`, HIP) and the target colours at them.  Returns ``(batch_rays [2,N,3], target_s [N,3], pixels [N,2])``."""
+    from . import rays as mrays
+    H, W = int(target.shape[0]), int(target.shape[1])
+    lm2d = mrays.project_landmarks(K, c2w, lm3d)
+    pix = mrays.train_pixels(lm2d, n_rand, H, W, precrop_frac=precrop_frac, generator=generator, draws=draws)
+    batch = mrays.rays_at_pixels(K, c2w, pix[:, 0], pix[:, 1], H, W)
+    return batch, target[pix[:, 0], pix[:, 1]], pix
+
+
+def sample_fit_batch(K, c2w: torch.Tensor, landmarks_rc: torch.Tensor, target: torch.Tensor, n_rand: int, scale: int = 1,
+                     generator=None, draws=None):
+    """The batch construction of run_fit.py:281-293: landmark-biased pixels on non-empty target pixels (`rays.fit_pixels`), rays
+    through them — differentiable in the fitted pose ``c2w`` (`mofa_rays_pose_backward`) — and the target colours."""
+    from . import rays as mrays
+    H, W = int(target.shape[0]), int(target.shape[1])
+    pix = mrays.fit_pixels(landmarks_rc, n_rand, target, scale=scale, generator=generator, draws=draws)
+    batch = mrays.rays_at_pixels(K, c2w, pix[:, 0], pix[:, 1], H, W)
+    return batch, target[pix[:, 0], pix[:, 1]], pix
+
+
 def fit_step(render, render_kwargs: Dict, optimizers: List[torch.optim.Optimizer], H: int, W: int, K, batch_rays,
              target_rgb, shape_code, tex_code, exp_code, light_scale, chunk: int):
     """One iteration of run_fit.py's loop: 1024 sampled rays -> render_fitting -> L1(light*rgb, target) -> backward ->

@@ -58,3 +58,38 @@ def test_train_dp_and_bulk_render_through_the_rccl_branches(tmp_path):
     j = _json([sys.executable, os.path.join(ROOT, "tools", "bulk_render.py"), "--out", str(tmp_path / "rf"), "--identities", "1", "--expressions", "1",
                "--views", "1", "--size", "32", "--arch", "8", "64", "10", "64"])
     assert j["world"] == 1 and j["images_rendered_total"] == 1
+
+
+def _ipc_child(q_in, q_out):
+    import torch
+    t = q_in.get()                        # a CUDA tensor of the parent, opened here through a HIP IPC memory handle
+    ok = bool(t.is_cuda and float(t.sum()) == 1024.0)
+    t.mul_(3.0)                           # written in the child, read back by the parent through the same memory
+    torch.cuda.synchronize()
+    q_out.put(ok)
+
+
+def test_hip_ipc_memory_handles_work_between_processes():
+    """RCCL's intra-node transport maps peer buffers through HIP IPC memory handles; on these hosts only the dmabuf mode works
+    (HSA_ENABLE_IPC_MODE_LEGACY=0, defaulted by mofanerf_amd.dist before a group is created — without it the 8-GPU run dies with
+    "hipIpcGetMemHandle: invalid argument").  One GPU is enough to exercise that mechanism: a device tensor is handed to a second
+    process (torch.multiprocessing: hipIpcGetMemHandle / hipIpcOpenMemHandle), modified there and read back here."""
+    code = (
+        "import os, sys; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "from mofanerf_amd import dist as mdist; mdist._rccl_env()\n"
+        "import torch, torch.multiprocessing as mp\n"
+        "from test_gpu_rccl import _ipc_child\n"
+        "if __name__ == '__main__':\n"
+        "    mp.set_start_method('spawn')\n"
+        "    qi, qo = mp.Queue(), mp.Queue()\n"
+        "    p = mp.Process(target=_ipc_child, args=(qi, qo)); p.start()\n"
+        "    t = torch.ones(1024, device='cuda')\n"
+        "    qi.put(t)\n"
+        "    ok = qo.get(timeout=120); p.join(60)\n"
+        "    torch.cuda.synchronize()\n"
+        "    print('IPC', ok, float(t.sum()), os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'))\n" % (ROOT, ROOT))
+    out = subprocess.run([sys.executable, "-c", code], env={k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"},
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-2500:])
+    line = [l for l in out.stdout.splitlines() if l.startswith("IPC")][-1].split()
+    assert line[1] == "True" and float(line[2]) == 3072.0 and line[3] == "0", line

@@ -67,3 +67,35 @@ def test_fitting_sampler_matches_the_reference_bit_for_bit(tag, dev):
         assert int(runs) <= n // 2
     with pytest.raises(ValueError):                                      # explicit draws of the wrong length are refused, not padded
         rays.fit_pixels(lm, n, target, scale=2, draws={"rand": G[f"fit_{tag}_rand"][:-1], "rand_outline": G[f"fit_{tag}_rand_outline"], "choice": None})
+
+
+@pytest.mark.gpu
+def test_batch_construction_on_the_device_matches_the_scripts_gather():
+    """steps.sample_train_batch / sample_fit_batch: landmarks -> pixels -> rays -> target colours without the H x W ray grid.  With the
+    reference's draws the pixels are the reference's, and the rays are bit-identical to the full-frame kernel's at those pixels (what
+    `rays_o[select[:, 0], select[:, 1]]` gathers in run_train.py:326-329 / run_fit.py:287-292)."""
+    from mofanerf_amd import steps
+    dev = "cuda"
+    H = int(G["train_H"])
+    K = G["train_K"]
+    pose = torch.from_numpy(G["train_a_pose"]).to(dev)
+    lm3d = torch.from_numpy(G["train_table"][int(G["train_a_id"]), int(G["train_a_exp"])] / 50.).to(dev)
+    target = torch.rand(H, H, 3, device=dev)
+    n = int(G["train_a_n"])
+    batch, tgt, pix = steps.sample_train_batch(K, pose, lm3d, target, n, draws={"rand": G["train_a_rand"], "choice": G["train_a_choice"]})
+    assert torch.equal(pix.cpu(), _as_gathered(G["train_a_select"], H, H)) and batch.shape == (2, n, 3)
+    ro, rd = rays.get_rays(H, H, K, pose, device=dev)
+    assert torch.equal(batch[1], rd[pix[:, 0], pix[:, 1]]) and torch.equal(batch[0], ro[pix[:, 0], pix[:, 1]])
+    assert torch.equal(tgt, target[pix[:, 0], pix[:, 1]])
+    # fitting: half-resolution target, pose with a gradient
+    lm = torch.from_numpy(G["fit_lm"]).to(dev)
+    tgt_img = torch.from_numpy(G["fit_target"]).to(dev)
+    pose_f = pose.clone().requires_grad_(True)
+    Kh = K / 2.0
+    Kh[2, 2] = 1.0
+    batch, tgt, pix = steps.sample_fit_batch(Kh, pose_f, lm, tgt_img, int(G["fit_a_n"]), scale=2,
+                                             draws={"rand": G["fit_a_rand"], "rand_outline": G["fit_a_rand_outline"], "choice": G["fit_a_choice"]})
+    assert torch.equal(pix.cpu(), torch.from_numpy(G["fit_a_select"]).long())
+    batch[1].sum().backward()
+    assert pose_f.grad is not None and float(pose_f.grad.abs().sum()) > 0
+    assert bool((tgt.sum(-1) != 0).float().mean() > 0.9)                      # only outline extras may sit on empty pixels

@@ -44,11 +44,13 @@ def main(argv=None):
     uv = torch.from_numpy(rng.uniform(0, 1, (512, 512, 3)).astype(np.float32)).to(dev)
     shape = synth.codes(rank)[0].to(dev)
     losses, times = [], []
+    lm3d = torch.from_numpy(rng.uniform([-1.6, -2.0, -0.3], [1.6, 2.0, 1.2], (68, 3))).to(dev)       # this rank's identity: 68 3D landmarks
+    image = torch.from_numpy(rng.uniform(0, 1, (a.size, a.size, 3)).astype(np.float32)).to(dev)      # ... and its target view
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     for it in range(a.steps):
         pose = mrays.pose_spherical(float(rng.uniform(-60, 60)), 0.0, 16.0)[:3, :4].to(dev)
-        pix = torch.from_numpy(rng.choice(a.size * a.size, a.rays, replace=False)).to(dev)
-        batch = mrays.rays_at_pixels(K, pose, pix // a.size, pix % a.size, a.size, a.size)
-        target = torch.from_numpy(rng.uniform(0, 1, (a.rays, 3)).astype(np.float32)).to(dev)
+        # run_train.py:306-330 on the device: landmark projection, landmark-biased + uniform pixels, rays through those pixels, colours
+        batch, target, _ = steps.sample_train_batch(K, pose, lm3d, image, a.rays, precrop_frac=0.5 if it == 0 else 0.0, generator=gen)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         loss = steps.train_step(render, kw_train, opt, bucket, a.size, a.size, K, batch, target, shape.expand(a.rays, -1), uv,
                                 int(rng.integers(0, 20)), chunk=a.rays)
