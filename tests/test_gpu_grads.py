@@ -59,6 +59,38 @@ def test_composite_backward_vs_autograd(S, white, use_noise):
     assert rel_err(dg.grad.cpu()[1:], d64.grad[1:]) < 2e-5
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_composite_random_shapes_forward_and_backward(seed):
+    """Seeded sweep of raw2outputs on the device — sample counts on both sides of every kernel boundary (64 / 128 / 256 per-lane
+    widths, the multi-pass kernels beyond), ragged ray counts, white background / noise on and off: forward vs the oracle in double,
+    backward vs its autograd."""
+    rng = np.random.default_rng(500 + seed)
+    S = int([2, 63, 65, 128, 255, 256, 513, 1025][seed])
+    R = int(rng.integers(1, 70))
+    white, use_noise = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    raw = T(rng.normal(0, 1.0, (R, S, 4)).astype(np.float32))
+    z = T(np.sort(rng.uniform(8, 26, (R, S)).astype(np.float32), -1))
+    d = T(rng.normal(size=(R, 3)).astype(np.float32))
+    noise = T(rng.uniform(0, 0.5, (R, S)).astype(np.float32)) if use_noise else None
+    cw = [T(rng.normal(size=s_).astype(np.float32)) for s_ in ((R, 3), (R,), (R,), (R, S))]
+
+    def loss_of(rgb, acc, depth, w):
+        return (rgb * cw[0].to(rgb.device)).sum() + (acc * cw[1].to(rgb.device)).sum() + (depth * cw[2].to(rgb.device)).sum() + \
+               (w * cw[3].to(rgb.device)).sum()
+
+    r64, d64 = raw.double().requires_grad_(True), d.double().requires_grad_(True)
+    rgb, disp, acc, w, depth = orc.raw2outputs(r64, z.double(), d64, None if noise is None else noise.double(), white)
+    loss_of(rgb, acc, depth, w).backward()
+    rg, dg = raw.to(DEV).requires_grad_(True), d.to(DEV).requires_grad_(True)
+    o = CompositeFn.apply(rg, z.to(DEV), S, dg, None if noise is None else noise.to(DEV).contiguous(), white)
+    loss_of(o[0], o[2], o[3], o[4]).backward()
+    torch.cuda.synchronize()
+    for name, got, want in zip(("rgb", "acc", "depth", "weights"), (o[0], o[2], o[3], o[4]), (rgb, acc, depth, w)):
+        assert rel_err(got.detach().cpu(), want.detach()) < 5e-6, (name, R, S)
+    nan_equal_close(o[1].detach().cpu().numpy(), disp.detach().float().numpy(), 1e-6, 2e-5)
+    assert rel_err(rg.grad.cpu(), r64.grad) < 3e-5 and rel_err(dg.grad.cpu(), d64.grad) < 3e-5, (R, S)
+
+
 def _mk(D, W, seed=3):
     from mofanerf_amd.hipnet import HipNet
     from mofanerf_amd.model import NeRF

@@ -454,6 +454,33 @@ def test_sample_pdf_merge_vs_oracle():
         nan_equal_close(sd.numpy(), torch.std(zs, dim=-1, unbiased=False).numpy(), 2e-6, 2e-6)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_sample_pdf_merge_random_shapes(seed):
+    """Seeded sweep over (rays, coarse samples, importance samples) incl. counts beyond one 256-sample wavefront pass and the
+    4 / 2 / 1 rays-per-block layouts of the dynamic-LDS resampler: every sample agrees with the oracle's `sample_pdf` or is explained
+    by its conditioning, the merged row is the exact sort, z_std matches."""
+    from harness import classify_samples
+    rng = np.random.default_rng(100 + seed)
+    R = int(rng.integers(1, 300))
+    S = int(rng.choice([4, 17, 64, 129, 256, 300, 700, 1500][seed % 8:] + [64]))
+    Ni = int(rng.choice([1, 16, 64, 200, 257, 600, 2000]))
+    while 3 * S + Ni > 16384:
+        Ni //= 2
+    z = T(np.sort(rng.uniform(8, 26, (R, S)).astype(np.float32), -1))
+    w = T((rng.uniform(0, 1, (R, S)) ** 4).astype(np.float32))
+    if R > 2:
+        w[0] = 0.0
+        w[1] = 0.0; w[1, S // 2] = 1.0
+    for u, ustride in ((torch.linspace(0., 1., Ni), 0), (T(rng.uniform(0, 1, (R, Ni)).astype(np.float32)), Ni)):
+        zs, zf, sd = _sample(dev(z), dev(w), dev(u), ustride)
+        ref = orc.sample_pdf(.5 * (z[:, 1:] + z[:, :-1]), w[:, 1:-1], u)
+        agree, expl = classify_samples(z, w, u, zs, ref)
+        assert (agree | expl).all(), (R, S, Ni, int((~(agree | expl)).sum()))
+        assert float(agree.float().mean()) > 0.85, (R, S, Ni)
+        assert torch.equal(zf, torch.sort(torch.cat([z, zs], -1), -1)[0]), (R, S, Ni)
+        nan_equal_close(sd.numpy(), torch.std(zs, dim=-1, unbiased=False).numpy(), 3e-6, 3e-6)
+
+
 def test_sample_pdf_golden(golden):
     """`sample_pdf(bins, weights, 64, det / pytest)` (run_nerf_helpers.py:203-247) through the bins-input entry point
     `mofa_sample_pdf`, against the REFERENCE's own outputs `spdf_det` / `spdf_rand` (40 rays incl. all-zero weights, a single
