@@ -17,13 +17,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
 
 
 def csrc_digest() -> str:
-    """sha256 over the kernel sources (names + contents of csrc/** and the C-ABI header): identifies WHICH kernels a profile was taken
-    on (profiles/hbm_traffic.json records it; bench.py quotes those counters only for the same digest)."""
+    """sha256 over the PRODUCT's kernel sources (names + contents of csrc/*.hip, csrc/*.h and the C-ABI header; csrc/measure/ is not
+    part of libmofanerf_hip.so): identifies WHICH kernels a profile was taken on (profiles/hbm_traffic.json records it; bench.py
+    quotes those counters only for the same digest)."""
     import hashlib
     h = hashlib.sha256()
-    files = []
-    for root, _dirs, names in os.walk(CSRC):
-        files += [os.path.join(root, n) for n in names if n.endswith((".hip", ".h"))]
+    files = [os.path.join(CSRC, n) for n in os.listdir(CSRC) if n.endswith((".hip", ".h"))]
     files.append(os.path.join(HERE, "..", "include", "mofanerf_hip.h"))
     for f in sorted(files, key=lambda q: os.path.relpath(q, HERE)):
         h.update(os.path.relpath(f, HERE).encode())

@@ -8,7 +8,8 @@
 //   unstaged           strided 16-byte epilogue stores instead of the LDS-window epilogue
 //   gap2 / gap3        2 / 3 MFMAs between two LDS-DMA requests of the pipelined loop (shipped: derived, 4)
 //   setprio1/3         s_setprio around every MFMA block of the plain loop
-//   waves3             __launch_bounds__(256, 3) (three workgroups per CU, spills)
+//   waves3             __launch_bounds__(256, 3): three workgroups per CU need <= 168 VGPRs; the pipelined loop's 197 then spill (1,166
+//                      spilled VGPRs -> 19.6 TFLOP/s: the bound, not an option; round 2 measured the PLAIN loop at 3 per CU: +-0.5 %)
 //   ring3              3-stage LDS ring twin of the plain loop (k_layer_ring3)
 //   persist / persist_dephase   persistent per-layer twin walking the tiles (k_layer_persist)
 //   timeline           per-workgroup / per-panel time stamps (mofa_measure_set_timeline)
