@@ -234,6 +234,9 @@ def main():
                     help="fp32 (default, the headline: exact fp32 MFMA).  bf16x6 / bf16x3 = OPT-IN split-product emulation of "
                          "the fp32 products on the bf16 matrix pipe — a labelled experiment, not the headline")
     ap.add_argument("--netchunk", type=int, default=None, help="labelled variant: points per network launch (default 196608, the reference's)")
+    ap.add_argument("--tape", choices=["keep", "recompute"], default="keep",
+                    help="fit / train: keep every layer output for the backward (default) or re-run each sub-batch's forward inside its "
+                         "backward (labelled variant: Renderer.tape_recompute)")
     ap.add_argument("--size", type=int, default=512, help="image side (512 = the benchmark; smaller only for functional tests)")
     ap.add_argument("--rays", type=int, default=None, help="fit / train: N_rand per GPU (default 1024 / 4096)")
     a = ap.parse_args()
@@ -259,6 +262,7 @@ def main():
     render, kw, args = build_product(dev, with_tex=(a.mode == "train"))
     if a.netchunk:
         render.netchunk = int(a.netchunk)
+    render.tape_recompute = a.tape == "recompute"
     bm, tex, exp = (t.to(dev) for t in synth.codes(0))
     K = synth.intrinsics(H, W)
     n_total = H * W
@@ -399,7 +403,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{workload}, 64 coarse + 128 fine samples/ray, coarse {ARCH[1]}x{ARCH[0]} + fine {ARCH[3]}x{ARCH[2]}, "
                                    f"chunk=196608, netchunk={int(a.netchunk) if a.netchunk else 196608}{' (VARIANT: the benchmark is netchunk=196608)' if a.netchunk and a.netchunk != 196608 else ''}, seeded Xavier weights (BASELINE.json configs[{ {'render': 1, 'fit': 2, 'train': 4}[a.mode] }])",
-                       "mode": a.mode, "rays_per_step": units_per_step, "rays_per_rank_per_step": units_per_step // world,
+                       "mode": a.mode, **({"tape": "recompute (VARIANT: one extra forward per step, tape bounded by netchunk)"} if a.tape == "recompute" else {}),
+                       "rays_per_step": units_per_step, "rays_per_rank_per_step": units_per_step // world,
                        "parallelism": par,
                        "gflop_per_ray_folded": round(work / 1e9, 4),
                        "gflop_per_ray_nominal": round(work / fwd * flops_per_ray(False) / 1e9, 4)},
