@@ -332,3 +332,21 @@ def test_texture_code_cache_semantics():
     rgb2 = render.render(8, 8, K, chunk=64, c2w=c2w, shapeCodes=bm, uvMap=uv, expType=3, **dict(kw_train, perturb=0.0))[0]
     assert len(calls) == 6 and rgb.requires_grad and torch.allclose(rgb, rgb2, atol=1e-6)     # autograd on: the encoder always runs
     assert torch.allclose(rgb.detach(), f, atol=2e-3)     # the taped forward folds the codes in torch: same frame up to the resampling sensitivity
+
+
+def test_real_checkpoint_parity_tool_on_the_reference_written_checkpoint(tmp_path, capsys):
+    """tools/real_checkpoint_parity.py — the check a holder of the real pretrained `.tar` runs — exercised on the checkpoint the
+    REFERENCE's modules wrote (fixture g10): loads through create_nerf's reload path, hands the same state dicts to the oracle, gates
+    the coarse and the teacher-forced fine pass at 1e-4 and reports the end-to-end agreement."""
+    import importlib.util
+    import json
+    p = tmp_path / "000100.tar"
+    p.write_bytes(gzip.open(os.path.join(GOLDEN, "ref_ckpt_000100.tar.gz")).read())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("real_checkpoint_parity", os.path.join(root, "tools", "real_checkpoint_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rc = mod.main(["--ckpt", str(p), "--arch", "8", "64", "10", "64", "--rays", "96", "--size", "32"])
+    j = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1])
+    assert rc == 0 and j["pass"] and j["global_step"] == 100 and j["teacher_forced_rgb_max_abs"] <= 1e-4
+    assert j["end_to_end_frac_within_1e-4"] > 0.5
