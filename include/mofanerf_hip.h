@@ -51,9 +51,11 @@ int mofa_abi_version(void);
 const char* mofa_last_error(void);   /* thread-local text of the calling thread's last failure */
 
 /* Library-wide state is limited to what is listed here; everything else is in caller-owned buffers.
- *   - measurement / A-B knobs (MOFA_STAGE, MOFA_FUSED, MOFA_PERSIST, MOFA_DEPHASE, MOFA_RING3, MOFA_LDS_PAD, MOFA_BN64, MOFA_SPLIT_V, MOFA_SPLIT_HH):
- *     read from the environment ONCE when the library is loaded into an immutable snapshot; no launch path calls getenv.
- *     mofa_config_reload() re-reads them (tests and A/B tools that change a knob inside one process call it explicitly).
+ *   - four run-time knobs, each choosing between forms that produce correct results — MOFA_PIPE=0 (plain instead of software-pipelined
+ *     K loops; bit-identical), MOFA_FUSED=0/1 (per-layer launches / persistent network kernel; bit-identical), MOFA_SPLIT_V, MOFA_SPLIT_HH
+ *     (variants of the opt-in split-product mode): read from the environment ONCE when the library is loaded into an immutable snapshot;
+ *     no launch path calls getenv.  mofa_config_reload() re-reads them (tests that change a knob inside one process call it explicitly).
+ *     Measurement arms (scheduling experiments, time stamps, ablations) are NOT in this library: csrc/measure/, tools/build_measure.py.
  *   - per-device caches (CU count, a one-time function attribute) and the per-device measurement session below. */
 int mofa_config_reload(void);
 
@@ -200,7 +202,7 @@ int mofa_positional_encode(const float* x, int64_t n, int32_t n_freqs, float* ou
 /* ---- measurement hook ------------------------------------------------------------------------
  * A measurement session of the CALLING THREAD'S CURRENT DEVICE (state is per device, mutex-guarded; with no session
  * open the launch paths read one atomic flag).  Between mofa_prof_begin() and mofa_prof_end() every launch of the MFMA
- * kernels — [0] the per-layer forward kernel k_layer<128,false,true> / k_layer_persist, [1] the persistent
+ * kernels — [0] the per-layer forward kernel k_layer<128,..,PIPE> (128-feature tile, pipelined K loop), [1] the persistent
  * whole-network kernel k_mlp_fused (widths <= 256), [2] the backward-data kernel k_layer<128,..,BWD>, [3] the
  * weight-gradient kernel k_wgrad, [4] the view layer's per-ray-bias instantiation of the forward kernel — is bracketed by
  * hipEventRecord on its own stream.  mofa_prof_end() synchronises those

@@ -570,9 +570,9 @@ int mofa_prof_begin(void) {
     return MOFA_OK;
 }
 
-/* arrays of MOFA_PROF_KINDS: [0] the per-layer forward MFMA kernel k_layer<128,false,true,false,false,false> (or its
- * persistent twin), [1] the persistent network kernel k_mlp_fused, [2] the backward-data kernel k_layer<128,..,BWD>, [3] the
- * weight-gradient kernel k_wgrad, [4] the per-ray-bias instantiation k_layer<128,false,true,false,false,true> (view layer).
+/* arrays of MOFA_PROF_KINDS: [0] the per-layer forward MFMA kernel k_layer<128,false,false,false,false,PIPE> (128-feature tile),
+ * [1] the persistent network kernel k_mlp_fused, [2] the backward-data kernel k_layer<128,false,BWD,..>, [3] the weight-gradient
+ * kernel k_wgrad, [4] the per-ray-bias instantiation k_layer<128,false,false,false,PERRAY,..> (view layer).
  * Session of the CURRENT device. */
 int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops) {
     MOFA_REQUIRE(total_ms && launches && padded_flops, "prof_end: null pointer");

@@ -109,7 +109,7 @@ PROF_KINDS = 5     # MOFA_PROF_KINDS: k_layer fwd, k_mlp_fused, k_layer<BWD>, k_
 
 
 def reload_env() -> None:
-    """Re-read the library's MOFA_* measurement knobs from the environment (they are read once at load time)."""
+    """Re-read the library's MOFA_* run-time knobs from the environment (they are read once at load time)."""
     check(load().mofa_config_reload(), "mofa_config_reload")
 
 
