@@ -8,7 +8,6 @@
 //   unstaged           strided 16-byte epilogue stores instead of the LDS-window epilogue
 //   gap2 / gap3        2 / 3 MFMAs between two LDS-DMA requests of the pipelined loop (shipped: derived, 4)
 //   setprio1/3         s_setprio around every MFMA block of the plain loop
-//   nt_stores          `nt` (streaming) hint on the staged epilogue's global stores
 //   waves3             __launch_bounds__(256, 3): three workgroups per CU need <= 168 VGPRs; the pipelined loop's 197 then spill (1,166
 //                      spilled VGPRs -> 19.6 TFLOP/s: the bound, not an option; round 2 measured the PLAIN loop at 3 per CU: +-0.5 %)
 //   ring3              3-stage LDS ring twin of the plain loop (k_layer_ring3)
@@ -69,9 +68,6 @@ struct GapPolicy : ShippedPolicy {
 template <int PRIO>
 struct SetPrioPolicy : ShippedPolicy {
     static constexpr int kSetPrio = PRIO;
-};
-struct NtStoresPolicy : ShippedPolicy {
-    static constexpr bool kNtStores = true;
 };
 struct Waves3Policy : ShippedPolicy {
     static constexpr int kMinWaves = 3;
@@ -428,7 +424,7 @@ using namespace mofa;
 #define MOFA_MEASURE_API extern "C" __attribute__((visibility("default")))
 
 MOFA_MEASURE_API const char* mofa_measure_arms(void) {
-    return "shipped,plain,bn64,unstaged,gap2,gap3,setprio1,setprio3,waves3,nt_stores,ring3,persist,persist_dephase,timeline,sink_epilogue";
+    return "shipped,plain,bn64,unstaged,gap2,gap3,setprio1,setprio3,waves3,ring3,persist,persist_dephase,timeline,sink_epilogue";
 }
 MOFA_MEASURE_API const char* mofa_measure_last_error(void) { return g_err; }
 
@@ -460,7 +456,6 @@ MOFA_MEASURE_API int mofa_measure_layer_forward(const char* arm, const float* x1
     if (!strcmp(arm, "gap2")) return launch_policy<GapPolicy<2>, true>(a, st);
     if (!strcmp(arm, "gap3")) return launch_policy<GapPolicy<3>, true>(a, st);
     if (!strcmp(arm, "waves3")) return launch_policy<Waves3Policy, true>(a, st);
-    if (!strcmp(arm, "nt_stores")) return launch_policy<NtStoresPolicy, true>(a, st);
     if (!strcmp(arm, "timeline")) return launch_policy<TimelinePolicy, true>(a, st);
     if (!strcmp(arm, "sink_epilogue")) return launch_policy<SinkPolicy, true>(a, st);
     set_error("measure_layer_forward: unknown arm '%s' (have: %s)", arm, mofa_measure_arms());

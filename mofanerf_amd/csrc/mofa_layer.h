@@ -69,7 +69,6 @@ struct ShippedPolicy {
     static constexpr int kPipeGap = 0;             // MFMAs between two LDS-DMA requests; 0 = as many as the half panel allows after its reads
     static constexpr int kSetPrio = 0;             // s_setprio level around every MFMA block of the plain loop (0 = none)
     static constexpr bool kStagedEpilogue = true;  // contiguous-store epilogue through a wave-private LDS window
-    static constexpr bool kNtStores = false;       // `nt` (streaming) hint on the staged epilogue's global stores
     static constexpr bool kSinkEpilogue = false;   // true: discard the tile instead of storing it (timing-only ablation; never shipped)
     static constexpr int kExtraLds = 0;            // bytes of dynamic LDS the hooks use behind the two stages
     struct Probe {                                 // time-stamp hooks: empty
@@ -340,7 +339,7 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[NI][NJ], const fl
 // No barrier: the window is wave-private and a wave's LDS operations execute in order.  `win` must not be read or written by
 // anyone else (the pipelined K loop's stage 0 is free for all waves after its last barrier).  Same values as store_tile
 // (bit-identical).  Measured against it (interleaved A/B): +0.4 % at K = N = 1024, +4 % at 256, k_mlp_fused 133.2 -> 135.5 TFLOP/s.
-template <int NI, int NJ, bool RELU, bool NT = false>
+template <int NI, int NJ, bool RELU>
 __device__ __forceinline__ void store_tile_staged(const f32x16 (&acc)[NI][NJ], const float* __restrict__ bias, float* __restrict__ y,
                                                   long long m_padded, long long m_first, int n_first, int lane, float* win) {
     static_assert(NJ % 2 == 0, "row halves of 64 points");
@@ -368,8 +367,7 @@ __device__ __forceinline__ void store_tile_staged(const f32x16 (&acc)[NI][NJ], c
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const f32x4 v = *(const f32x4*)(win + it * 256 + lane * 4);
-                    if constexpr (NT) __builtin_nontemporal_store(v, (f32x4*)(panel + jh * 1024 + it * 256 + lane * 4));
-                    else *(f32x4*)(panel + jh * 1024 + it * 256 + lane * 4) = v;
+                    *(f32x4*)(panel + jh * 1024 + it * 256 + lane * 4) = v;
                 }
             }
         }
@@ -590,8 +588,8 @@ __global__ __launch_bounds__(256, P::kMinWaves) void k_layer(const LayerArgs a) 
     // forward epilogue: bias + ReLU, into the next layer's panels
     if constexpr (P::kStagedEpilogue && PIPE && !PERRAY && !HH) {
         float* win = smem + wave * 1024;      // 4 KiB per wave inside stage 0 (free for everybody after the K loop's last barrier)
-        if (a.relu) store_tile_staged<NI, NJ, true, P::kNtStores>(acc, a.bias, a.y, a.m_padded, m0 + wm * (32 * NJ), n0 + wn * 64, lane, win);
-        else store_tile_staged<NI, NJ, false, P::kNtStores>(acc, a.bias, a.y, a.m_padded, m0 + wm * (32 * NJ), n0 + wn * 64, lane, win);
+        if (a.relu) store_tile_staged<NI, NJ, true>(acc, a.bias, a.y, a.m_padded, m0 + wm * (32 * NJ), n0 + wn * 64, lane, win);
+        else store_tile_staged<NI, NJ, false>(acc, a.bias, a.y, a.m_padded, m0 + wm * (32 * NJ), n0 + wn * 64, lane, win);
     } else {
         f32x4 bv[NI][4];
         store_tile<NI, NJ, PERRAY, HH>(acc, a.bias, a.bias_rows, a.bias_row_div, a.n_padded, a.y, a.m_padded, m0 + wm * (32 * NJ),
