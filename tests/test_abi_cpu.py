@@ -72,3 +72,24 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "mofa_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_hot_kernels_fit_their_occupancy_without_scratch():
+    """ISA-level regression guard, read from the built library's own code objects (tools/kernel_resources.py; no GPU needed): the MFMA
+    kernels are written for TWO workgroups per CU (<= 256 registers per lane in the unified VGPR file) and must not touch scratch —
+    a compiler or source change that spills them would halve the matrix pipe's feed long before any parity test noticed."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    rs = {r["kernel"]: r for r in kernel_resources.resources(build.build())}
+    hot = [k for k in rs if k.startswith(("mofa::k_layer<", "mofa::k_mlp_fused", "mofa::k_wgrad<", "mofa::k_layer_split"))]
+    assert len(hot) >= 15, sorted(rs)
+    for k in hot:
+        r = rs[k]
+        assert r["scratch"] == 0 and r["vgpr_spill"] == 0, (k, r)
+        assert r["vgpr"] + r["agpr"] <= 256, (k, r)
+    dom = rs["mofa::k_layer<128, false, false, false, false, true, mofa::ShippedPolicy>"]
+    assert dom["vgpr"] <= 200 and dom["agpr"] == 0, dom            # 197 since round 2; the refactor into mofa_layer.h + policy did not move it
+    for k, r in rs.items():                                        # the ray-side kernels run many rays per CU: keep them light
+        if k.startswith(("mofa::k_composite", "mofa::k_sample_pdf_merge", "mofa::k_get_rays")):
+            assert r["vgpr"] <= 128 and r["scratch"] == 0, (k, r)
