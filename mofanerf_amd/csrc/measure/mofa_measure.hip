@@ -12,7 +12,10 @@
 //                      spilled VGPRs -> 19.6 TFLOP/s: the bound, not an option; round 2 measured the PLAIN loop at 3 per CU: +-0.5 %)
 //   ring3              3-stage LDS ring twin of the plain loop (k_layer_ring3)
 //   persist / persist_dephase   persistent per-layer twin walking the tiles (k_layer_persist)
+//   persist_pipe       persistent twin of the SHIPPED kernel (pipelined loop + staged epilogue), no next-tile prefetch
+//   persist_pipe_sink  the same with no epilogue at all (WRONG RESULTS): the bound of hiding the store drain in that schedule
 //   timeline           per-workgroup / per-panel time stamps (mofa_measure_set_timeline)
+//   timeline_sink      the same stamps on a launch whose epilogue stores nothing (WRONG RESULTS): the slot turnaround without a store drain
 //   sink_epilogue      WRONG RESULTS BY DESIGN: the tile is discarded instead of stored — what a free epilogue would be worth
 // and k_mfma_peak_probe (what the fp32 matrix pipe sustains with no memory traffic at all).
 #include <stdarg.h>
@@ -369,6 +372,63 @@ __global__ __launch_bounds__(256, 2) void k_mfma_peak_probe(float* __restrict__ 
     if (s_ == 123.456f) out[0] = s_;   // keeps the accumulators alive
 }
 
+// time stamps of a launch WITHOUT the epilogue's stores: what is left of the slot turnaround when there is nothing to drain
+struct TimelineSinkPolicy : TimelinePolicy {
+    static constexpr bool kSinkEpilogue = true;
+    struct Probe : TimelinePolicy::Probe {
+        using TimelinePolicy::Probe::Probe;
+        __device__ __forceinline__ void kloop_end() {
+            TimelinePolicy::Probe::kloop_end();
+            TimelinePolicy::Probe::stores_issued();          // the kernel returns right after the sink: record here
+        }
+    };
+    template <class Acc>
+    static __device__ __forceinline__ void sink(const Acc& acc, float* y) { SinkPolicy::sink(acc, y); }
+};
+
+// ---- persistent twin of the SHIPPED kernel (pipelined K loop + staged epilogue): 2 workgroups per CU walk the tiles -----------------
+// PREFETCH = false: after a tile's epilogue the next tile simply starts (its first LDS-DMA requests queue behind the 32 stores per lane
+// in the wave's in-order vmcnt, so the first panel waits for the store drain — but no dispatcher is involved).
+template <bool SINK>      // SINK: no epilogue at all (WRONG RESULTS) — the bound of what hiding the store drain in this schedule could reach
+__global__ __launch_bounds__(256, 2) void k_layer_persist_pipe(const LayerArgs a, int per_xcd_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BN = 128, BM = kRowTile, NI = 2, NJ = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+    const int KT = a.k1p + a.k2p;
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
+    ShippedPolicy::Probe probe(a, 0, tid, smem, KT);
+    for (int it = 0;; ++it) {
+        const int local = w + it * wg_per_xcd;
+        const int logical = xcd * per_xcd_tiles + local;
+        if (local >= per_xcd_tiles || logical >= a.total_tiles) break;
+        const int mt = logical / a.n_tiles;
+        const long long m0 = (long long)mt * BM;
+        const int n0 = (logical - mt * a.n_tiles) * BN;
+        f32x16 acc[NI][NJ];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        kloop_pipelined<NI, NJ, BM, BN, ShippedPolicy>(a.x1 + m0 * 16, a.k2p ? a.x2 + m0 * 16 : nullptr, a.w + (long long)n0 * 16, a.m_padded * 16,
+                                                       (long long)a.n_padded * 16, a.k1p, KT, smem, tid, wave, lane, wm * (32 * NJ), wn * 64, acc, probe);
+        if constexpr (SINK) {
+            SinkPolicy::sink(acc, a.y);
+        } else {
+            float* win = smem + wave * 1024;
+            if (a.relu) store_tile_staged<NI, NJ, true>(acc, a.bias, a.y, a.m_padded, m0 + wm * (32 * NJ), n0 + wn * 64, lane, win);
+            else store_tile_staged<NI, NJ, false>(acc, a.bias, a.y, a.m_padded, m0 + wm * (32 * NJ), n0 + wn * 64, lane, win);
+        }
+        // every wave is done with the stages (last panel's reads, the epilogue windows) before the next tile's requests overwrite them;
+        // only LDS operations need to have completed — NOT the global stores (no vmcnt wait here)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 template <class P, bool PIPE, int BN = 128>
 int launch_policy(LayerArgs a, hipStream_t st) {
     a.n_tiles = a.n_padded / BN;
@@ -402,6 +462,21 @@ int launch_ring3(LayerArgs a, hipStream_t st) {
     return check_launch("k_layer_ring3");
 }
 
+int launch_persist_pipe(LayerArgs a, bool sink, hipStream_t st) {
+    constexpr int BN = 128;
+    a.n_tiles = a.n_padded / BN;
+    const long long total = (a.m_padded / kRowTile) * a.n_tiles;
+    a.total_tiles = (int)total;
+    const size_t lds = 2 * (size_t)(kRowTile + BN) * 16 * sizeof(float);
+    const int cus = compute_units(current_device());
+    long long G = 2LL * cus / 8 * 8;
+    const int per_xcd_tiles = (int)((total + 7) / 8);
+    if (G > 8LL * per_xcd_tiles) G = 8LL * per_xcd_tiles;
+    if (sink) hipLaunchKernelGGL(k_layer_persist_pipe<true>, dim3((unsigned)G), dim3(256), lds, st, a, per_xcd_tiles);
+    else hipLaunchKernelGGL(k_layer_persist_pipe<false>, dim3((unsigned)G), dim3(256), lds, st, a, per_xcd_tiles);
+    return check_launch("k_layer_persist_pipe");
+}
+
 int launch_persist(LayerArgs a, int dephase, hipStream_t st) {
     constexpr int BN = 128;
     a.n_tiles = a.n_padded / BN;
@@ -424,7 +499,7 @@ using namespace mofa;
 #define MOFA_MEASURE_API extern "C" __attribute__((visibility("default")))
 
 MOFA_MEASURE_API const char* mofa_measure_arms(void) {
-    return "shipped,plain,bn64,unstaged,gap2,gap3,setprio1,setprio3,waves3,ring3,persist,persist_dephase,timeline,sink_epilogue";
+    return "shipped,plain,bn64,unstaged,gap2,gap3,setprio1,setprio3,waves3,ring3,persist,persist_dephase,persist_pipe,persist_pipe_sink,timeline,timeline_sink,sink_epilogue";
 }
 MOFA_MEASURE_API const char* mofa_measure_last_error(void) { return g_err; }
 
@@ -457,6 +532,12 @@ MOFA_MEASURE_API int mofa_measure_layer_forward(const char* arm, const float* x1
     if (!strcmp(arm, "gap3")) return launch_policy<GapPolicy<3>, true>(a, st);
     if (!strcmp(arm, "waves3")) return launch_policy<Waves3Policy, true>(a, st);
     if (!strcmp(arm, "timeline")) return launch_policy<TimelinePolicy, true>(a, st);
+    if (!strcmp(arm, "timeline_sink")) return launch_policy<TimelineSinkPolicy, true>(a, st);
+    if (!strcmp(arm, "persist_pipe")) {
+        MOFA_REQUIRE(!a.bias_row_div, "measure_layer_forward: arm persist_pipe has no per-ray-bias form");
+        return launch_persist_pipe(a, false, st);
+    }
+    if (!strcmp(arm, "persist_pipe_sink")) return launch_persist_pipe(a, true, st);
     if (!strcmp(arm, "sink_epilogue")) return launch_policy<SinkPolicy, true>(a, st);
     set_error("measure_layer_forward: unknown arm '%s' (have: %s)", arm, mofa_measure_arms());
     return MOFA_EINVAL;

@@ -28,9 +28,12 @@ build_measure.build(verbose=False)
 Lm = build_measure.load()
 
 
+ARM = sys.argv[sys.argv.index("--arm") + 1].encode() if "--arm" in sys.argv else b"timeline"     # timeline | timeline_sink
+
+
 def layer(*a):
     """the stamped kernel (stamps are written only while a buffer is set)"""
-    return Lm.mofa_measure_layer_forward(b"timeline", *a)
+    return Lm.mofa_measure_layer_forward(ARM, *a)
 
 M, K, N = 196608, 1024, 1024
 tiles = (M // 256) * (N // 128)
