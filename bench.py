@@ -46,12 +46,12 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Pe
 H = W = 512
 ARCH = (8, 256, 10, 1024)
 N_SAMPLES, N_IMPORTANCE = 64, 64
-# (symbol, role, description) per profiler kind of libmofanerf_hip.so; k_layer's template = <BN, L0, BWD, HH, PERRAY, PIPE, policy>
-KERNELS = [("mofa::k_layer<128,false,false,false,false,true,mofa::ShippedPolicy>", "forward", "fp32 MFMA Linear+bias+ReLU, software-pipelined K loop"),
+# (symbol, role, description) per profiler kind of libmofanerf_hip.so; k_layer's template = <BN, L0, BWD, PERRAY, PIPE, policy>
+KERNELS = [("mofa::k_layer<128,false,false,false,true,mofa::ShippedPolicy>", "forward", "fp32 MFMA Linear+bias+ReLU, software-pipelined K loop"),
            ("mofa::k_mlp_fused", "forward, persistent", "persistent fp32-MFMA network kernel, widths <= 256"),
-           ("mofa::k_layer<128,false,true,false,false,true,mofa::ShippedPolicy>", "BWD backward-data", "fp32 MFMA backward-data GEMM + ReLU mask, the same K loop"),
+           ("mofa::k_layer<128,false,true,false,true,mofa::ShippedPolicy>", "BWD backward-data", "fp32 MFMA backward-data GEMM + ReLU mask, the same K loop"),
            ("mofa::k_wgrad<128,256>", "weight gradient", "fp32 MFMA weight-gradient GEMM, contraction over points"),
-           ("mofa::k_layer<128,false,false,false,true,true,mofa::ShippedPolicy>", "forward, PERRAY view layer", "the same kernel with the view layer's per-ray bias")]
+           ("mofa::k_layer<128,false,false,true,true,mofa::ShippedPolicy>", "forward, PERRAY view layer", "the same kernel with the view layer's per-ray bias")]
 
 
 def pose_spherical(phi_deg, theta_deg, radius):
@@ -230,9 +230,6 @@ def main():
     ap.add_argument("--arch", type=int, nargs=4, default=list(ARCH), metavar=("Dc", "Wc", "Df", "Wf"),
                     help="network sizes; default = shipped config (8 256 10 1024).  '8 256 8 256' is the labelled variant "
                          "BASELINE.md lists (fine net as small as the coarse one)")
-    ap.add_argument("--gemm", choices=["fp32", "bf16x6", "bf16x3", "fp16x3"], default="fp32",
-                    help="fp32 (default, the headline: exact fp32 MFMA).  bf16x6 / bf16x3 = OPT-IN split-product emulation of "
-                         "the fp32 products on the bf16 matrix pipe — a labelled experiment, not the headline")
     ap.add_argument("--netchunk", type=int, default=None, help="labelled variant: points per network launch (default 196608, the reference's)")
     ap.add_argument("--tape", choices=["keep", "recompute"], default="keep",
                     help="fit / train: keep every layer output for the backward (default) or re-run each sub-batch's forward inside its "
@@ -244,7 +241,6 @@ def main():
         sys.exit(self_spawn(a.gpus))
     H = W = a.size
     ARCH = tuple(a.arch)
-    os.environ["MOFA_GEMM"] = a.gemm
     d_steps, d_warm = {"render": (2, 1), "fit": (10, 3), "train": (4, 4)}[a.mode]   # train: MIOpen searches conv solvers first
     a.steps = d_steps if a.steps is None else a.steps
     a.warmup = d_warm if a.warmup is None else a.warmup
@@ -360,9 +356,6 @@ def main():
         # K = 63 -> 64 inside the persistent kernel (0.1 %).
         dom = max(range(NK), key=lambda k: ms[k])
         ksym, krole, kdesc = KERNELS[dom]
-        if a.gemm != "fp32" and dom == 0:
-            ksym, kdesc = (f"mofa::k_layer_split<128,{3 if a.gemm == 'bf16x6' else 2}>",
-                           f"{a.gemm} split products on the 16-bit matrix pipe; peak quoted = fp32 MFMA")
         kname = f"{ksym} ({kdesc})"
         achieved = pflops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         traffic, tinfo = None, {}
@@ -399,7 +392,7 @@ def main():
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "f32" if a.gemm == "fp32" else f"f32 emulated by {a.gemm} split products (16-bit MFMA, fp32 accumulation) - OPT-IN EXPERIMENT",
+            "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{workload}, 64 coarse + 128 fine samples/ray, coarse {ARCH[1]}x{ARCH[0]} + fine {ARCH[3]}x{ARCH[2]}, "
                                    f"chunk=196608, netchunk={int(a.netchunk) if a.netchunk else 196608}{' (VARIANT: the benchmark is netchunk=196608)' if a.netchunk and a.netchunk != 196608 else ''}, seeded Xavier weights (BASELINE.json configs[{ {'render': 1, 'fit': 2, 'train': 4}[a.mode] }])",

@@ -51,9 +51,9 @@ int mofa_abi_version(void);
 const char* mofa_last_error(void);   /* thread-local text of the calling thread's last failure */
 
 /* Library-wide state is limited to what is listed here; everything else is in caller-owned buffers.
- *   - four run-time knobs, each choosing between forms that produce correct results — MOFA_PIPE=0 (plain instead of software-pipelined
- *     K loops; bit-identical), MOFA_FUSED=0/1 (per-layer launches / persistent network kernel; bit-identical), MOFA_SPLIT_V, MOFA_SPLIT_HH
- *     (variants of the opt-in split-product mode): read from the environment ONCE when the library is loaded into an immutable snapshot;
+ *   - two run-time knobs, each choosing between BIT-IDENTICAL forms of the exact-fp32 path — MOFA_PIPE=0 (plain instead of
+ *     software-pipelined K loops), MOFA_FUSED=0/1 (per-layer launches / persistent network kernel); there is no reduced-precision
+ *     mode: read from the environment ONCE when the library is loaded into an immutable snapshot;
  *     no launch path calls getenv.  mofa_config_reload() re-reads them (tests that change a knob inside one process call it explicitly).
  *     Measurement arms (scheduling experiments, time stamps, ablations) are NOT in this library: csrc/measure/, tools/build_measure.py.
  *   - per-device caches (CU count, a one-time function attribute) and the per-device measurement session below. */
@@ -105,25 +105,7 @@ int mofa_net_fold(MofaNetShape s, const float* const* weights, const float* cons
 int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, const float* view_w,
                      const float* view_b, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
                      const float* pts, const float* viewdirs, int64_t n_rays, int32_t S, float* workspace,
-                     float* raw_out, float* tape, const float* view_bias_rows, const uint16_t* packed_split,
-                     int32_t split_pieces, void* stream);
-/* packed_split / split_pieces: NULL / 0 for the shipped exact-fp32 path.  OPT-IN experiment (MOFA_GEMM, default off; DESIGN.md
- * 3.6): split_pieces = 2 (bf16x3), 3 (bf16x6) or -2 (fp16x3) makes every layer whose width is a multiple of 128 run the
- * split-product kernel - fp32 products emulated by partial products of 16-bit pieces on the 16-bit matrix pipe, fp32
- * accumulation.  bf16 modes: packed_split may stay NULL (both operands split in registers from the ordinary fp32 panels, kernel
- * v2) or point to weights pre-split into bf16 planes by mofa_net_pack_split (kernel v1).  fp16x3 needs packed_split, assumes
- * |activation| < 65504 (a violation yields NaN in raw_out, never a plausible value) and, without a tape and from width 512 up,
- * keeps the activations between layers as pre-split fp16 piece panels (internal layout; raw_out is unaffected). */
-size_t mofa_net_packed_split_elems(MofaNetShape s, int32_t pieces);   /* uint16 elements */
-int mofa_net_pack_split(MofaNetShape s, const float* const* weights, uint16_t* dst, int32_t pieces, void* stream);
-int mofa_pack_split(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, uint16_t* dst,
-                    int32_t rows_padded, int32_t panel0, int32_t k_padded, int32_t pieces, void* stream);
-/* w_packed (the ordinary fp32 panels) selects v2: both operands split in registers, 3-stage LDS ring; w_split (bf16 planes from
- * mofa_pack_split) selects v1 (the only choice for pieces = -2).  At least one of them must be given. */
-int mofa_layer_forward_split(const float* x1, int32_t k1, const float* x2, int32_t k2, const uint16_t* w_split,
-                             const float* w_packed, int32_t pieces, const float* bias, int32_t bias_row_div,
-                             int64_t bias_rows, float* y, int64_t m_padded, int32_t n_padded, int32_t relu, void* stream);
-
+                     float* raw_out, float* tape, const float* view_bias_rows, void* stream);
 /* ---- backward (run_fit.py:305-313 photometric fitting, run_train.py:333-357 training) -----------------------
  * Backward of mofa_net_forward given d_raw [n_rays,S,4] and the tape of that forward:
  *   d_folded  [mofa_net_folded_floats]: gradient w.r.t. every folded bias (sum over points of the ReLU-masked

@@ -82,7 +82,7 @@ class NetFn(torch.autograd.Function):
         ws = h.workspace(R * S, R, ro.device)
         lib.check(L.mofa_net_forward(h.shape, lib.ptr(h.packed()), lib.ptr(fo), None, None, lib.ptr(ro), lib.ptr(rd),
                                      lib.ptr(zc), z_row_stride, None, None, R, S, lib.ptr(ws), lib.ptr(raw), lib.ptr(tape),
-                                     lib.ptr(vb), None, 0, lib.stream()), "mofa_net_forward(tape)" if tape is not None else "mofa_net_forward")
+                                     lib.ptr(vb), lib.stream()), "mofa_net_forward(tape)" if tape is not None else "mofa_net_forward")
         return raw
 
     @staticmethod

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmofanerf_hip.so")
-SOURCES = ["mofa_mlp.hip", "mofa_split.hip", "mofa_rays.hip", "mofa_bwd.hip", "mofa_net.hip"]
+SOURCES = ["mofa_mlp.hip", "mofa_rays.hip", "mofa_bwd.hip", "mofa_net.hip"]
 # -fvisibility=hidden: the library exports exactly the C ABI of include/mofanerf_hip.h (declared under a visibility pragma there);
 # the mofa_internal_* hand-offs between the translation units stay out of the dynamic symbol table
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden", "-Wall",

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_ring3(const LayerArgs a) {
         nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
     }
     f32x4 bv[NI][4];
-    store_tile<NI, NJ, PERRAY, false>(acc, a.bias, a.bias_rows, a.bias_row_div, a.n_padded, a.y, a.m_padded, m0 + wm * (32 * NJ),
+    store_tile<NI, NJ, PERRAY>(acc, a.bias, a.bias_rows, a.bias_row_div, a.n_padded, a.y, a.m_padded, m0 + wm * (32 * NJ),
                                       n0 + wn * 64, a.relu, lane, bv);
 }
 
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_persist(const LayerArgs a, int
         if (more) stage_issue(0, 0, m1, n1);
         if (perray) {
             f32x4 bv[NI][4];
-            store_tile<NI, NJ, true, false>(acc, a.bias, a.bias_rows, a.bias_row_div, a.n_padded, a.y, a.m_padded,
+            store_tile<NI, NJ, true>(acc, a.bias, a.bias_rows, a.bias_row_div, a.n_padded, a.y, a.m_padded,
                                             m0 + wm * (32 * NJ), n0 + wn * 64, a.relu, lane, bv);
         } else {
             const int lr = lane & 31, g = lane >> 5;
@@ -437,8 +437,8 @@ int launch_policy(LayerArgs a, hipStream_t st) {
     a.total_tiles = (int)total;
     const dim3 grid((unsigned)round_up(total, 8)), block(256);
     const size_t lds = 2 * (size_t)(kRowTile + BN) * 16 * sizeof(float) + P::kExtraLds;
-    if (a.bias_row_div) hipLaunchKernelGGL((k_layer<BN, false, false, false, true, PIPE, P>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((k_layer<BN, false, false, false, false, PIPE, P>), grid, block, lds, st, a);
+    if (a.bias_row_div) hipLaunchKernelGGL((k_layer<BN, false, false, true, PIPE, P>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((k_layer<BN, false, false, false, PIPE, P>), grid, block, lds, st, a);
     return check_launch("k_layer(measure)");
 }
 

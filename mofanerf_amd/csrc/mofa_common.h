@@ -37,23 +37,21 @@ __device__ __forceinline__ void pinhole_ray(int i, int j, float fx, float fy, fl
     }
 }
 
-// ReLU with torch's NaN behaviour (F.relu(nan) = nan; fmaxf(nan, 0) would be 0): a NaN that enters the network - bad
-// input, or an fp16 overflow in the opt-in split mode - must reach the image exactly as it does in the reference.
+// ReLU with torch's NaN behaviour (F.relu(nan) = nan; fmaxf(nan, 0) would be 0): a NaN that enters the network (bad
+// input) must reach the image exactly as it does in the reference.
 // gfx950's v_maximum3_f32 is IEEE-754-2019 `maximum` (NaN-propagating): ONE instruction instead of compare + select.
 __device__ __forceinline__ float relu_np(float v) { return __builtin_elementwise_maximum(v, 0.0f); }
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
-// Run-time knobs.  Every one of them selects between forms that produce CORRECT results (the plain and the pipelined K loop
-// are bit-identical, so are the persistent and the per-layer network path); measurement arms live in csrc/measure/, not here.
+// Run-time knobs.  Both select between BIT-IDENTICAL forms of the exact-fp32 path (plain / pipelined K loop; persistent /
+// per-layer network launch) — there is no reduced-precision mode in this library; measurement arms live in csrc/measure/.
 // The environment is read ONCE (at library load, and again only when the host calls mofa_config_reload()) into an immutable
 // snapshot, so no launch path calls getenv and concurrent host threads see one consistent configuration.
 // -1 = "not set: use the built-in heuristic".
 struct Config {
-    int split_v = 2;      // MOFA_SPLIT_V=1 -> pre-split weight planes for the opt-in bf16 modes
     int fused = -1;       // MOFA_FUSED=0/1: persistent whole-network kernel off / on
-    int split_hh = -1;    // MOFA_SPLIT_HH=0/1: fp16 piece panels off / on (opt-in fp16x3 mode)
     int pipe = -1;        // MOFA_PIPE=0: the plain K loops (layer kernel, persistent kernel, weight gradient) instead of the pipelined ones
 };
 const Config& config();

@@ -1,6 +1,5 @@
 // The fp32-MFMA layer kernel of the MoFaNeRF hot path and its building blocks (gfx950 only), shared by every translation
-// unit that launches it: mofa_mlp.hip (the product: per-layer launches + the persistent whole-network kernel), mofa_split.hip
-// (the opt-in split-product experiment reuses the argument block, the LDS-DMA helper and the fp16 piece store) and
+// unit that launches it: mofa_mlp.hip (the product: per-layer launches + the persistent whole-network kernel) and
 // measure/mofa_measure.hip (measurement builds — time stamps, ablations, scheduling arms — built only by tools/).
 //
 // Replaces run_network/batchify/NeRF.forward of the reference (models/render_class.py:69-109, models/model.py:121-137, :202-230):
@@ -54,7 +53,6 @@ struct LayerArgs {
     int S;
     int n_tiles;          // n_padded / BN
     int total_tiles;
-    int y_hh;             // opt-in fp16x3 mode only: write y as pre-split fp16 piece panels (store_quad_hh)
     // layer-0 camera mode (mofa_layer0_forward_cam): rays are built in the prologue from (K, c2w, pixel) instead of being read
     const float* cam_c2w;   // 12 floats [3,4] (device) or NULL = read rays_o / rays_d
     const int* cam_pix;     // flat pixel index per ray, or NULL = pixel cam_pix0 + ray
@@ -83,26 +81,6 @@ struct ShippedPolicy {
     template <class Acc>
     static __device__ __forceinline__ void sink(const Acc&, float*) {}
 };
-
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-// "hh" activation panels (opt-in fp16x3 mode): same bytes and swizzle as an fp32 panel row (64 B = four
-// 16-B chunks per point and 16 features), but the chunks hold PRE-SPLIT fp16 pieces: chunk 2G = h1 of features 8G..8G+7,
-// chunk 2G+1 = h2 of the same features (x = h1 + h2 + O(2^-23 |x|), both round-to-nearest).  The consuming kernel's
-// operand fragment is then exactly the two 16-B reads it already makes - no conversion work per use.
-// `v` = features n..n+3 (n % 4 == 0) of point m; msw = (m >> 2) & 3.
-__device__ __forceinline__ void store_quad_hh(float* __restrict__ y, long long m_padded, int n, long long m, int msw,
-                                              const f32x4 v) {
-    f16x4 h1, h2;
-    h1.x = (_Float16)v.x, h1.y = (_Float16)v.y, h1.z = (_Float16)v.z, h1.w = (_Float16)v.w;
-    h2.x = (_Float16)(v.x - (float)h1.x), h2.y = (_Float16)(v.y - (float)h1.y);
-    h2.z = (_Float16)(v.z - (float)h1.z), h2.w = (_Float16)(v.w - (float)h1.w);
-    const int G = (n >> 3) & 1, half = (n >> 2) & 1;
-    float* row = y + (long long)(n >> 4) * m_padded * 16 + m * 16 + half * 2;
-    *(f16x4*)(row + (((2 * G) ^ msw) << 2)) = h1;
-    *(f16x4*)(row + (((2 * G + 1) ^ msw) << 2)) = h2;
-}
 
 __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
     // 16 B per lane, LDS destination = wave-uniform base + lane*16 (LDS-DMA, no VGPR round trip)
@@ -291,7 +269,7 @@ __device__ __forceinline__ void bias_fetch(const float* __restrict__ bias_base, 
         for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(bias_base + boff + 32 * i + 8 * q);
 }
 
-template <int NI, int NJ, bool PERRAY, bool HH>
+template <int NI, int NJ, bool PERRAY>
 __device__ __forceinline__ void store_tile(const f32x16 (&acc)[NI][NJ], const float* __restrict__ bias_base, long long bias_rows,
                                            int bias_row_div, int n_padded, float* __restrict__ y, long long m_padded,
                                            long long m_first, int n_first, int relu, int lane, f32x4 (&bv)[NI][4]) {
@@ -325,8 +303,7 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[NI][NJ], const fl
                 if (relu) {
                     v.x = relu_np(v.x), v.y = relu_np(v.y), v.z = relu_np(v.z), v.w = relu_np(v.w);
                 }
-                if constexpr (HH) store_quad_hh(y, m_padded, n, m, msw, v);
-                else *(f32x4*)(y + (long long)(n >> 4) * m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
+                *(f32x4*)(y + (long long)(n >> 4) * m_padded * 16 + m * 16 + ((((n >> 2) & 3) ^ msw) << 2)) = v;
             }
         }
     }
@@ -424,9 +401,9 @@ __device__ __forceinline__ void store_tile_staged_bwd(const f32x16 (&acc)[NI][NJ
 // BN: feature-tile height; L0: X tile is generated (positional encoding) instead of loaded; operands are staged by LDS-DMA.
 // BWD: backward-data epilogue (no bias/ReLU; optional accumulate into y and ReLU mask from the saved activation):
 //      dX[m][k] = sum_n G[m][n] * W[n][k]  is the same GEMM with the transposed weight pack as "Wp".
-// HH: write y as fp16 piece panels (opt-in fp16x3 mode).  PERRAY: per-ray bias rows (the view layer).
+// PERRAY: per-ray bias rows (the view layer).
 // PIPE: the software-pipelined K loop (128-feature tile, >= 4 and an even number of panels); otherwise the plain loop.
-template <int BN, bool L0, bool BWD = false, bool HH = false, bool PERRAY = false, bool PIPE = false, class P = ShippedPolicy>
+template <int BN, bool L0, bool BWD = false, bool PERRAY = false, bool PIPE = false, class P = ShippedPolicy>
 __global__ __launch_bounds__(256, P::kMinWaves) void k_layer(const LayerArgs a) {
     static_assert(!PIPE || (!L0 && BN == 128), "the pipelined K loop stages both operands by LDS-DMA at the 128-feature tile");
     // (measured on the 64-feature tile too - 4 workgroups per CU, 16 MFMAs per half panel carrying 4 reads + 5 requests: 132 against
@@ -586,13 +563,13 @@ __global__ __launch_bounds__(256, P::kMinWaves) void k_layer(const LayerArgs a) 
         return;
     }
     // forward epilogue: bias + ReLU, into the next layer's panels
-    if constexpr (P::kStagedEpilogue && PIPE && !PERRAY && !HH) {
+    if constexpr (P::kStagedEpilogue && PIPE && !PERRAY) {
         float* win = smem + wave * 1024;      // 4 KiB per wave inside stage 0 (free for everybody after the K loop's last barrier)
         if (a.relu) store_tile_staged<NI, NJ, true>(acc, a.bias, a.y, a.m_padded, m0 + wm * (32 * NJ), n0 + wn * 64, lane, win);
         else store_tile_staged<NI, NJ, false>(acc, a.bias, a.y, a.m_padded, m0 + wm * (32 * NJ), n0 + wn * 64, lane, win);
     } else {
         f32x4 bv[NI][4];
-        store_tile<NI, NJ, PERRAY, HH>(acc, a.bias, a.bias_rows, a.bias_row_div, a.n_padded, a.y, a.m_padded, m0 + wm * (32 * NJ),
+        store_tile<NI, NJ, PERRAY>(acc, a.bias, a.bias_rows, a.bias_row_div, a.n_padded, a.y, a.m_padded, m0 + wm * (32 * NJ),
                                        n0 + wn * 64, a.relu, lane, bv);
     }
     probe.stores_issued();

@@ -2,7 +2,7 @@
 // policy only, the persistent whole-network kernel k_mlp_fused for widths <= 256, the small kernels around them (heads, per-ray
 // view bias, folded biases, panel packing, positional encoding) and their C ABI.  No measurement arms live here: scheduling
 // experiments, time-stamp builds and ablations are csrc/measure/mofa_measure.hip (built only by tools/build_measure.py into
-// its own library), the opt-in split-product experiment is mofa_split.hip.
+// its own library).
 #include <stdlib.h>
 
 #include <atomic>
@@ -18,7 +18,7 @@ namespace {
 // ---- heads: sigma = sigmaCodes . w + b (model.py:130), rgb = v . W3 + b3 (model.py:134) ---------
 __global__ __launch_bounds__(256) void k_head(const float* __restrict__ x, int kp, long long m_padded,
                                               const float* __restrict__ w, const float* __restrict__ b, int n_out,
-                                              float* __restrict__ raw, int raw_off, long long n_points, int hh) {
+                                              float* __restrict__ raw, int raw_off, long long n_points) {
     const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
     if (m >= n_points) return;
     const int sw = (int)(m >> 2) & 3;
@@ -27,20 +27,10 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ x, int k
     for (int kt = 0; kt < kp; ++kt) {
         const f32x4* row = (const f32x4*)(x + ((long long)kt * m_padded + m) * 16);
         float xv[16];
-        if (hh) {   // pre-split fp16 piece panels (store_quad_hh): x = h1 + h2
 #pragma unroll
-            for (int G = 0; G < 2; ++G) {
-                const f16x8 h1 = __builtin_bit_cast(f16x8, row[(2 * G) ^ sw]);
-                const f16x8 h2 = __builtin_bit_cast(f16x8, row[(2 * G + 1) ^ sw]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xv[8 * G + e] = (float)h1[e] + (float)h2[e];
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x4 t = row[c ^ sw];
-                xv[4 * c] = t.x, xv[4 * c + 1] = t.y, xv[4 * c + 2] = t.z, xv[4 * c + 3] = t.w;
-            }
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 t = row[c ^ sw];
+            xv[4 * c] = t.x, xv[4 * c + 1] = t.y, xv[4 * c + 2] = t.z, xv[4 * c + 3] = t.w;
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -302,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
                 float* y = a.arena_w + l.y_off;
                 f32x4 bv[NI][4];
                 if (l.bias_row_div)
-                    store_tile<NI, NJ, true, false>(acc, a.view_bias_rows + l.bias_off, a.bias_rows, l.bias_row_div, np, y, a.m_padded, m0,
+                    store_tile<NI, NJ, true>(acc, a.view_bias_rows + l.bias_off, a.bias_rows, l.bias_row_div, np, y, a.m_padded, m0,
                                                     nbase + wn * 64, 1, lane, bv);
                 else      // both loops end with a workgroup barrier: stage 0 is free, 4 KiB of it per wave
                     store_tile_staged<NI, NJ, true>(acc, a.folded + l.bias_off, y, a.m_padded, m0, nbase + wn * 64, lane, smem + wn * 1024);
@@ -383,29 +373,24 @@ int launch_layer(LayerArgs a, hipStream_t st) {
     bool pipe = false;
     if constexpr (BN == 128 && !L0) pipe = config().pipe != 0 && (a.k1p + a.k2p) >= 4 && ((a.k1p + a.k2p) & 1) == 0;
     if constexpr (L0) {
-        if constexpr (BN == 128) {
-            if (a.y_hh) hipLaunchKernelGGL((k_layer<BN, true, false, true>), grid, block, lds, st, a);   // opt-in fp16x3: piece panels out
-            else hipLaunchKernelGGL((k_layer<BN, true>), grid, block, lds, st, a);
-        } else {
-            hipLaunchKernelGGL((k_layer<BN, true>), grid, block, lds, st, a);
-        }
+        hipLaunchKernelGGL((k_layer<BN, true>), grid, block, lds, st, a);
     } else if constexpr (BWD) {
         if constexpr (BN == 128) {
-            if (pipe) hipLaunchKernelGGL((k_layer<BN, false, true, false, false, true>), grid, block, lds, st, a);
+            if (pipe) hipLaunchKernelGGL((k_layer<BN, false, true, false, true>), grid, block, lds, st, a);
             else hipLaunchKernelGGL((k_layer<BN, false, true>), grid, block, lds, st, a);
         } else {
             hipLaunchKernelGGL((k_layer<BN, false, true>), grid, block, lds, st, a);
         }
     } else if (a.bias_row_div) {   // per-ray bias (the view layer): its own instantiation, see store_tile
         if constexpr (BN == 128) {
-            if (pipe) hipLaunchKernelGGL((k_layer<BN, false, false, false, true, true>), grid, block, lds, st, a);
-            else hipLaunchKernelGGL((k_layer<BN, false, false, false, true>), grid, block, lds, st, a);
+            if (pipe) hipLaunchKernelGGL((k_layer<BN, false, false, true, true>), grid, block, lds, st, a);
+            else hipLaunchKernelGGL((k_layer<BN, false, false, true>), grid, block, lds, st, a);
         } else {
-            hipLaunchKernelGGL((k_layer<BN, false, false, false, true>), grid, block, lds, st, a);
+            hipLaunchKernelGGL((k_layer<BN, false, false, true>), grid, block, lds, st, a);
         }
     } else {
         if constexpr (BN == 128) {
-            if (pipe) hipLaunchKernelGGL((k_layer<BN, false, false, false, false, true>), grid, block, lds, st, a);
+            if (pipe) hipLaunchKernelGGL((k_layer<BN, false, false, false, true>), grid, block, lds, st, a);
             else hipLaunchKernelGGL((k_layer<BN, false>), grid, block, lds, st, a);
         } else {
             hipLaunchKernelGGL((k_layer<BN, false>), grid, block, lds, st, a);
@@ -541,7 +526,7 @@ int mofa_head_forward(const float* x, int32_t k_padded, int64_t m_padded, const 
                      n_points <= m_padded,
                  "head_forward: bad shape");
     hipLaunchKernelGGL(k_head, dim3(blocks_for(n_points)), dim3(256), 0, (hipStream_t)stream, x, k_padded / 16,
-                       (long long)m_padded, w_dense, b, n_out, raw, raw_off, (long long)n_points, 0);
+                       (long long)m_padded, w_dense, b, n_out, raw, raw_off, (long long)n_points);
     return check_launch("k_head");
 }
 
@@ -570,9 +555,9 @@ int mofa_prof_begin(void) {
     return MOFA_OK;
 }
 
-/* arrays of MOFA_PROF_KINDS: [0] the per-layer forward MFMA kernel k_layer<128,false,false,false,false,PIPE> (128-feature tile),
+/* arrays of MOFA_PROF_KINDS: [0] the per-layer forward MFMA kernel k_layer<128,false,false,false,PIPE> (128-feature tile),
  * [1] the persistent network kernel k_mlp_fused, [2] the backward-data kernel k_layer<128,false,BWD,..>, [3] the weight-gradient
- * kernel k_wgrad, [4] the per-ray-bias instantiation k_layer<128,false,false,false,PERRAY,..> (view layer).
+ * kernel k_wgrad, [4] the per-ray-bias instantiation k_layer<128,false,false,PERRAY,..> (view layer).
  * Session of the CURRENT device. */
 int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops) {
     MOFA_REQUIRE(total_ms && launches && padded_flops, "prof_end: null pointer");
@@ -598,25 +583,6 @@ int mofa_internal_prof_open(void* stream, int kind) { return prof_enabled() ? (p
 void mofa_internal_prof_close(void* stream, int kind, double flops) { prof_close((hipStream_t)stream, kind, flops); }
 
 // internal (used by mofa_net.hip): run a list of MFMA layers of one network (all widths <= 256) as ONE persistent launch
-// ---- opt-in fp16x3 mode with pre-split ("hh") activation panels: internal to mofa_net_forward --------------------------
-int mofa_internal_layer0_forward_hh(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
-                                    const float* pts, int64_t n_points, int32_t S, const float* w_packed, const float* bias,
-                                    float* y, int64_t m_padded, int32_t n_padded, void* stream) {
-    MOFA_REQUIRE(n_padded % 128 == 0, "layer0_forward_hh: n_padded %% 128 != 0");
-    LayerArgs a{};
-    a.w = w_packed, a.bias = bias, a.y = y, a.rays_o = rays_o, a.rays_d = rays_d, a.z = z, a.pts = pts;
-    a.z_row_stride = z_row_stride, a.n_points = n_points, a.S = S > 0 ? S : 1;
-    a.k1p = 4, a.k2p = 0, a.n_padded = n_padded, a.m_padded = m_padded, a.relu = 1, a.y_hh = 1;
-    return launch_layer<128, true>(a, (hipStream_t)stream);
-}
-
-int mofa_internal_head_forward_hh(const float* x, int32_t k_padded, int64_t m_padded, const float* w_dense, const float* b,
-                                  int32_t n_out, float* raw, int32_t raw_off, int64_t n_points, void* stream) {
-    hipLaunchKernelGGL(k_head, dim3(blocks_for(n_points)), dim3(256), 0, (hipStream_t)stream, x, k_padded / 16,
-                       (long long)m_padded, w_dense, b, n_out, raw, raw_off, (long long)n_points, 1);
-    return check_launch("k_head(hh)");
-}
-
 int mofa_internal_fused_forward(const float* arena, float* arena_w, const float* packed, const float* folded,
                                 const float* view_bias_rows, long long bias_rows, const float* rays_o, const float* rays_d,
                                 const float* z, long long z_row_stride, const float* pts, long long n_points, int S,

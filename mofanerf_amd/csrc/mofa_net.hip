@@ -17,19 +17,6 @@ int mofa_internal_fold_bias(const float* w, int n_out, int ld, int col0, int nco
 int mofa_internal_dense_rows(const float* w, int n_out, int ld, int col0, int ncols, float* dst, int k_padded,
                              void* stream);
 int mofa_internal_raw_colsum(const float* d_raw, long long n_points, int off, int n, float* out, void* stream);
-int mofa_layer_forward_split(const float* x1, int32_t k1, const float* x2, int32_t k2, const uint16_t* w_split,
-                             const float* w_packed, int32_t pieces, const float* bias, int32_t bias_row_div,
-                             int64_t bias_rows, float* y, int64_t m_padded, int32_t n_padded, int32_t relu, void* stream);
-int mofa_pack_split(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, uint16_t* dst,
-                    int32_t rows_padded, int32_t panel0, int32_t k_padded, int32_t pieces, void* stream);
-int mofa_internal_layer0_forward_hh(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
-                                    const float* pts, int64_t n_points, int32_t S, const float* w_packed, const float* bias,
-                                    float* y, int64_t m_padded, int32_t n_padded, void* stream);
-int mofa_internal_layer_split_hh(const float* x1, int32_t k1, const float* x2, int32_t k2, const uint16_t* w_split,
-                                 const float* bias, int32_t bias_row_div, int64_t bias_rows, float* y, int64_t m_padded,
-                                 int32_t n_padded, int32_t relu, void* stream);
-int mofa_internal_head_forward_hh(const float* x, int32_t k_padded, int64_t m_padded, const float* w_dense, const float* b,
-                                  int32_t n_out, float* raw, int32_t raw_off, int64_t n_points, void* stream);
 int mofa_internal_fused_forward(const float* arena, float* arena_w, const float* packed, const float* folded,
                                 const float* view_bias_rows, long long bias_rows, const float* rays_o, const float* rays_d,
                                 const float* z, long long z_row_stride, const float* pts, long long n_points, int S,
@@ -76,9 +63,7 @@ namespace {
 Config read_env() {
     Config c;
     auto tri = [](const char* name) { const char* e = getenv(name); return e ? (e[0] == '1' ? 1 : 0) : -1; };
-    const char* e;
-    if ((e = getenv("MOFA_SPLIT_V")) && e[0] == '1') c.split_v = 1;
-    c.fused = tri("MOFA_FUSED"), c.split_hh = tri("MOFA_SPLIT_HH"), c.pipe = tri("MOFA_PIPE");
+    c.fused = tri("MOFA_FUSED"), c.pipe = tri("MOFA_PIPE");
     return c;
 }
 // two slots + an atomic index: readers never see a half-written snapshot, reload is rare and host-side only
@@ -128,13 +113,12 @@ struct Layer {
     size_t packed_off, folded_off;
     size_t packed_t_off[2];   // transposed packs for the backward-data GEMMs (one per source part)
     size_t tape_cols;         // sum of n_padded of the MFMA layers before this one (tape slot = Mp * tape_cols)
-    size_t split_elems_off;   // offset (in units of n_padded*k_padded elements, before the x pieces factor) into the split blob
 };
 
 struct Plan {
     int D, W, Wp, Hp;
     std::vector<Layer> L;
-    size_t packed_floats = 0, folded_floats = 0, packed_t_floats = 0, tape_cols = 0, split_elems = 0;
+    size_t packed_floats = 0, folded_floats = 0, packed_t_floats = 0, tape_cols = 0;
     // indices into L
     int xyz0, bim0, bim_skip, uv0, uv_skip, view, alpha, rgb;
 };
@@ -198,8 +182,6 @@ Plan make_plan(MofaNetShape s) {
         p.folded_floats += (l.fold == kView) ? 0 : (size_t)l.n_padded;
         l.tape_cols = p.tape_cols;
         l.packed_t_off[0] = l.packed_t_off[1] = 0;
-        l.split_elems_off = p.split_elems;
-        if (!l.head) p.split_elems += (size_t)l.n_padded * kp;
         if (!l.head) {
             p.tape_cols += (size_t)l.n_padded;
             for (int part = 0; part < l.nsrc; ++part) {
@@ -313,41 +295,14 @@ int mofa_net_pack_t(MofaNetShape s, const float* const* weights, float* packed_t
     return MOFA_OK;
 }
 
-size_t mofa_net_packed_split_elems(MofaNetShape s, int32_t pieces) {
-    const int np = pieces < 0 ? -pieces : pieces;   // negative = fp16 pieces
-    return (shape_ok(s) && (np == 2 || np == 3)) ? make_plan(s).split_elems * (size_t)np : 0;
-}
-
-int mofa_net_pack_split(MofaNetShape s, const float* const* weights, uint16_t* dst, int32_t pieces, void* stream) {
-    MOFA_REQUIRE(shape_ok(s), "net_pack_split: unsupported shape D=%d W=%d", s.D, s.W);
-    MOFA_REQUIRE(weights && dst && (pieces == 2 || pieces == 3 || pieces == -2), "net_pack_split: bad arguments");
-    const Plan p = make_plan(s);
-    const int np = pieces < 0 ? -pieces : pieces;
-    for (size_t li = 0; li < p.L.size(); ++li) {
-        const Layer& l = p.L[li];
-        if (l.head) continue;
-        uint16_t* d = dst + l.split_elems_off * (size_t)np;
-        int rc = mofa_pack_split(weights[li], l.n_out, l.ld, l.col0[0], l.ncols[0], d, l.n_padded, 0, l.k_padded[0], pieces,
-                                 stream);
-        if (rc == MOFA_OK && l.nsrc > 1)
-            rc = mofa_pack_split(weights[li], l.n_out, l.ld, l.col0[1], l.ncols[1], d, l.n_padded, l.k_padded[0] / 16,
-                                 l.k_padded[1], pieces, stream);
-        if (rc != MOFA_OK) return rc;
-    }
-    return MOFA_OK;
-}
-
 #define MOFA_TRY(expr) \
     if ((rc = (expr)) != MOFA_OK) return rc
 
 int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, const float* view_w,
                      const float* view_b, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
                      const float* pts, const float* viewdirs, int64_t n_rays, int32_t S, float* workspace,
-                     float* raw_out, float* tape, const float* view_bias_rows, const uint16_t* packed_split,
-                     int32_t split_pieces, void* stream) {
+                     float* raw_out, float* tape, const float* view_bias_rows, void* stream) {
     MOFA_REQUIRE(shape_ok(s), "net_forward: unsupported shape D=%d W=%d", s.D, s.W);
-    MOFA_REQUIRE(split_pieces == 0 || split_pieces == 2 || split_pieces == 3 || split_pieces == -2,
-                 "net_forward: split_pieces must be 0, 2, 3 or -2");
     MOFA_REQUIRE(packed && folded && workspace && raw_out, "net_forward: null pointer");
     MOFA_REQUIRE(view_bias_rows || (view_w && view_b && viewdirs),
                  "net_forward: need view_bias_rows or (view_w, view_b, viewdirs)");
@@ -415,18 +370,7 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     // ---- dispatch: one persistent launch for widths <= 256 (every layer of a point tile lives in one workgroup), else
     //      one launch per layer.  MOFA_FUSED=0/1 overrides the heuristic (tests / A-B).
     const Config& cfg = config();
-    // the opt-in split-product modes run 128-multiple widths per layer (the persistent kernel is exact-fp32 only)
-    const bool split_here = split_pieces != 0 && packed_split && p.Wp % 128 == 0;
-    const bool fused = cfg.fused >= 0 ? cfg.fused == 1 : (p.Wp <= 256 && Mp / kRowTile >= 128 && !split_here);
-    // fp16x3 with pre-split activation panels: every MFMA layer after the first consumes and produces fp16 piece panels
-    // (the split then costs one pass in the producer's epilogue instead of one per consuming N-tile).  Inference only.
-    // Measured (M=196608): +9 % per layer at K=N=1024, -9 % at 256 (the conversion epilogue is amortised over K), so the
-    // default takes it from width 512 up; MOFA_SPLIT_HH=0/1 forces it off/on (A/B, tests).
-    bool hh = split_pieces == -2 && split_here && !tape && !fused;
-    if (hh) {
-        hh = cfg.split_hh >= 0 ? cfg.split_hh == 1 : p.Wp >= 512;
-        for (const Step& st : steps) hh = hh && p.L[st.li].n_padded % 128 == 0;
-    }
+    const bool fused = cfg.fused >= 0 ? cfg.fused == 1 : (p.Wp <= 256 && Mp / kRowTile >= 128);
     if (fused) {
         const float* arena = tape ? tape : workspace;
         const int n = (int)steps.size();
@@ -449,15 +393,7 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     } else {
         for (const Step& st : steps) {
             const Layer& l = p.L[st.li];
-            if (!st.x1 && hh) {
-                MOFA_TRY(mofa_internal_layer0_forward_hh(rays_o, rays_d, z, z_row_stride, pts, M, S, packed + l.packed_off,
-                                                         folded + l.folded_off, st.y, Mp, l.n_padded, stream));
-            } else if (hh) {
-                const bool view = st.li == p.view;
-                MOFA_TRY(mofa_internal_layer_split_hh(st.x1, l.k_padded[0], st.x2, st.x2 ? l.k_padded[1] : 0,
-                                                      packed_split + l.split_elems_off * 2, view ? view_bias_rows : folded + l.folded_off,
-                                                      view ? S : 0, view ? n_rays : 1, st.y, Mp, l.n_padded, 1, stream));
-            } else if (!st.x1 && !pts && l.n_padded % 128 == 0 && l.n_padded >= 512 && st.y != t1 && config().pipe != 0) {
+            if (!st.x1 && !pts && l.n_padded % 128 == 0 && l.n_padded >= 512 && st.y != t1 && config().pipe != 0) {
                 // Wide first layer: the 63 encoding features of every point are computed ONCE into panels (t1 is free until layer 1
                 // writes it) and the layer runs as an ordinary K = 64 launch of the pipelined kernel.  The generated-operand kernel
                 // (k_layer<.., L0>) re-derives them in each of the n_padded / 128 feature-tile workgroups of a point tile — 8 times
@@ -469,14 +405,6 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
             } else if (!st.x1) {
                 MOFA_TRY(mofa_layer0_forward(rays_o, rays_d, z, z_row_stride, pts, M, S, packed + l.packed_off,
                                              folded + l.folded_off, st.y, Mp, l.n_padded, stream));
-            } else if (split_pieces && l.n_padded % 128 == 0) {
-                // OPT-IN split-product path (MOFA_GEMM): bf16 matrix pipe, fp32 accumulation
-                const bool view = st.li == p.view;
-                MOFA_TRY(mofa_layer_forward_split(st.x1, l.k_padded[0], st.x2, st.x2 ? l.k_padded[1] : 0,
-                                                  packed_split ? packed_split + l.split_elems_off * (size_t)(split_pieces < 0 ? -split_pieces : split_pieces) : nullptr,
-                                                  packed + l.packed_off, split_pieces,
-                                                  view ? view_bias_rows : folded + l.folded_off, view ? S : 0,
-                                                  view ? n_rays : 1, st.y, Mp, l.n_padded, 1, stream));
             } else if (st.li == p.view) {
                 MOFA_TRY(mofa_layer_forward(st.x1, l.k_padded[0], nullptr, 0, packed + l.packed_off, view_bias_rows, S,
                                             n_rays, st.y, Mp, l.n_padded, 1, stream));
@@ -489,7 +417,7 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     // ---- heads: sigma from sigmaCodes, rgb from the view layer's output ------------------------------------------
     {
         const Layer& l = p.L[p.alpha];
-        auto head = hh ? mofa_internal_head_forward_hh : mofa_head_forward;
+        auto head = mofa_head_forward;
         MOFA_TRY(head(sigma, l.k_padded[0], Mp, packed + l.packed_off, folded + l.folded_off, 1, raw_out, 3, M, stream));
         const Layer& r = p.L[p.rgb];
         MOFA_TRY(head(v, r.k_padded[0], Mp, packed + r.packed_off, folded + r.folded_off, 3, raw_out, 0, M, stream));

@@ -41,8 +41,6 @@ class HipNet:
         self._packed_t: Optional[torch.Tensor] = None
         self._packed_t_key = None
         self._bws: Optional[torch.Tensor] = None
-        self._split: Optional[torch.Tensor] = None
-        self._split_key = None
         self._nominal, self._nominal_key = None, None
 
     @property
@@ -50,9 +48,9 @@ class HipNet:
         return self._net_strong if self._net_strong is not None else self._net_weak()
 
     def invalidate(self):
-        """Forget the packed / transposed / split copies of the weights (they are rebuilt on the next call).  Needed only
+        """Forget the packed / transposed copies of the weights (they are rebuilt on the next call).  Needed only
         after an edit made through ``.data``, which bypasses the version counter the cache keys on."""
-        self._packed_key = self._packed_t_key = self._split_key = self._nominal_key = None
+        self._packed_key = self._packed_t_key = self._nominal_key = None
 
     # -- weights -----------------------------------------------------------------------------------
     def _weights(self):
@@ -91,28 +89,6 @@ class HipNet:
                       "mofa_net_pack_t")
             self._packed_t_key = key
         return self._packed_t
-
-    def split(self):
-        """OPT-IN split-product mode (env MOFA_GEMM=bf16x3|bf16x6, default off = exact fp32 MFMA): weights pre-split into
-        2 / 3 bf16 planes.  Returns ``(ptr, pieces)`` or ``(None, 0)``."""
-        import os
-        mode = os.environ.get("MOFA_GEMM", "")
-        pieces = {"bf16x3": 2, "bf16x6": 3, "fp16x3": -2}.get(mode, 0)
-        if not pieces:
-            if mode not in ("", "fp32"):
-                raise lib.MofaError(f"MOFA_GEMM={mode!r}: expected fp32 (default), bf16x3, bf16x6 or fp16x3")
-            return None, 0
-        if pieces > 0 and os.environ.get("MOFA_SPLIT_V", "1") == "2":
-            return None, pieces          # kernel v2 splits both operands in registers from the ordinary fp32 panels
-        key = (pieces,) + self._key()
-        if self._split is None or key != self._split_key:
-            ws, _ = self._weights()
-            n = self._L.mofa_net_packed_split_elems(self.shape, pieces)
-            self._split = torch.empty(n, dtype=torch.int16, device=ws[0].device)
-            lib.check(self._L.mofa_net_pack_split(self.shape, lib.ptr_array(ws), self._split.data_ptr(), pieces, lib.stream()),
-                      "mofa_net_pack_split")
-            self._split_key = key
-        return self._split.data_ptr(), pieces
 
     def backward_workspace(self, n_points: int, device) -> torch.Tensor:
         n = self._L.mofa_net_backward_workspace_floats(self.shape, n_points)
@@ -264,13 +240,12 @@ class HipNet:
         R = viewdirs.shape[0]
         view = self._linears[-3]
         ws = self.workspace(R * S, R, viewdirs.device, slot)
-        sp, pieces = self.split()
         lib.check(self._L.mofa_net_forward(self.shape, lib.ptr(self.packed()),
                                            lib.ptr(folded if folded is not None else self._folded),
                                            lib.ptr(view.weight.detach().contiguous()),
                                            lib.ptr(view.bias.detach().contiguous()), lib.ptr(rays_o), lib.ptr(rays_d),
                                            lib.ptr(z), z_row_stride, None, lib.ptr(viewdirs), R, S, lib.ptr(ws),
-                                           lib.ptr(raw_out), None, None, sp, pieces, lib.stream()), "mofa_net_forward")
+                                           lib.ptr(raw_out), None, None, lib.stream()), "mofa_net_forward")
         return raw_out
 
     def forward_points(self, pts, viewdirs, S: int, raw_out: torch.Tensor, folded: Optional[torch.Tensor] = None):
@@ -282,6 +257,6 @@ class HipNet:
                                            lib.ptr(folded if folded is not None else self._folded),
                                            lib.ptr(view.weight.detach().contiguous()),
                                            lib.ptr(view.bias.detach().contiguous()), None, None, None, 0, lib.ptr(pts),
-                                           lib.ptr(viewdirs), R, S, lib.ptr(ws), lib.ptr(raw_out), None, None, None, 0,
+                                           lib.ptr(viewdirs), R, S, lib.ptr(ws), lib.ptr(raw_out), None, None,
                                            lib.stream()), "mofa_net_forward")
         return raw_out

@@ -35,12 +35,7 @@ SIGNATURES = {
     "mofa_net_pack": (C.c_int, [NetShape, C.POINTER(_fp), _fp, _fp]),
     "mofa_net_fold": (C.c_int, [NetShape, C.POINTER(_fp), C.POINTER(_fp), _fp, _fp, _fp, _fp, _fp]),
     "mofa_net_forward": (C.c_int, [NetShape, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _fp, _fp, _i64, _i32, _fp, _fp,
-                                   _fp, _fp, _fp, _i32, _fp]),
-    "mofa_net_packed_split_elems": (_sz, [NetShape, _i32]),
-    "mofa_net_pack_split": (C.c_int, [NetShape, C.POINTER(_fp), _fp, _i32, _fp]),
-    "mofa_pack_split": (C.c_int, [_fp, _i32, _i32, _i32, _i32, _fp, _i32, _i32, _i32, _i32, _fp]),
-    "mofa_layer_forward_split": (C.c_int, [_fp, _i32, _fp, _i32, _fp, _fp, _i32, _fp, _i32, _i64, _fp, _i64, _i32, _i32,
-                                           _fp]),
+                                   _fp, _fp, _fp]),
     "mofa_net_packed_t_floats": (_sz, [NetShape]),
     "mofa_net_tape_floats": (_sz, [NetShape, _i64]),
     "mofa_net_backward_workspace_floats": (_sz, [NetShape, _i64]),
@@ -88,9 +83,20 @@ class MofaError(RuntimeError):
     pass
 
 
+def _exact_fp32_only() -> None:
+    """The library computes in exact fp32 (fp32 MFMA, bitwise an fmaf chain) and nothing else.  Earlier rounds carried an opt-in
+    split-product experiment behind MOFA_GEMM (bf16x3 / bf16x6 / fp16x3); it is gone, and a leftover setting must not be
+    silently ignored — a caller who asked for another arithmetic is told there is none."""
+    mode = os.environ.get("MOFA_GEMM", "")
+    if mode not in ("", "fp32"):
+        raise MofaError(f"MOFA_GEMM={mode!r}: this library has no reduced-precision / split-product mode (exact fp32 only); "
+                        "unset MOFA_GEMM")
+
+
 def load() -> C.CDLL:
     """Load the HIP library (once).  Raises if it has not been built — never falls back."""
     global _lib
+    _exact_fp32_only()
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise MofaError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

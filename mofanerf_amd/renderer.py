@@ -120,7 +120,7 @@ class Renderer(torch.nn.Module):
         return self
 
     def invalidate_caches(self):
-        """Drop every derived device-side copy: packed / transposed / split weight panels of both networks, the cached
+        """Drop every derived device-side copy: packed / transposed weight panels of both networks, the cached
         texture code and the constant sample rows.  The caches are keyed on ``(data_ptr, tensor._version)``, which every
         autograd-visible in-place update bumps (optimizer steps, ``load_state_dict``, ``copy_``) — but an edit made THROUGH
         ``.data`` (``w.data.copy_(...)``, ``w.data[:] = ...``) does not, so call this after one."""
@@ -319,7 +319,7 @@ class Renderer(torch.nn.Module):
                 return raw
             # Independent sub-batches round-robin over a few streams: kernels of different streams are not in step with each
             # other, so one stream's launch boundaries (tail, write burst, first fetches) are filled by the others' workgroups.
-            h.packed(), h.split()                                   # (re)pack on the main stream, before the side streams fork
+            h.packed()                                              # (re)pack on the main stream, before the side streams fork
             main = torch.cuda.current_stream(dev)
             side = self._side_streams(n_str, dev)
             for s_ in side:
@@ -430,9 +430,6 @@ class Renderer(torch.nn.Module):
         fine = kwargs.get("network_fine")
         self._folded_fine = self._fold_codes(fine, tex_code).clone() if fine is not None else None
         all_ret = self.batchify_rays(chunk, **kwargs)
-        if os.environ.get("MOFA_GEMM") == "fp16x3" and not bool(torch.isfinite(all_ret["rgb_map"]).all()):
-            # the opt-in fp16 split assumes |activation| < 65504; beyond it the pieces overflow to Inf and the result is NaN
-            raise lib.MofaError("MOFA_GEMM=fp16x3: an activation left the fp16 range (non-finite RGB); use fp32 or bf16x6")
         for k in all_ret:
             all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
         ret_list = [all_ret[k] for k in _OUT_KEYS]

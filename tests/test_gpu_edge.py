@@ -235,28 +235,19 @@ def test_bulk_render_tool_and_ray_helpers(tmp_path):
     assert pose.grad is not None and float(pose.grad.abs().sum()) > 0
 
 
-def test_opt_in_fp16x3_range_contract_is_loud(monkeypatch):
-    """The opt-in fp16x3 mode assumes |activation| < 65504.  Outside it the result must be visibly broken (non-finite RGB ->
-    MofaError), never a plausible wrong image; the default fp32 path and bf16x6 render the same weights fine."""
-    render, kw, _ = make_product((8, 128, 10, 128), 0, 100000, DEV)
-    fine = kw["network_fine"]
-    with torch.no_grad():
-        fine.xyzEncode.linears1.Linear0.weight.mul_(3.0e5)          # first-layer outputs ~1e6: beyond fp16, fine for fp32
-        fine.xyzEncode.linears1.Linear1.weight.mul_(1.0 / 3.0e5)
-    bm, tex, exp = synth.codes(0)
-    K = synth.intrinsics(8, 8)
-    pose = rays.pose_spherical(0.0, 0.0, 16.0)[:3, :4].to(DEV)
-    call = lambda: render.render_fitting(8, 8, K, chunk=4096, c2w=pose, shapeCodes=bm.to(DEV), uvCodes=tex.to(DEV), expType=20,
-                                         expCodes=exp.to(DEV), **kw)
-    with torch.no_grad():
-        monkeypatch.setenv("MOFA_GEMM", "fp32")
-        ref = call()[0]
-        assert torch.isfinite(ref).all()
-        monkeypatch.setenv("MOFA_GEMM", "bf16x6")
-        assert torch.isfinite(call()[0]).all()
-        monkeypatch.setenv("MOFA_GEMM", "fp16x3")
-        with pytest.raises(lib.MofaError, match="fp16 range"):
-            call()
+def test_no_reduced_precision_mode_is_reachable(monkeypatch):
+    """The library is exact fp32 and nothing else: a leftover MOFA_GEMM setting (the removed split-product experiment) is refused
+    loudly instead of being ignored, and the ABI carries no split entry point."""
+    L = lib.load()
+    assert not any(hasattr(L, n) for n in ("mofa_layer_forward_split", "mofa_pack_split", "mofa_net_pack_split", "mofa_net_packed_split_elems"))
+    for mode in ("bf16x3", "bf16x6", "fp16x3"):
+        monkeypatch.setenv("MOFA_GEMM", mode)
+        with pytest.raises(lib.MofaError, match="exact fp32 only"):
+            lib.load()
+        with pytest.raises(lib.MofaError, match="exact fp32 only"):
+            lib.reload_env()
+    monkeypatch.setenv("MOFA_GEMM", "fp32")
+    lib.load()
 
 
 def test_nan_input_propagates_like_the_reference():

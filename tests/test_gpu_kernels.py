@@ -644,107 +644,3 @@ def test_wide_first_layer_through_encoding_panels_is_bit_identical(D, W, R, S, k
     nan_equal_close(tapes["1"].cpu().numpy(), outs["1"].cpu().numpy(), 2e-5)      # (tape mode takes torch's per-ray view-bias rows)
 
 
-@pytest.mark.parametrize("version", [1, 2])
-@pytest.mark.parametrize("pieces,tol", [(3, 1.5e-5), (2, 2e-3), (-2, 2e-5)])
-@pytest.mark.parametrize("M,K,N,k2", [(512, 128, 128, 0), (1024, 1024, 256, 0), (777, 256, 128, 256), (256, 16, 128, 0)])
-def test_opt_in_split_product_layer(M, K, N, k2, pieces, tol, version):
-    """OPT-IN mode (default off): fp32 products emulated by 16-bit partial products on the 16-bit matrix pipe.
-    pieces=3 (bf16x6) must be fp32-equivalent; pieces=2 (bf16x3) ~2^-15 relative per product; pieces=-2 (fp16x3: two
-    round-to-nearest fp16 pieces, three products, dropped term ~2^-22) must be fp32-class too."""
-    if pieces < 0 and version == 2:
-        pytest.skip("fp16x3 exists only with pre-split weight planes")
-    rng = np.random.default_rng(M + K + N + abs(pieces))
-    x = dev(rng.normal(size=(M, K)).astype(np.float32))
-    x2 = dev(rng.normal(size=(M, k2)).astype(np.float32)) if k2 else None
-    w = dev((rng.normal(size=(N, K + k2)) / np.sqrt(K + k2)).astype(np.float32))
-    b = dev(rng.normal(size=(N,)).astype(np.float32))
-    Mp = (M + 255) // 256 * 256
-    st = lib.stream()
-    p1 = torch.empty(L().mofa_panel_floats(Mp, K), device=DEV)
-    lib.check(L().mofa_to_panels(lib.ptr(x), M, K, lib.ptr(p1), Mp, st), "to_panels")
-    p2 = None
-    if k2:
-        p2 = torch.empty(L().mofa_panel_floats(Mp, k2), device=DEV)
-        lib.check(L().mofa_to_panels(lib.ptr(x2), M, k2, lib.ptr(p2), Mp, st), "to_panels")
-    ws = torch.empty(abs(pieces) * N * (K + k2), dtype=torch.int16, device=DEV)
-    lib.check(L().mofa_pack_split(lib.ptr(w), N, K + k2, 0, K, ws.data_ptr(), N, 0, K, pieces, st), "pack_split")
-    if k2:
-        lib.check(L().mofa_pack_split(lib.ptr(w), N, K + k2, K, k2, ws.data_ptr(), N, K // 16, k2, pieces, st), "pack_split")
-    yp = torch.full((Mp * N,), float("nan"), device=DEV)
-    wp = torch.empty(N * (K + k2), device=DEV)
-    lib.check(L().mofa_pack_panels(lib.ptr(w), N, K + k2, 0, K, lib.ptr(wp), N, 0, K, st), "pack")
-    if k2:
-        lib.check(L().mofa_pack_panels(lib.ptr(w), N, K + k2, K, k2, lib.ptr(wp), N, K // 16, k2, st), "pack")
-    lib.check(L().mofa_layer_forward_split(lib.ptr(p1), K, lib.ptr(p2), k2, ws.data_ptr() if version == 1 else None,
-                                           lib.ptr(wp) if version == 2 else None, pieces, lib.ptr(b), 0, 1, lib.ptr(yp), Mp, N, 1,
-                                           st), "layer_split")
-    y = torch.empty(M, N, device=DEV)
-    lib.check(L().mofa_from_panels(lib.ptr(yp), Mp, M, N, lib.ptr(y), st), "from_panels")
-    xin = x if x2 is None else torch.cat([x, x2], 1)
-    ref = torch.relu(xin.double().cpu() @ w.double().cpu().T + b.double().cpu()).float().numpy()
-    err = nan_equal_close(y.cpu().numpy(), ref, tol)
-    print(f"v{version} pieces={pieces} M={M} K={K + k2} N={N}: max abs err {err:.2e}")
-
-
-def test_opt_in_split_product_network(monkeypatch, knob):
-    """Whole fine-size-like network (10 x 128) under MOFA_GEMM=bf16x6 / bf16x3 vs the default exact-fp32 path."""
-    from mofanerf_amd.hipnet import HipNet
-    from mofanerf_amd.model import NeRF
-    rng = np.random.default_rng(0)
-    net = NeRF(D=10, W=128, input_ch=93, input_ch_views=27, input_ch_textureCodes=256, input_ch_shapeCodes=50,
-               use_viewdirs=True)
-    net.load_state_dict(synth.nerf_state(10, 128, 0, "fine"))
-    h = HipNet(net.to(DEV))
-    R, S = 64, 128
-    o = dev(rng.uniform(-2, 2, (R, 3)).astype(np.float32))
-    d = dev(rng.normal(0, 0.3, (R, 3)).astype(np.float32))
-    z = dev(np.sort(rng.uniform(8, 26, (R, S)).astype(np.float32), -1))
-    vd = torch.nn.functional.normalize(d, dim=-1).contiguous()
-    bm, tex, e = synth.codes(3)
-    folded = h.fold(e.to(DEV), bm.to(DEV), tex.to(DEV)).clone()
-    knob("MOFA_FUSED", "0")
-    outs = {}
-    for mode in ("fp32", "bf16x6", "bf16x3", "fp16x3"):
-        monkeypatch.setenv("MOFA_GEMM", mode)
-        raw = torch.empty(R, S, 4, device=DEV)
-        h.forward_rays(o, d, z, S, vd, S, raw, folded)
-        torch.cuda.synchronize()
-        outs[mode] = raw.cpu().numpy()
-    e6 = nan_equal_close(outs["bf16x6"], outs["fp32"], 3e-5)
-    e3 = nan_equal_close(outs["bf16x3"], outs["fp32"], 3e-3)
-    eh = nan_equal_close(outs["fp16x3"], outs["fp32"], 5e-5)
-    print(f"raw: bf16x6 vs fp32 {e6:.2e}, bf16x3 vs fp32 {e3:.2e}, fp16x3 vs fp32 {eh:.2e}")
-    assert e6 < e3 and eh < e3
-
-
-def test_opt_in_fp16x3_piece_panels(monkeypatch, knob):
-    """fp16x3 can keep activations as PRE-SPLIT fp16 piece panels between layers whenever every layer width is a multiple
-    of 128 (default from width 512 up; forced here for 8 x 256, view layer 128).  Splitting at every use instead (MOFA_SPLIT_HH=0) feeds the matrix pipe the very same
-    pieces, so only the two heads - which then read h1 + h2 instead of the fp32 value, 2^-23 relative - may differ."""
-    from mofanerf_amd.hipnet import HipNet
-    from mofanerf_amd.model import NeRF
-    rng = np.random.default_rng(1)
-    net = NeRF(D=8, W=256, input_ch=93, input_ch_views=27, input_ch_textureCodes=256, input_ch_shapeCodes=50,
-               use_viewdirs=True)
-    net.load_state_dict(synth.nerf_state(8, 256, 0, "coarse"))
-    h = HipNet(net.to(DEV))
-    R, S = 96, 64
-    o = dev(rng.uniform(-2, 2, (R, 3)).astype(np.float32))
-    d = dev(rng.normal(0, 0.3, (R, 3)).astype(np.float32))
-    z = dev(np.sort(rng.uniform(8, 26, (R, S)).astype(np.float32), -1))
-    vd = torch.nn.functional.normalize(d, dim=-1).contiguous()
-    bm, tex, e = synth.codes(2)
-    folded = h.fold(e.to(DEV), bm.to(DEV), tex.to(DEV)).clone()
-    outs = {}
-    for name, gemm, hh in (("fp32", "fp32", "1"), ("panels", "fp16x3", "1"), ("at_use", "fp16x3", "0")):
-        monkeypatch.setenv("MOFA_GEMM", gemm)
-        knob("MOFA_SPLIT_HH", hh)
-        raw = torch.full((R, S, 4), float("nan"), device=DEV)
-        h.forward_rays(o, d, z, S, vd, S, raw, folded)
-        torch.cuda.synchronize()
-        outs[name] = raw.cpu().numpy()
-    e_pan = nan_equal_close(outs["panels"], outs["fp32"], 5e-5)
-    e_use = nan_equal_close(outs["at_use"], outs["fp32"], 5e-5)
-    e_rel = nan_equal_close(outs["panels"], outs["at_use"], 1e-6, 1e-6)
-    print(f"raw vs fp32: piece panels {e_pan:.2e}, split at use {e_use:.2e}; panels vs at-use {e_rel:.2e}")
-    assert e_rel > 0 or R * S % 256, "the two modes should differ in the heads' last bits (is the piece-panel path running?)"

@@ -169,22 +169,6 @@ def test_fine_pass_teacher_forced_true_size(golden):
     _teacher_forced(golden("e2e_true.npz"))
 
 
-def test_opt_in_bf16x6_teacher_forced_true_size(golden, monkeypatch):
-    """OPT-IN split-product mode at the shipped sizes: with the reference's sample positions, bf16x6 must still meet the
-    1e-4 gate on every ray (it is fp32-equivalent: measured ~1e-6)."""
-    monkeypatch.setenv("MOFA_GEMM", "bf16x6")
-    outs = _teacher_forced(golden("e2e_true.npz"))
-    assert outs["fine"]["rgb"] < 2e-5
-
-
-def test_opt_in_fp16x3_teacher_forced_true_size(golden, monkeypatch):
-    """OPT-IN fp16x3 mode (two fp16 pieces per operand, three products) at the shipped sizes with the reference's sample
-    positions: must meet the same 1e-4 gate on every ray (CPU study predicts ~6e-7 on RGB)."""
-    monkeypatch.setenv("MOFA_GEMM", "fp16x3")
-    outs = _teacher_forced(golden("e2e_true.npz"))
-    assert outs["fine"]["rgb"] < 2e-5
-
-
 def test_run_network_api():
     """run_network(inputs[R,S,3], viewdirs[R,3], fn) — the reference's network_query_fn."""
     from oracle import mofa_oracle as orc

@@ -14,64 +14,6 @@ L = lib.load()
 dev = "cuda"
 
 
-def run_split(M, K, N, pieces, iters=10, version=2):
-    x = torch.randn(M * K, device=dev); w = torch.randn(N, K, device=dev) * 0.03
-    b = torch.randn(N, device=dev); y = torch.empty(M * N, device=dev)
-    ws = torch.empty(abs(pieces) * N * K, dtype=torch.int16, device=dev)
-    wp = torch.empty(N * K, device=dev)
-    st = lib.stream()
-    lib.check(L.mofa_pack_split(lib.ptr(w.contiguous()), N, K, 0, K, ws.data_ptr(), N, 0, K, pieces, st), "pack_split")
-    lib.check(L.mofa_pack_panels(lib.ptr(w.contiguous()), N, K, 0, K, lib.ptr(wp), N, 0, K, st), "pack")
-    args = (lib.ptr(x), K, None, 0, ws.data_ptr() if version == 1 else None, lib.ptr(wp) if version == 2 else None, pieces,
-            lib.ptr(b), 0, 1, lib.ptr(y), M, N, 1, st)
-    for _ in range(3):
-        lib.check(L.mofa_layer_forward_split(*args), "layer_split")
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        lib.check(L.mofa_layer_forward_split(*args), "layer_split")
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    return ms, 2.0 * M * K * N / (ms * 1e-3) / 1e12
-
-
-def run_split_hh(M, K, N, iters=10):
-    """fp16x3 with pre-split activation panels (net-internal entry point): time a layer whose INPUT is a real piece-panel
-    tensor (the output of a first call), so operand statistics are those of the running network."""
-    sys.exit("the net-internal piece-panel entry point is no longer exported (the library exports the C ABI only): time the mode "
-             "end to end with `python bench.py --gemm fp16x3` instead")
-    w = torch.randn(N, K, device=dev) * (2.0 / K) ** 0.5
-    b = torch.randn(N, device=dev) * 0.1
-    ws = torch.empty(2 * N * K, dtype=torch.int16, device=dev)
-    st = lib.stream()
-    lib.check(L.mofa_pack_split(lib.ptr(w.contiguous()), N, K, 0, K, ws.data_ptr(), N, 0, K, -2, st), "pack_split")
-    x = torch.zeros(M * K, device=dev)
-    y = torch.empty(M * N, device=dev)
-    # seed: fp32 panels -> (in-register split kernel) would give fp32 output; instead run hh kernel on zeros (-> relu(b)) twice
-    lib.check(f(lib.ptr(x), K, None, 0, ws.data_ptr(), lib.ptr(b), 0, 1, lib.ptr(y), M, N, 1, st), "hh")
-    x2 = y.clone() if K == N else None
-    src = x2 if x2 is not None else x
-    lib.check(f(lib.ptr(src), K, None, 0, ws.data_ptr(), lib.ptr(b), 0, 1, lib.ptr(y), M, N, 1, st), "hh")
-    if K == N:
-        src = y.clone()
-    for _ in range(3):
-        lib.check(f(lib.ptr(src), K, None, 0, ws.data_ptr(), lib.ptr(b), 0, 1, lib.ptr(y), M, N, 1, st), "hh")
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        lib.check(f(lib.ptr(src), K, None, 0, ws.data_ptr(), lib.ptr(b), 0, 1, lib.ptr(y), M, N, 1, st), "hh")
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    return ms, 2.0 * M * K * N / (ms * 1e-3) / 1e12
-
-
-_measure = None
-
-
 def measure_lib():
     global _measure
     if _measure is None:
@@ -176,26 +118,6 @@ if __name__ == "__main__" and "--arms" in sys.argv:
     i = sys.argv.index("--arms")
     names = sys.argv[i + 1].split(",") if len(sys.argv) > i + 1 else measure_lib().mofa_measure_arms().decode().split(",")
     ab(["product"] + [n for n in names if n != "timeline"], ((196608, 1024, 1024, 0), (196608, 256, 256, 0), (32768, 1024, 1024, 0)))
-    sys.exit(0)
-
-if __name__ == "__main__" and "--split-hh" in sys.argv:
-    for (M, K, N) in ((196608, 1024, 1024), (196608, 256, 256)):
-        ms, tf = run_split_hh(M, K, N)
-        print(f"split fp16x3 piece panels M={M} K={K} N={N}: {ms:8.3f} ms  {tf:7.2f} algorithmic TFLOP/s  "
-              f"(16-bit pipe at {tf * 3 / 2500 * 100:4.1f}% of 2.5 PF)", flush=True)
-        ms, tf = run_split(M, K, N, -2, version=1)
-        print(f"split fp16x3 split-at-use  M={M} K={K} N={N}: {ms:8.3f} ms  {tf:7.2f} algorithmic TFLOP/s", flush=True)
-    sys.exit(0)
-
-if __name__ == "__main__" and "--split" in sys.argv:
-    for version in (1, 2):
-      for pieces, name in ((3, "bf16x6"), (2, "bf16x3"), (-2, "fp16x3")):
-        if pieces < 0 and version == 2:
-            continue
-        for (M, K, N) in ((196608, 1024, 1024), (196608, 1024, 512), (196608, 256, 256)):
-            ms, tf = run_split(M, K, N, pieces, version=version)
-            print(f"split v{version} {name} M={M} K={K} N={N}: {ms:8.3f} ms  {tf:7.2f} algorithmic TFLOP/s  "
-                  f"({tf / 157.3:4.2f}x the fp32-MFMA peak; 16-bit pipe at {tf * (6 if pieces == 3 else 3) / 2500 * 100:4.1f}% of 2.5 PF)", flush=True)
     sys.exit(0)
 
 if __name__ == "__main__":
