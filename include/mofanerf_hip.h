@@ -35,16 +35,20 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define MOFA_ABI_VERSION 1
+#define MOFA_ABI_VERSION 2 /* 2: MofaNetShape carries the encoding / code widths; explicit-point backward; mask tape; no split modes */
 #define MOFA_OK 0
 #define MOFA_EINVAL (-1)
 #define MOFA_EHIP (-2)
 
-#define MOFA_PE_POINT_FREQS 10 /* multires       (tools/config_parser.py) -> 63 features */
-#define MOFA_PE_VIEW_FREQS 4   /* multires_views                          -> 27 features */
-#define MOFA_CH_EXP 30
-#define MOFA_CH_SHAPE 50
-#define MOFA_CH_TEX 256
+/* the shipped configuration (configs/exp_mofanerf.txt over tools/config_parser.py:51-56,113-118) — DEFAULTS, not limits:
+ * every one of them is a field of MofaNetShape below */
+#define MOFA_DEFAULT_PE_POINT_FREQS 10 /* multires       -> 3 + 6*10 = 63 features */
+#define MOFA_DEFAULT_PE_VIEW_FREQS 4   /* multires_views -> 3 + 6*4  = 27 features */
+#define MOFA_DEFAULT_CH_EXP 30         /* input_ch_expCodes     */
+#define MOFA_DEFAULT_CH_SHAPE 50       /* input_ch_shapeCodes   */
+#define MOFA_DEFAULT_CH_TEX 256        /* input_ch_textureCodes */
+#define MOFA_MAX_PE_FREQS 16           /* 3 + 6*16 = 99 features */
+#define MOFA_MAX_CODE 4096
 #define MOFA_ROW_TILE 256 /* activation rows are padded to this */
 
 int mofa_abi_version(void);
@@ -60,17 +64,28 @@ const char* mofa_last_error(void);   /* thread-local text of the calling thread'
 int mofa_config_reload(void);
 
 /* ---- network description -------------------------------------------------------------------
- * NeRF(D, W, use_viewdirs=True, skips=[4]) of models/model.py:80-137.  `weights`/`biases` are the
- * 2D+7 Linear layers in state-dict order (mofanerf_amd/schema.py::nerf_layers):
+ * NeRF(D, W, input_ch, input_ch_views, input_ch_textureCodes, input_ch_shapeCodes, use_viewdirs=True, skips=[4]) of
+ * models/model.py:80-137 as tools/create_model_condition.py:16-34 builds it from the flags of tools/config_parser.py:51-56,113-118:
+ *   input_ch       = (3 + 6*multires) + input_ch_expCodes      (get_embedder, models/model.py:48-63; i_embed = -1: multires -> 0)
+ *   input_ch_views =  3 + 6*multires_views
+ * `weights`/`biases` are the 2D+7 Linear layers in state-dict order (mofanerf_amd/schema.py::nerf_layers):
  *   xyzEncode.linears1.Linear0..3, linear_BiM_xyz.linears1.Linear0..4, .linears2.Linear0..D-6,
  *   linear_uv_xyzBiM.linears1.Linear0..4, .linears2.Linear0..D-6, linear_view_xyBMuv.0,
- *   alpha_linear.0, rgb_linear — each weight row-major [out, in] exactly as PyTorch stores it. */
+ *   alpha_linear.0, rgb_linear — each weight row-major [out, in] exactly as PyTorch stores it; mofa_net_layer_dims() states the
+ * [out, in] every entry point below assumes for layer li, so a host layer can REFUSE a module that does not match. */
 typedef struct MofaNetShape {
-    int32_t D; /* netdepth  (8 coarse / 10 fine)   */
-    int32_t W; /* netwidth  (256 coarse / 1024 fine) */
+    int32_t D;              /* netdepth  (8 coarse / 10 fine)   */
+    int32_t W;              /* netwidth  (256 coarse / 1024 fine) */
+    int32_t pe_point_freqs; /* multires       (0 .. MOFA_MAX_PE_FREQS; 0 = the raw coordinates only, i_embed = -1) */
+    int32_t pe_view_freqs;  /* multires_views (same range) */
+    int32_t ch_exp;         /* expression-code columns behind the point encoding in xyzEncode.Linear0 (0 .. MOFA_MAX_CODE) */
+    int32_t ch_shape;       /* shape-code columns in front of linear_BiM_xyz.linears{1,2}.Linear0 */
+    int32_t ch_tex;         /* texture-code columns in front of linear_uv_xyzBiM.linears{1,2}.Linear0 */
 } MofaNetShape;
 
-int mofa_net_num_layers(MofaNetShape s);          /* 2D+7 */
+int mofa_net_num_layers(MofaNetShape s);          /* 2D+7, or MOFA_EINVAL for an unsupported shape */
+int mofa_net_layer_dims(MofaNetShape s, int32_t li, int32_t* n_out, int32_t* n_in);   /* PyTorch weight shape of layer li */
+int mofa_pe_k_padded(int32_t n_freqs);            /* roundup(3 + 6*n_freqs, 64): K of the first layer's operand panels */
 size_t mofa_net_packed_floats(MofaNetShape s);    /* size of the packed per-point weight blob */
 size_t mofa_net_folded_floats(MofaNetShape s);    /* size of the per-call folded-bias blob    */
 size_t mofa_net_workspace_floats(MofaNetShape s, int64_t n_points, int64_t n_rays);
@@ -81,10 +96,10 @@ size_t mofa_net_workspace_floats(MofaNetShape s, int64_t n_points, int64_t n_ray
 int mofa_net_pack(MofaNetShape s, const float* const* weights, float* packed, void* stream);
 
 /* Per-call folded biases: b' = b + W[:, const cols] @ code for the five conditioned layers
- * (expression 30 -> xyzEncode.L0; shape 50 -> BiM l1.L0 / l2.L0; texture 256 -> uv l1.L0 / l2.L0),
+ * (expression [ch_exp] -> xyzEncode.L0; shape [ch_shape] -> BiM l1.L0 / l2.L0; texture [ch_tex] -> uv l1.L0 / l2.L0),
  * plus plain copies of every other bias.  Replaces the torch.cat of expanded codes in
- * render_class.py:74-85,104 and model.py:129,132.   exp_code[30] is the ALREADY modulated code
- * (scale*sigma+bias, render_class.py:81). */
+ * render_class.py:74-85,104 and model.py:129,132.   exp_code is the ALREADY modulated code
+ * (scale*sigma+bias, render_class.py:81).  A code of width 0 may be NULL. */
 int mofa_net_fold(MofaNetShape s, const float* const* weights, const float* const* biases,
                   const float* exp_code, const float* shape_code, const float* tex_code, float* folded,
                   void* stream);
@@ -94,34 +109,40 @@ int mofa_net_fold(MofaNetShape s, const float* const* weights, const float* cons
  * 2D+5 fused Linear+bias+ReLU layers on MFMA, per-ray view-direction bias, sigma/rgb heads.
  *   rays_o, rays_d, viewdirs [n_rays,3]; z [n_rays,S] (z_row_stride = S) or one shared row (stride 0)
  *   pts: optional explicit [n_rays*S,3] points (then rays_o/rays_d/z may be NULL)
- *   view_w [W/2, 27+W], view_b [W/2]: the ORIGINAL linear_view_xyBMuv.0 tensors (their 27 view
+ *   view_w [W/2, (3+6*multires_views)+W], view_b [W/2]: the ORIGINAL linear_view_xyBMuv.0 tensors (their view-encoding
  *   columns become a per-ray bias, computed here from viewdirs)
  *   raw_out [n_rays,S,4] = (rgb pre-sigmoid, sigma pre-ReLU)
  *   workspace: mofa_net_workspace_floats(s, n_rays*S, n_rays) floats.
- *   tape: NULL for inference (4 activation buffers are recycled), or mofa_net_tape_floats() floats that receive EVERY
- *         layer's output for mofa_net_backward (fitting / training; sized for 288 GB of HBM: no recomputation)
+ *   tape: NULL, or mofa_net_tape_floats() floats that receive EVERY layer's output for mofa_net_backward WITH weight gradients
+ *         (training; sized for 288 GB of HBM: no recomputation).  tape == mask_tape == NULL: inference, 4 recycled buffers.
+ *   mask_tape: NULL, or mofa_net_mask_tape_words() 64-bit words that receive ONE BIT per layer output, (output > 0) — all the
+ *         backward needs when no weight gradient is asked for (fitting: run_fit.py:305-313 never steps the networks).  The
+ *         activations themselves are recycled as in inference: 1/32 of the tape, no recomputation.  Excludes `tape`.
  *   view_bias_rows: NULL (computed here from viewdirs), or caller-provided per-ray bias rows [n_rays, roundup(W/2,64)]
  *         (the autograd path computes them on the host so that gradients reach viewdirs and the 27 view columns) */
 int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, const float* view_w,
                      const float* view_b, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
                      const float* pts, const float* viewdirs, int64_t n_rays, int32_t S, float* workspace,
-                     float* raw_out, float* tape, const float* view_bias_rows, void* stream);
+                     float* raw_out, float* tape, uint64_t* mask_tape, const float* view_bias_rows, void* stream);
 /* ---- backward (run_fit.py:305-313 photometric fitting, run_train.py:333-357 training) -----------------------
- * Backward of mofa_net_forward given d_raw [n_rays,S,4] and the tape of that forward:
+ * Backward of mofa_net_forward given d_raw [n_rays,S,4] and the tape (fp32, or mask-only when d_weights == NULL) of that forward:
  *   d_folded  [mofa_net_folded_floats]: gradient w.r.t. every folded bias (sum over points of the ReLU-masked
  *             pre-activation gradient) — host autograd carries it on to the codes / raw biases / constant columns;
  *   d_view_bias_rows [n_rays, roundup(W/2,64)]: gradient w.r.t. the per-ray view bias rows;
  *   d_rays_o, d_rays_d [n_rays,3]: through the positional encoding and pts = o + d*z (z carries no gradient: the
- *             coarse z is constant and the fine z is detached, render_class.py:326).
+ *             coarse z is constant and the fine z is detached, render_class.py:326);
+ *   or, when the forward ran on explicit points (`pts` != NULL — run_network(inputs, viewdirs, fn) under autograd,
+ *             render_class.py:69-94): d_pts [n_rays*S,3]; rays_o / rays_d / z / d_rays_o / d_rays_d are then unused (NULL).
  * packed_t: transposed weight panels from mofa_net_pack_t; workspace: mofa_net_backward_workspace_floats(). */
 size_t mofa_net_packed_t_floats(MofaNetShape s);
 size_t mofa_net_tape_floats(MofaNetShape s, int64_t n_points);
+size_t mofa_net_mask_tape_words(MofaNetShape s, int64_t n_points);   /* uint64 words = tape floats / 64 */
 size_t mofa_net_backward_workspace_floats(MofaNetShape s, int64_t n_points);
 int mofa_net_pack_t(MofaNetShape s, const float* const* weights, float* packed_t, void* stream);
-int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t, const float* tape,
-                      const float* d_raw, const float* rays_o, const float* rays_d, const float* z,
-                      int64_t z_row_stride, int64_t n_rays, int32_t S, float* workspace, float* d_folded,
-                      float* d_view_bias_rows, float* d_rays_o, float* d_rays_d, float* const* d_weights, void* stream);
+int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t, const float* tape, const uint64_t* mask_tape,
+                      const float* d_raw, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
+                      const float* pts, int64_t n_rays, int32_t S, float* workspace, float* d_folded,
+                      float* d_view_bias_rows, float* d_rays_o, float* d_rays_d, float* d_pts, float* const* d_weights, void* stream);
 /* d_weights: NULL (fitting: only codes/pose are optimised), or 2D+7 pointers to [out,in] gradient tensors in state-dict
  * order: the per-point column blocks are OVERWRITTEN with dW = G^T X (fp32 MFMA, contraction over the points, split over
  * M with a deterministic second-stage sum); the per-call-constant columns are left untouched (host autograd owns them). */
@@ -132,20 +153,29 @@ int mofa_weight_grad(const float* g, int32_t n_padded, const float* x, int32_t k
                      void* stream);
 int mofa_head_weight_grad(const float* d_raw, int32_t raw_off, int32_t n_out, const float* x, int32_t k_padded,
                           int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, void* stream);
-int mofa_pe_panels(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride, int64_t n_points,
-                   int32_t S, int64_t m_padded, float* out, void* stream);
+/* positional-encoding features of every point (o + d z, or explicit `pts`) as panels [mofa_pe_k_padded(n_freqs)/16][m_padded][16] */
+int mofa_pe_panels(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride, const float* pts, int64_t n_points,
+                   int32_t S, int32_t n_freqs, int64_t m_padded, float* out, void* stream);
 /* pieces of mofa_net_backward (unit-testable) */
 int mofa_pack_panels_t(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, float* dst,
                        int32_t rows_padded, int32_t k_padded, void* stream);
+/* mask: the saved fp32 activation (dx *= mask > 0).  _bits: the same mask as ONE BIT per activation — the mask-only tape's layout:
+ * float offset o of the dx-shaped panel buffer <-> bit ((o & 255) >> 2) of 64-bit word (o >> 8) * 4 + (o & 3). */
 int mofa_layer_backward_data(const float* g, int32_t g_k, const float* wt_packed, const float* mask, int32_t accumulate,
                              float* dx, int64_t m_padded, int32_t k_out_padded, void* stream);
+int mofa_layer_backward_data_bits(const float* g, int32_t g_k, const float* wt_packed, const uint64_t* mask_bits, int32_t accumulate,
+                                  float* dx, int64_t m_padded, int32_t k_out_padded, void* stream);
 int mofa_head_backward(const float* d_raw, int32_t raw_off, int32_t n_out, const float* w_dense, int32_t k_padded,
                        const float* mask, int32_t accumulate, float* dx, int64_t m_padded, int64_t n_points, void* stream);
+int mofa_head_backward_bits(const float* d_raw, int32_t raw_off, int32_t n_out, const float* w_dense, int32_t k_padded,
+                            const uint64_t* mask_bits, int32_t accumulate, float* dx, int64_t m_padded, int64_t n_points, void* stream);
 int mofa_bias_grad(const float* g, int64_t m_padded, int64_t n_points, int32_t n_padded, float* out, void* stream);
 int mofa_bias_grad_rays(const float* g, int64_t m_padded, int64_t n_rays, int32_t S, int32_t n_padded, float* out,
                         void* stream);
 int mofa_pe_backward(const float* dpe, int64_t m_padded, const float* rays_o, const float* rays_d, const float* z,
-                     int64_t z_row_stride, int64_t n_rays, int32_t S, float* d_rays_o, float* d_rays_d, void* stream);
+                     int64_t z_row_stride, int64_t n_rays, int32_t S, int32_t n_freqs, float* d_rays_o, float* d_rays_d, void* stream);
+int mofa_pe_backward_points(const float* dpe, int64_t m_padded, const float* pts, int64_t n_points, int32_t n_freqs, float* d_pts,
+                            void* stream);
 /* raw2outputs backward: upstream gradients g_* (g_disp/g_acc/g_depth/g_weights may be NULL = zero) ->
  * d_raw [n_rays,S,4] and the |rays_d| contribution d_rays_d [n_rays,3] (may be NULL). */
 int mofa_composite_backward(const float* raw, const float* z, int64_t z_row_stride, const float* rays_d,
@@ -159,25 +189,31 @@ int mofa_pack_panels(const float* w, int32_t n_out, int32_t ld, int32_t col0, in
                      int32_t rows_padded, int32_t panel0, int32_t k_padded, void* stream);
 int mofa_to_panels(const float* x, int64_t rows, int32_t k, float* dst, int64_t rows_padded, void* stream);
 int mofa_from_panels(const float* src, int64_t rows_padded, int64_t rows, int32_t k, float* x, void* stream);
-/* y = act(x1|x2 @ Wpacked^T + bias); bias_row_div = 0: bias[Np]; else bias[(m / div), Np] (per ray). */
+/* y = act(x1|x2 @ Wpacked^T + bias); bias_row_div = 0: bias[Np]; else bias[(m / div), Np] (per ray).
+ * _masked: mask_bits_out = NULL, or m_padded * n_padded / 64 words receiving (y > 0) as bits (mask-only tape; requires relu). */
 int mofa_layer_forward(const float* x1, int32_t k1, const float* x2, int32_t k2, const float* w_packed,
                        const float* bias, int32_t bias_row_div, int64_t bias_rows, float* y, int64_t m_padded,
                        int32_t n_padded, int32_t relu, void* stream);
-/* first layer with the positional encoding generated in the prologue (model.py:44-45 + Linear0). */
+int mofa_layer_forward_masked(const float* x1, int32_t k1, const float* x2, int32_t k2, const float* w_packed,
+                              const float* bias, int32_t bias_row_div, int64_t bias_rows, float* y, int64_t m_padded,
+                              int32_t n_padded, int32_t relu, uint64_t* mask_bits_out, void* stream);
+/* first layer with the positional encoding (n_freqs = multires) generated in the prologue (model.py:44-45 + Linear0);
+ * w_packed: mofa_pe_k_padded(n_freqs) / 16 panels. */
 int mofa_layer0_forward(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
-                        const float* pts, int64_t n_points, int32_t S, const float* w_packed, const float* bias,
-                        float* y, int64_t m_padded, int32_t n_padded, void* stream);
+                        const float* pts, int64_t n_points, int32_t S, int32_t n_freqs, const float* w_packed, const float* bias,
+                        float* y, int64_t m_padded, int32_t n_padded, uint64_t* mask_bits_out, void* stream);
 /* Layer 0 with ray generation FOLDED INTO THE PROLOGUE: the ray of point m is built from
  * (intrinsics, c2w[3,4], pixel) by the arithmetic of mofa_get_rays — pixel = pixels[m / S] (flat row * img_w + col) or
  * pix0 + m / S when pixels == NULL — then pts = o + d * z as in mofa_layer0_forward.  Bit-identical to
  * mofa_get_rays(_at) followed by mofa_layer0_forward.  (The shipped renderer keeps the 24 B / ray arrays because compositing and
  * the positional-encoding backward read them as well; this entry is the kernel-level form.) */
 int mofa_layer0_forward_cam(int32_t img_w, float fx, float fy, float cx, float cy, const float* c2w, const int32_t* pixels,
-                            int64_t pix0, const float* z, int64_t z_row_stride, int64_t n_points, int32_t S,
+                            int64_t pix0, const float* z, int64_t z_row_stride, int64_t n_points, int32_t S, int32_t n_freqs,
                             const float* w_packed, const float* bias, float* y, int64_t m_padded, int32_t n_padded, void* stream);
 int mofa_head_forward(const float* x, int32_t k_padded, int64_t m_padded, const float* w_dense, const float* b,
                       int32_t n_out, float* raw, int32_t raw_off, int64_t n_points, void* stream);
-int mofa_view_bias(const float* viewdirs, int64_t n_rays, const float* w, int32_t n_out, int32_t ld,
+/* out[r][n] = bias[n] + sum_k w[n][k] * PE(viewdirs[r])[k], k < 3 + 6 * n_freqs (n_freqs = multires_views) */
+int mofa_view_bias(const float* viewdirs, int64_t n_rays, int32_t n_freqs, const float* w, int32_t n_out, int32_t ld,
                    const float* bias, float* out, int32_t n_padded, void* stream);
 int mofa_positional_encode(const float* x, int64_t n, int32_t n_freqs, float* out, void* stream);
 

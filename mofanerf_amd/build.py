@@ -14,6 +14,7 @@ SOURCES = ["mofa_mlp.hip", "mofa_rays.hip", "mofa_bwd.hip", "mofa_net.hip"]
 # the mofa_internal_* hand-offs between the translation units stay out of the dynamic symbol table
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden", "-Wall",
          "-Wno-unused-function"]
+LINK_FLAGS = ["-Wl,--version-script=" + os.path.join(CSRC, "exports.map")]
 
 
 def csrc_digest() -> str:
@@ -42,14 +43,14 @@ def stale() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [os.path.join(HERE, "..", "include", "mofanerf_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".map"))] + [os.path.join(HERE, "..", "include", "mofanerf_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not stale():
         return OUT
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+    cmd = [hipcc()] + FLAGS + LINK_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -4,7 +4,7 @@
 // Built with -ffp-contract=off like the forward.
 #include <type_traits>
 
-#include "mofa_common.h"
+#include "mofa_layer.h"
 
 extern "C" {
 int mofa_internal_prof_open(void* stream, int kind);
@@ -26,8 +26,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // one thread per (point, 16-byte chunk of features); dx in panels [kp][m_padded][16].
 __global__ __launch_bounds__(256) void k_head_backward(const float* __restrict__ d_raw, int raw_off, int n_out,
                                                        const float* __restrict__ w, int k_padded,
-                                                       const float* __restrict__ mask, int accumulate,
-                                                       float* __restrict__ dx, long long m_padded, long long n_points) {
+                                                       const float* __restrict__ mask, const unsigned long long* __restrict__ mask_bits,
+                                                       int accumulate, float* __restrict__ dx, long long m_padded, long long n_points) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over m_padded * (k_padded/4)
     const int chunks = k_padded >> 2;
     if (idx >= m_padded * chunks) return;
@@ -53,6 +53,10 @@ __global__ __launch_bounds__(256) void k_head_backward(const float* __restrict__
     if (mask) {
         const f32x4 s = *(const f32x4*)(mask + off);
         v.x = s.x > 0.f ? v.x : 0.f, v.y = s.y > 0.f ? v.y : 0.f, v.z = s.z > 0.f ? v.z : 0.f, v.w = s.w > 0.f ? v.w : 0.f;
+    } else if (mask_bits) {
+        bool keep[4];
+        mask_load_quad(mask_bits, off, keep);
+        v.x = keep[0] ? v.x : 0.f, v.y = keep[1] ? v.y : 0.f, v.z = keep[2] ? v.z : 0.f, v.w = keep[3] ? v.w : 0.f;
     }
     *(f32x4*)(dx + off) = v;
 }
@@ -125,11 +129,45 @@ __global__ __launch_bounds__(256) void k_colsum_rays(const float* __restrict__ g
 }
 
 // ---- positional-encoding backward + pts = o + d*z backward --------------------------------------------------
-// dpe: panels [4][m_padded][16] (gradient w.r.t. the 63 encoding features, k = 63 is padding).  One wavefront per ray.
+// gradient w.r.t. the point x from the gradient w.r.t. its 3 + 6 * n_freqs encoding features (panel layout, point row m)
+__device__ __forceinline__ void pe_point_backward(const float* __restrict__ dpe, long long m_padded, long long m, const float (&x)[3],
+                                                  int n_freqs, float (&gx)[3]) {
+    const int sw = (int)(m >> 2) & 3;
+    auto at = [&](int k) -> float {   // gradient w.r.t. encoding feature k of point m (panel layout)
+        return dpe[(long long)(k >> 4) * m_padded * 16 + m * 16 + ((((k >> 2) & 3) ^ sw) << 2) + (k & 3)];
+    };
+#pragma unroll
+    for (int d = 0; d < 3; ++d) gx[d] = at(d);                     // identity features
+#pragma unroll 1
+    for (int f = 0; f < n_freqs; ++f) {
+        const float fr = (float)(1 << f);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float gs = at(3 + 6 * f + d), gc = at(6 + 6 * f + d);
+            float sn, cs;
+            sincosf(x[d] * fr, &sn, &cs);
+            // d/dx sin(f x) = f cos(f x);  d/dx cos(f x) = -f sin(f x)
+            gx[d] += fr * (gs * cs - gc * sn);
+        }
+    }
+}
+
+// explicit points (run_network(inputs, ...) under autograd, models/render_class.py:69-94): d_pts[m] per point, one thread each
+__global__ __launch_bounds__(256) void k_pe_backward_pts(const float* __restrict__ dpe, long long m_padded, const float* __restrict__ pts,
+                                                         long long n_points, int n_freqs, float* __restrict__ d_pts) {
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= n_points) return;
+    const float x[3] = {pts[m * 3], pts[m * 3 + 1], pts[m * 3 + 2]};
+    float gx[3];
+    pe_point_backward(dpe, m_padded, m, x, n_freqs, gx);
+    d_pts[m * 3] = gx[0], d_pts[m * 3 + 1] = gx[1], d_pts[m * 3 + 2] = gx[2];
+}
+
+// dpe: panels [pe_k_padded/16][m_padded][16] (gradient w.r.t. the 3 + 6 * n_freqs encoding features; the rest is padding).  One wavefront per ray.
 __global__ __launch_bounds__(256) void k_pe_backward(const float* __restrict__ dpe, long long m_padded,
                                                      const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                      const float* __restrict__ z, long long z_row_stride,
-                                                     long long n_rays, int S, float* __restrict__ d_rays_o,
+                                                     long long n_rays, int S, int n_freqs, float* __restrict__ d_rays_o,
                                                      float* __restrict__ d_rays_d) {
     const int lane = threadIdx.x & 63;
     const long long ray = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -142,25 +180,8 @@ __global__ __launch_bounds__(256) void k_pe_backward(const float* __restrict__ d
         const float zz = z[ray * z_row_stride + s];
         const float x[3] = {__fadd_rn(ox, __fmul_rn(dx, zz)), __fadd_rn(oy, __fmul_rn(dy, zz)),
                             __fadd_rn(oz, __fmul_rn(dz, zz))};
-        const int sw = (int)(m >> 2) & 3;
-        auto at = [&](int k) -> float {   // gradient w.r.t. encoding feature k of point m (panel layout)
-            return dpe[(long long)(k >> 4) * m_padded * 16 + m * 16 + ((((k >> 2) & 3) ^ sw) << 2) + (k & 3)];
-        };
         float gx[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) gx[d] = at(d);                     // identity features
-#pragma unroll 1
-        for (int f = 0; f < MOFA_PE_POINT_FREQS; ++f) {
-            const float fr = (float)(1 << f);
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const float gs = at(3 + 6 * f + d), gc = at(6 + 6 * f + d);
-                float sn, cs;
-                sincosf(x[d] * fr, &sn, &cs);
-                // d/dx sin(f x) = f cos(f x);  d/dx cos(f x) = -f sin(f x)
-                gx[d] += fr * (gs * cs - gc * sn);
-            }
-        }
+        pe_point_backward(dpe, m_padded, m, x, n_freqs, gx);
 #pragma unroll
         for (int c = 0; c < 3; ++c) go[c] += gx[c], gd[c] += gx[c] * zz;
     }
@@ -458,15 +479,27 @@ using namespace mofa;
 
 extern "C" {
 
+static int head_backward(const float* d_raw, int32_t raw_off, int32_t n_out, const float* w_dense, int32_t k_padded,
+                         const float* mask, const uint64_t* mask_bits, int32_t accumulate, float* dx, int64_t m_padded, int64_t n_points,
+                         void* stream);
 int mofa_head_backward(const float* d_raw, int32_t raw_off, int32_t n_out, const float* w_dense, int32_t k_padded,
-                       const float* mask, int32_t accumulate, float* dx, int64_t m_padded, int64_t n_points,
-                       void* stream) {
+                       const float* mask, int32_t accumulate, float* dx, int64_t m_padded, int64_t n_points, void* stream) {
+    return head_backward(d_raw, raw_off, n_out, w_dense, k_padded, mask, nullptr, accumulate, dx, m_padded, n_points, stream);
+}
+int mofa_head_backward_bits(const float* d_raw, int32_t raw_off, int32_t n_out, const float* w_dense, int32_t k_padded,
+                            const uint64_t* mask_bits, int32_t accumulate, float* dx, int64_t m_padded, int64_t n_points, void* stream) {
+    MOFA_REQUIRE(mask_bits, "head_backward_bits: null mask");
+    return head_backward(d_raw, raw_off, n_out, w_dense, k_padded, nullptr, mask_bits, accumulate, dx, m_padded, n_points, stream);
+}
+static int head_backward(const float* d_raw, int32_t raw_off, int32_t n_out, const float* w_dense, int32_t k_padded,
+                         const float* mask, const uint64_t* mask_bits, int32_t accumulate, float* dx, int64_t m_padded, int64_t n_points,
+                         void* stream) {
     MOFA_REQUIRE(d_raw && w_dense && dx, "head_backward: null pointer");
     MOFA_REQUIRE(k_padded % 16 == 0 && n_out >= 1 && raw_off >= 0 && raw_off + n_out <= 4 && n_points <= m_padded,
                  "head_backward: bad shape");
     hipLaunchKernelGGL(k_head_backward, dim3(blocks_for(m_padded * (k_padded / 4), 256)), dim3(256), 0,
-                       (hipStream_t)stream, d_raw, raw_off, n_out, w_dense, k_padded, mask, accumulate, dx,
-                       (long long)m_padded, (long long)n_points);
+                       (hipStream_t)stream, d_raw, raw_off, n_out, w_dense, k_padded, mask, (const unsigned long long*)mask_bits,
+                       accumulate, dx, (long long)m_padded, (long long)n_points);
     return check_launch("k_head_backward");
 }
 
@@ -491,13 +524,23 @@ int mofa_bias_grad_rays(const float* g, int64_t m_padded, int64_t n_rays, int32_
 }
 
 int mofa_pe_backward(const float* dpe, int64_t m_padded, const float* rays_o, const float* rays_d, const float* z,
-                     int64_t z_row_stride, int64_t n_rays, int32_t S, float* d_rays_o, float* d_rays_d, void* stream) {
+                     int64_t z_row_stride, int64_t n_rays, int32_t S, int32_t n_freqs, float* d_rays_o, float* d_rays_d, void* stream) {
     MOFA_REQUIRE(dpe && rays_o && rays_d && z && d_rays_o && d_rays_d && n_rays * S <= m_padded,
                  "pe_backward: bad arguments");
+    MOFA_REQUIRE(n_freqs >= 0 && n_freqs <= MOFA_MAX_PE_FREQS, "pe_backward: n_freqs=%d out of [0, %d]", n_freqs, MOFA_MAX_PE_FREQS);
     hipLaunchKernelGGL(k_pe_backward, dim3(blocks_for(n_rays, kWavesPerBlock)), dim3(256), 0, (hipStream_t)stream, dpe,
-                       (long long)m_padded, rays_o, rays_d, z, (long long)z_row_stride, (long long)n_rays, S, d_rays_o,
+                       (long long)m_padded, rays_o, rays_d, z, (long long)z_row_stride, (long long)n_rays, S, n_freqs, d_rays_o,
                        d_rays_d);
     return check_launch("k_pe_backward");
+}
+
+int mofa_pe_backward_points(const float* dpe, int64_t m_padded, const float* pts, int64_t n_points, int32_t n_freqs, float* d_pts,
+                            void* stream) {
+    MOFA_REQUIRE(dpe && pts && d_pts && n_points > 0 && n_points <= m_padded, "pe_backward_points: bad arguments");
+    MOFA_REQUIRE(n_freqs >= 0 && n_freqs <= MOFA_MAX_PE_FREQS, "pe_backward_points: n_freqs=%d out of [0, %d]", n_freqs, MOFA_MAX_PE_FREQS);
+    hipLaunchKernelGGL(k_pe_backward_pts, dim3(blocks_for(n_points, 256)), dim3(256), 0, (hipStream_t)stream, dpe, (long long)m_padded,
+                       pts, (long long)n_points, n_freqs, d_pts);
+    return check_launch("k_pe_backward_pts");
 }
 
 int mofa_composite_backward(const float* raw, const float* z, int64_t z_row_stride, const float* rays_d,
@@ -927,24 +970,30 @@ __global__ __launch_bounds__(256) void k_head_wgrad_reduce(const float* __restri
     dst[(long long)o * ld + k] = s;
 }
 
-// positional-encoding features of every point as panels [4][m_padded][16] (the X operand of layer 0's weight gradient)
+// positional-encoding features of every point as panels [k_padded/16][m_padded][16] (the X operand of layer 0's weight gradient, and of
+// the wide networks' first layer); pts != NULL: explicit points instead of o + d z
 __global__ __launch_bounds__(256) void k_pe_panels(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                   const float* __restrict__ z, long long z_row_stride, long long n_points,
-                                                   int S, long long m_padded, float* __restrict__ out) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over m_padded * 64
-    if (idx >= m_padded * 64) return;
+                                                   const float* __restrict__ z, long long z_row_stride, const float* __restrict__ pts,
+                                                   long long n_points, int S, int pe_feats, int k_padded, long long m_padded,
+                                                   float* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over m_padded * k_padded
+    if (idx >= m_padded * k_padded) return;
     const int e = idx & 3, p = (idx >> 2) & 3;
     const long long rowpanel = idx >> 4;
     const long long m = rowpanel % m_padded;
     const int panel = (int)(rowpanel / m_padded);
     const int k = panel * 16 + ((p ^ ((int)(m >> 2) & 3)) << 2) + e;
     float v = 0.f;
-    if (m < n_points && k < 3 + 6 * MOFA_PE_POINT_FREQS) {
-        const long long r = m / S;
-        const int s = (int)(m - r * S);
-        const float zz = z[r * z_row_stride + s];
+    if (m < n_points && k < pe_feats) {
         const int d = k < 3 ? k : ((k - 3) % 6) % 3;
-        const float xd = __fadd_rn(rays_o[r * 3 + d], __fmul_rn(rays_d[r * 3 + d], zz));
+        float xd;
+        if (pts) xd = pts[m * 3 + d];
+        else {
+            const long long r = m / S;
+            const int s = (int)(m - r * S);
+            const float zz = z[r * z_row_stride + s];
+            xd = __fadd_rn(rays_o[r * 3 + d], __fmul_rn(rays_d[r * 3 + d], zz));
+        }
         if (k < 3) v = xd;
         else {
             const int j = k - 3, f = j / 6, rr = j - 6 * f;
@@ -1057,11 +1106,14 @@ int mofa_internal_head_weight_grad_split(const float* d_raw, int32_t raw_off, in
     return check_launch("k_head_wgrad(split)");
 }
 
-int mofa_pe_panels(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride, int64_t n_points,
-                   int32_t S, int64_t m_padded, float* out, void* stream) {
-    MOFA_REQUIRE(rays_o && rays_d && z && out && S > 0 && n_points <= m_padded, "pe_panels: bad arguments");
-    hipLaunchKernelGGL(k_pe_panels, dim3((unsigned)((m_padded * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       rays_o, rays_d, z, (long long)z_row_stride, (long long)n_points, S, (long long)m_padded, out);
+int mofa_pe_panels(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride, const float* pts, int64_t n_points,
+                   int32_t S, int32_t n_freqs, int64_t m_padded, float* out, void* stream) {
+    MOFA_REQUIRE(out && (pts || (rays_o && rays_d && z && S > 0)) && n_points <= m_padded, "pe_panels: bad arguments");
+    MOFA_REQUIRE(n_freqs >= 0 && n_freqs <= MOFA_MAX_PE_FREQS, "pe_panels: n_freqs=%d out of [0, %d]", n_freqs, MOFA_MAX_PE_FREQS);
+    const int kp = (int)round_up(3 + 6 * n_freqs, 64);
+    hipLaunchKernelGGL(k_pe_panels, dim3((unsigned)((m_padded * kp + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       rays_o, rays_d, z, (long long)z_row_stride, pts, (long long)n_points, S > 0 ? S : 1, 3 + 6 * n_freqs, kp,
+                       (long long)m_padded, out);
     return check_launch("k_pe_panels");
 }
 

@@ -36,6 +36,8 @@ struct LayerArgs {
     const float* bias;    // [bias_rows][n_padded]
     float* y;             // panels [n_padded/16][m_padded][16]
     const float* mask;    // backward epilogue: saved forward activation with y's geometry; y *= (mask > 0)
+    const unsigned long long* mask_bits;   // the same mask as ONE BIT per activation (mask-only tape, mask_store_block()); excludes `mask`
+    unsigned long long* mask_out;          // forward epilogue: also write (y > 0) as bits for a mask-only tape (NULL = no)
     int accumulate;       // backward epilogue: y = (y_old + acc) [* mask]
     // layer-0 (positional encoding prologue) inputs
     const float* rays_o;
@@ -53,6 +55,7 @@ struct LayerArgs {
     int S;
     int n_tiles;          // n_padded / BN
     int total_tiles;
+    int pe_feats;         // layer 0: number of positional-encoding features 3 + 6 * multires (the rest of the K panels is zero)
     // layer-0 camera mode (mofa_layer0_forward_cam): rays are built in the prologue from (K, c2w, pixel) instead of being read
     const float* cam_c2w;   // 12 floats [3,4] (device) or NULL = read rays_o / rays_d
     const int* cam_pix;     // flat pixel index per ray, or NULL = pixel cam_pix0 + ray
@@ -86,6 +89,24 @@ __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
     // 16 B per lane, LDS destination = wave-uniform base + lane*16 (LDS-DMA, no VGPR round trip)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ---- mask-only tape (fitting: the backward needs (activation > 0), not the activation) -------------------------------------------
+// One bit per activation, addressed through the activation's own float offset `off` inside its panel buffer: the 256 floats of
+// a 1 KiB block [256 b, 256 b + 256) own the four 64-bit words 4 b .. 4 b + 3, and float 256 b + 4 l + c is bit l of word c.  That is
+// exactly what a wavefront holds when lane l carries the 16-byte quad l of the block (the contiguous-store epilogues): word c =
+// ballot(component c > 0), so writing costs four v_cmp and one 32-byte store per KiB of activations, and reading is one 32-byte
+// wave-uniform load per KiB.  32x smaller than the fp32 tape, no recomputation.
+__device__ __forceinline__ void mask_store_block(unsigned long long* __restrict__ bits, long long off_block_floats, int lane, const f32x4 v) {
+    const unsigned long long b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);
+    if (lane < 4) bits[(off_block_floats >> 8) * 4 + lane] = lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
+}
+// the four (activation > 0) flags of the quad at float offset `off` (a multiple of 4), for any thread-to-quad mapping
+__device__ __forceinline__ void mask_load_quad(const unsigned long long* __restrict__ bits, long long off, bool (&keep)[4]) {
+    const unsigned long long* w = bits + (off >> 8) * 4;
+    const int l = (int)(off & 255) >> 2;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) keep[c] = (w[c] >> l) & 1ull;
 }
 
 // positional-encoding feature k of a 3-vector: [x, sin(2^0 x), cos(2^0 x), sin(2^1 x), ...]
@@ -316,9 +337,10 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[NI][NJ], const fl
 // No barrier: the window is wave-private and a wave's LDS operations execute in order.  `win` must not be read or written by
 // anyone else (the pipelined K loop's stage 0 is free for all waves after its last barrier).  Same values as store_tile
 // (bit-identical).  Measured against it (interleaved A/B): +0.4 % at K = N = 1024, +4 % at 256, k_mlp_fused 133.2 -> 135.5 TFLOP/s.
-template <int NI, int NJ, bool RELU>
+template <int NI, int NJ, bool RELU, bool MASKW = false>
 __device__ __forceinline__ void store_tile_staged(const f32x16 (&acc)[NI][NJ], const float* __restrict__ bias, float* __restrict__ y,
-                                                  long long m_padded, long long m_first, int n_first, int lane, float* win) {
+                                                  long long m_padded, long long m_first, int n_first, int lane, float* win,
+                                                  unsigned long long* __restrict__ mask_out = nullptr) {
     static_assert(NJ % 2 == 0, "row halves of 64 points");
     const int lr = lane & 31, g = lane >> 5, msw = (lr >> 2) & 3;   // m_first + 32 j is a multiple of 32: the row swizzle is the lane's
     f32x4 bv[NI][4];
@@ -345,6 +367,7 @@ __device__ __forceinline__ void store_tile_staged(const f32x16 (&acc)[NI][NJ], c
                 for (int it = 0; it < 4; ++it) {
                     const f32x4 v = *(const f32x4*)(win + it * 256 + lane * 4);
                     *(f32x4*)(panel + jh * 1024 + it * 256 + lane * 4) = v;
+                    if constexpr (MASKW) mask_store_block(mask_out, (panel - y) + jh * 1024 + it * 256, lane, v);
                 }
             }
         }
@@ -354,9 +377,11 @@ __device__ __forceinline__ void store_tile_staged(const f32x16 (&acc)[NI][NJ], c
 // first turns the accumulator fragments into 1 KiB contiguous wave rows, so the optional reads of dX_old and of the saved
 // activation are fully coalesced 1 KiB loads (all four of a slice in flight together) instead of 16 B per lane at a 64-byte
 // stride, and ACC / MASK are compile-time: no wait sits between a load and the next one.  Same arithmetic as the strided form.
-template <int NI, int NJ, bool ACC, bool MASK>
+// MASK: 0 none, 1 the saved fp32 activation, 2 the mask-only tape's bits (one 32-byte wave-uniform load per KiB instead of a KiB).
+template <int NI, int NJ, bool ACC, int MASK>
 __device__ __forceinline__ void store_tile_staged_bwd(const f32x16 (&acc)[NI][NJ], float* __restrict__ y, const float* __restrict__ mask,
-                                                      long long m_padded, long long m_first, int n_first, int lane, float* win) {
+                                                      long long m_padded, long long m_first, int n_first, int lane, float* win,
+                                                      const unsigned long long* __restrict__ mask_bits = nullptr) {
     static_assert(NJ % 2 == 0, "row halves of 64 points");
     const int lr = lane & 31, g = lane >> 5, msw = (lr >> 2) & 3;
 #pragma unroll
@@ -368,13 +393,21 @@ __device__ __forceinline__ void store_tile_staged_bwd(const f32x16 (&acc)[NI][NJ
             for (int jh = 0; jh < NJ / 2; ++jh) {
                 const long long off = poff + jh * 1024 + lane * 4;
                 f32x4 old[4], act[4];
+                unsigned long long mb[4][4];
                 if constexpr (ACC) {
 #pragma unroll
                     for (int it = 0; it < 4; ++it) old[it] = *(const f32x4*)(y + off + it * 256);
                 }
-                if constexpr (MASK) {
+                if constexpr (MASK == 1) {
 #pragma unroll
                     for (int it = 0; it < 4; ++it) act[it] = *(const f32x4*)(mask + off + it * 256);
+                }
+                if constexpr (MASK == 2) {
+                    const unsigned long long* w = mask_bits + ((poff + jh * 1024) >> 8) * 4;      // wave-uniform: 4 blocks x 4 words
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) mb[it][c] = w[it * 4 + c];
                 }
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj)
@@ -389,9 +422,12 @@ __device__ __forceinline__ void store_tile_staged_bwd(const f32x16 (&acc)[NI][NJ
                 for (int it = 0; it < 4; ++it) {
                     f32x4 v = *(const f32x4*)(win + it * 256 + lane * 4);
                     if constexpr (ACC) v.x += old[it].x, v.y += old[it].y, v.z += old[it].z, v.w += old[it].w;
-                    if constexpr (MASK)
+                    if constexpr (MASK == 1)
                         v.x = act[it].x > 0.f ? v.x : 0.f, v.y = act[it].y > 0.f ? v.y : 0.f, v.z = act[it].z > 0.f ? v.z : 0.f,
                         v.w = act[it].w > 0.f ? v.w : 0.f;
+                    if constexpr (MASK == 2)
+                        v.x = ((mb[it][0] >> lane) & 1ull) ? v.x : 0.f, v.y = ((mb[it][1] >> lane) & 1ull) ? v.y : 0.f,
+                        v.z = ((mb[it][2] >> lane) & 1ull) ? v.z : 0.f, v.w = ((mb[it][3] >> lane) & 1ull) ? v.w : 0.f;
                     *(f32x4*)(y + off + it * 256) = v;
                 }
             }
@@ -474,7 +510,7 @@ __global__ __launch_bounds__(256, P::kMinWaves) void k_layer(const LayerArgs a) 
             const int swz = (tid >> 2) & 3;
 #pragma unroll 1
             for (int kk = 0; kk < 16; ++kk) {
-                const float v = pe_feature(kt * 16 + kk, px, py, pz, 3 + 6 * MOFA_PE_POINT_FREQS);
+                const float v = pe_feature(kt * 16 + kk, px, py, pz, a.pe_feats);
                 xs[tid * 16 + ((((kk >> 2) & 3) ^ swz) << 2) + (kk & 3)] = v;
             }
         } else {
@@ -524,11 +560,13 @@ __global__ __launch_bounds__(256, P::kMinWaves) void k_layer(const LayerArgs a) 
         const long long mf = m0 + wm * (32 * NJ);
         const int nf = n0 + wn * 64;
         if (a.accumulate) {
-            if (a.mask) store_tile_staged_bwd<NI, NJ, true, true>(acc, a.y, a.mask, a.m_padded, mf, nf, lane, win);
-            else store_tile_staged_bwd<NI, NJ, true, false>(acc, a.y, a.mask, a.m_padded, mf, nf, lane, win);
+            if (a.mask) store_tile_staged_bwd<NI, NJ, true, 1>(acc, a.y, a.mask, a.m_padded, mf, nf, lane, win);
+            else if (a.mask_bits) store_tile_staged_bwd<NI, NJ, true, 2>(acc, a.y, nullptr, a.m_padded, mf, nf, lane, win, a.mask_bits);
+            else store_tile_staged_bwd<NI, NJ, true, 0>(acc, a.y, a.mask, a.m_padded, mf, nf, lane, win);
         } else {
-            if (a.mask) store_tile_staged_bwd<NI, NJ, false, true>(acc, a.y, a.mask, a.m_padded, mf, nf, lane, win);
-            else store_tile_staged_bwd<NI, NJ, false, false>(acc, a.y, a.mask, a.m_padded, mf, nf, lane, win);
+            if (a.mask) store_tile_staged_bwd<NI, NJ, false, 1>(acc, a.y, a.mask, a.m_padded, mf, nf, lane, win);
+            else if (a.mask_bits) store_tile_staged_bwd<NI, NJ, false, 2>(acc, a.y, nullptr, a.m_padded, mf, nf, lane, win, a.mask_bits);
+            else store_tile_staged_bwd<NI, NJ, false, 0>(acc, a.y, a.mask, a.m_padded, mf, nf, lane, win);
         }
         return;
     }
@@ -555,6 +593,10 @@ __global__ __launch_bounds__(256, P::kMinWaves) void k_layer(const LayerArgs a) 
                         const f32x4 k = *(const f32x4*)(a.mask + off);
                         v.x = k.x > 0.f ? v.x : 0.f, v.y = k.y > 0.f ? v.y : 0.f, v.z = k.z > 0.f ? v.z : 0.f,
                         v.w = k.w > 0.f ? v.w : 0.f;
+                    } else if (a.mask_bits) {
+                        bool keep[4];
+                        mask_load_quad(a.mask_bits, off, keep);
+                        v.x = keep[0] ? v.x : 0.f, v.y = keep[1] ? v.y : 0.f, v.z = keep[2] ? v.z : 0.f, v.w = keep[3] ? v.w : 0.f;
                     }
                     *(f32x4*)(a.y + off) = v;
                 }
@@ -565,7 +607,8 @@ __global__ __launch_bounds__(256, P::kMinWaves) void k_layer(const LayerArgs a) 
     // forward epilogue: bias + ReLU, into the next layer's panels
     if constexpr (P::kStagedEpilogue && PIPE && !PERRAY) {
         float* win = smem + wave * 1024;      // 4 KiB per wave inside stage 0 (free for everybody after the K loop's last barrier)
-        if (a.relu) store_tile_staged<NI, NJ, true>(acc, a.bias, a.y, a.m_padded, m0 + wm * (32 * NJ), n0 + wn * 64, lane, win);
+        if (a.mask_out) store_tile_staged<NI, NJ, true, true>(acc, a.bias, a.y, a.m_padded, m0 + wm * (32 * NJ), n0 + wn * 64, lane, win, a.mask_out);
+        else if (a.relu) store_tile_staged<NI, NJ, true>(acc, a.bias, a.y, a.m_padded, m0 + wm * (32 * NJ), n0 + wn * 64, lane, win);
         else store_tile_staged<NI, NJ, false>(acc, a.bias, a.y, a.m_padded, m0 + wm * (32 * NJ), n0 + wn * 64, lane, win);
     } else {
         f32x4 bv[NI][4];

@@ -53,9 +53,9 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ x, int k
 __global__ __launch_bounds__(256) void k_view_bias(const float* __restrict__ viewdirs, long long n_rays,
                                                    const float* __restrict__ w, int n_out, int ld,
                                                    const float* __restrict__ bias, float* __restrict__ out,
-                                                   int n_padded) {
-    constexpr int RPB = 8, NF = 3 + 6 * MOFA_PE_VIEW_FREQS;
-    __shared__ float pe[RPB][NF + 1];
+                                                   int n_padded, int NF) {
+    constexpr int RPB = 8, NFMAX = 3 + 6 * MOFA_MAX_PE_FREQS;
+    __shared__ float pe[RPB][NFMAX + 1];
     const long long r0 = (long long)blockIdx.x * RPB;
     for (int t = threadIdx.x; t < RPB * NF; t += 256) {
         const int rr = t / NF, k = t - rr * NF;
@@ -95,6 +95,16 @@ __global__ __launch_bounds__(256) void k_fold_bias(const float* __restrict__ w, 
         acc += bias[n];
     }
     out[n] = acc;
+}
+
+// ---- mask-only tape, generic writer: bits of (y > 0) for a whole panel buffer (layers whose epilogue is not the contiguous-store
+// one: the first layer, the per-ray-bias view layer, narrow / short-K launches).  One wavefront per KiB block, see mask_store_block.
+__global__ __launch_bounds__(256) void k_mask_pack(const float* __restrict__ y, long long n_blocks, unsigned long long* __restrict__ bits) {
+    const int lane = threadIdx.x & 63;
+    for (long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); b < n_blocks; b += (long long)gridDim.x * 4) {
+        const f32x4 v = *(const f32x4*)(y + b * 256 + lane * 4);
+        mask_store_block(bits, b * 256, lane, v);
+    }
 }
 
 // ---- weight / activation repacking -------------------------------------------------------------
@@ -180,6 +190,7 @@ struct FusedLayer {
     long long x1_off, x2_off, y_off;  // float offsets into the activation arena; x1_off < 0: layer 0 (positional encoding)
     long long w_off;                  // into the packed weights
     long long bias_off;               // into `folded` (bias_row_div == 0) or into `view_bias_rows`
+    long long mask_off;               // mask-only tape: 64-bit word offset of this layer's bits (MASKW kernels only)
     int k1p, k2p, n_padded, bias_row_div;
 };
 
@@ -196,9 +207,12 @@ struct FusedArgs {
     long long z_row_stride, n_points, m_padded, bias_rows;
     int S, n_layers, m_tiles;
     int pipe;             // 1: full 256-feature blocks use kloop_pipelined (MOFA_PIPE != 0)
+    int pe_feats;         // 3 + 6 * multires
+    unsigned long long* mask_bits;   // mask-only tape (MASKW) or NULL
     FusedLayer L[kMaxFusedLayers];
 };
 
+template <bool MASKW>      // MASKW: also leave (y > 0) of every layer as bits (fitting's mask-only tape); the inference kernel is MASKW = false
 __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // 4 waves side by side over the (<= 256) features, each 64 features x 128 points (8 accumulators of 32x32): a workgroup
@@ -248,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
                     const int swz = (row >> 2) & 3;
 #pragma unroll 1
                     for (int kk = k0; kk < k0 + 8; ++kk) {
-                        const float v = pe_feature(kt * 16 + kk, px, py, pz, 3 + 6 * MOFA_PE_POINT_FREQS);
+                        const float v = pe_feature(kt * 16 + kk, px, py, pz, a.pe_feats);
                         xs[row * 16 + ((((kk >> 2) & 3) ^ swz) << 2) + (kk & 3)] = v;
                     }
                 } else {
@@ -295,7 +309,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
                     store_tile<NI, NJ, true>(acc, a.view_bias_rows + l.bias_off, a.bias_rows, l.bias_row_div, np, y, a.m_padded, m0,
                                                     nbase + wn * 64, 1, lane, bv);
                 else      // both loops end with a workgroup barrier: stage 0 is free, 4 KiB of it per wave
-                    store_tile_staged<NI, NJ, true>(acc, a.folded + l.bias_off, y, a.m_padded, m0, nbase + wn * 64, lane, smem + wn * 1024);
+                    store_tile_staged<NI, NJ, true, MASKW>(acc, a.folded + l.bias_off, y, a.m_padded, m0, nbase + wn * 64, lane, smem + wn * 1024,
+                                                           MASKW ? a.mask_bits + l.mask_off : nullptr);
             }
             // Another feature block of this layer follows (layers wider than 256): its first LDS-DMA requests land in stage 0, where the
             // staged epilogue's wave-private windows live — a faster wave must not overwrite a window its neighbour is still reading.
@@ -313,7 +328,8 @@ int launch_fused(const FusedArgs& a, hipStream_t st) {
     const int half_tiles = a.m_tiles * 2;
     const int grid = half_tiles < 2 * cus ? half_tiles : 2 * cus;      // two resident workgroups per CU
     const size_t lds = 2 * (size_t)(128 + 256) * 16 * sizeof(float);   // 48 KiB
-    hipLaunchKernelGGL(k_mlp_fused, dim3(grid), dim3(256), lds, st, a);
+    if (a.mask_bits) hipLaunchKernelGGL(k_mlp_fused<true>, dim3(grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(k_mlp_fused<false>, dim3(grid), dim3(256), lds, st, a);
     return check_launch("k_mlp_fused");
 }
 
@@ -358,6 +374,14 @@ inline void prof_close(hipStream_t st, int kind, double flops) {
 // One Linear(+bias+ReLU) / backward-data launch.  Which instantiation runs is decided by the shape alone (plus MOFA_PIPE=0, which
 // selects the plain K loop — bit-identical, kept as the reference form of the loop): 128-feature tile when the width allows it,
 // the software-pipelined K loop for an even number of panels >= 4, the per-ray-bias instantiation for the view layer.
+int launch_mask_pack(const float* y, long long n_floats, unsigned long long* bits, hipStream_t st) {
+    const long long blocks = n_floats / 256;                 // panel buffers are multiples of 256 rows x 16 floats
+    long long grid = (blocks + 3) / 4;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_mask_pack, dim3((unsigned)grid), dim3(256), 0, st, y, blocks, bits);
+    return check_launch("k_mask_pack");
+}
+
 template <int BN, bool L0, bool BWD = false>
 int launch_layer(LayerArgs a, hipStream_t st) {
     a.n_tiles = a.n_padded / BN;
@@ -397,6 +421,11 @@ int launch_layer(LayerArgs a, hipStream_t st) {
         }
     }
     if (prof) prof_close(st, pkind, 2.0 * (double)a.m_padded * (double)a.n_padded * 16.0 * (double)(a.k1p + a.k2p));
+    if (!BWD && a.mask_out && !(pipe && !a.bias_row_div)) {   // every epilogue but the contiguous-store one: bits from a pass over y
+        const int rc = check_launch("k_layer");
+        if (rc != MOFA_OK) return rc;
+        return launch_mask_pack(a.y, a.m_padded * a.n_padded, a.mask_out, st);
+    }
     return check_launch(BWD ? "k_layer<BWD>" : (L0 ? "k_layer<L0>" : "k_layer"));
 }
 
@@ -457,6 +486,12 @@ int mofa_from_panels(const float* src, int64_t rows_padded, int64_t rows, int32_
 int mofa_layer_forward(const float* x1, int32_t k1, const float* x2, int32_t k2, const float* w_packed,
                        const float* bias, int32_t bias_row_div, int64_t bias_rows, float* y, int64_t m_padded,
                        int32_t n_padded, int32_t relu, void* stream) {
+    return mofa_layer_forward_masked(x1, k1, x2, k2, w_packed, bias, bias_row_div, bias_rows, y, m_padded, n_padded, relu, nullptr, stream);
+}
+
+int mofa_layer_forward_masked(const float* x1, int32_t k1, const float* x2, int32_t k2, const float* w_packed,
+                              const float* bias, int32_t bias_row_div, int64_t bias_rows, float* y, int64_t m_padded,
+                              int32_t n_padded, int32_t relu, uint64_t* mask_bits_out, void* stream) {
     MOFA_REQUIRE(x1 && w_packed && bias && y, "layer_forward: null pointer");
     MOFA_REQUIRE(k1 > 0 && k1 % 16 == 0 && k2 >= 0 && k2 % 16 == 0 && (k2 == 0 || x2),
                  "layer_forward: k1=%d k2=%d must be multiples of 16 (x2 required when k2>0)", k1, k2);
@@ -465,17 +500,30 @@ int mofa_layer_forward(const float* x1, int32_t k1, const float* x2, int32_t k2,
     a.x1 = x1, a.x2 = x2, a.w = w_packed, a.bias = bias, a.y = y;
     a.k1p = k1 / 16, a.k2p = k2 / 16, a.n_padded = n_padded, a.m_padded = m_padded;
     a.bias_row_div = bias_row_div, a.bias_rows = bias_rows, a.relu = relu;
+    MOFA_REQUIRE(!mask_bits_out || relu, "layer_forward: a mask tape records the ReLU of the layer (relu must be 1)");
+    a.mask_out = (unsigned long long*)mask_bits_out;
     return dispatch_layer(a, false, (hipStream_t)stream);
 }
 
 /* dX = G @ W (optionally += and * ReLU mask): g panels [n_padded_fwd/16][Mp][16], wt_packed = transposed pack
  * (rows = forward input features padded to k_out_padded, contraction = g_k), dx panels [k_out_padded/16][Mp][16]. */
+static int layer_backward_data(const float* g, int32_t g_k, const float* wt_packed, const float* mask, const uint64_t* mask_bits,
+                               int32_t accumulate, float* dx, int64_t m_padded, int32_t k_out_padded, void* stream);
 int mofa_layer_backward_data(const float* g, int32_t g_k, const float* wt_packed, const float* mask, int32_t accumulate,
                              float* dx, int64_t m_padded, int32_t k_out_padded, void* stream) {
+    return layer_backward_data(g, g_k, wt_packed, mask, nullptr, accumulate, dx, m_padded, k_out_padded, stream);
+}
+int mofa_layer_backward_data_bits(const float* g, int32_t g_k, const float* wt_packed, const uint64_t* mask_bits, int32_t accumulate,
+                                  float* dx, int64_t m_padded, int32_t k_out_padded, void* stream) {
+    MOFA_REQUIRE(mask_bits, "layer_backward_data_bits: null mask");
+    return layer_backward_data(g, g_k, wt_packed, nullptr, mask_bits, accumulate, dx, m_padded, k_out_padded, stream);
+}
+static int layer_backward_data(const float* g, int32_t g_k, const float* wt_packed, const float* mask, const uint64_t* mask_bits,
+                               int32_t accumulate, float* dx, int64_t m_padded, int32_t k_out_padded, void* stream) {
     MOFA_REQUIRE(g && wt_packed && dx, "layer_backward_data: null pointer");
     MOFA_REQUIRE(g_k > 0 && g_k % 16 == 0, "layer_backward_data: g_k=%d must be a positive multiple of 16", g_k);
     LayerArgs a{};
-    a.x1 = g, a.w = wt_packed, a.y = dx, a.mask = mask, a.accumulate = accumulate;
+    a.x1 = g, a.w = wt_packed, a.y = dx, a.mask = mask, a.mask_bits = (const unsigned long long*)mask_bits, a.accumulate = accumulate;
     a.k1p = g_k / 16, a.k2p = 0, a.n_padded = k_out_padded, a.m_padded = m_padded;
     return dispatch_layer_bwd(a, (hipStream_t)stream);
 }
@@ -492,30 +540,38 @@ int mofa_pack_panels_t(const float* w, int32_t n_out, int32_t ld, int32_t col0, 
     return check_launch("k_pack_panels_t");
 }
 
+int mofa_pe_k_padded(int32_t n_freqs) {
+    return (n_freqs >= 0 && n_freqs <= MOFA_MAX_PE_FREQS) ? (int)round_up(3 + 6 * n_freqs, 64) : MOFA_EINVAL;
+}
+
 int mofa_layer0_forward(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
-                        const float* pts, int64_t n_points, int32_t S, const float* w_packed, const float* bias,
-                        float* y, int64_t m_padded, int32_t n_padded, void* stream) {
+                        const float* pts, int64_t n_points, int32_t S, int32_t n_freqs, const float* w_packed, const float* bias,
+                        float* y, int64_t m_padded, int32_t n_padded, uint64_t* mask_bits_out, void* stream) {
     MOFA_REQUIRE(w_packed && bias && y, "layer0_forward: null pointer");
+    MOFA_REQUIRE(n_freqs >= 0 && n_freqs <= MOFA_MAX_PE_FREQS, "layer0_forward: n_freqs=%d out of [0, %d]", n_freqs, MOFA_MAX_PE_FREQS);
     MOFA_REQUIRE(pts || (rays_o && rays_d && z && S > 0), "layer0_forward: need pts or (rays_o, rays_d, z, S)");
     MOFA_REQUIRE(n_points > 0 && n_points <= m_padded, "layer0_forward: n_points=%lld m_padded=%lld",
                  (long long)n_points, (long long)m_padded);
     LayerArgs a{};
     a.w = w_packed, a.bias = bias, a.y = y, a.rays_o = rays_o, a.rays_d = rays_d, a.z = z, a.pts = pts;
     a.z_row_stride = z_row_stride, a.n_points = n_points, a.S = S > 0 ? S : 1;
-    a.k1p = 4, a.k2p = 0, a.n_padded = n_padded, a.m_padded = m_padded, a.relu = 1;
+    a.pe_feats = 3 + 6 * n_freqs, a.k1p = mofa_pe_k_padded(n_freqs) / 16;
+    a.k2p = 0, a.n_padded = n_padded, a.m_padded = m_padded, a.relu = 1, a.mask_out = (unsigned long long*)mask_bits_out;
     return dispatch_layer(a, true, (hipStream_t)stream);
 }
 
 int mofa_layer0_forward_cam(int32_t img_w, float fx, float fy, float cx, float cy, const float* c2w, const int32_t* pixels,
-                            int64_t pix0, const float* z, int64_t z_row_stride, int64_t n_points, int32_t S,
+                            int64_t pix0, const float* z, int64_t z_row_stride, int64_t n_points, int32_t S, int32_t n_freqs,
                             const float* w_packed, const float* bias, float* y, int64_t m_padded, int32_t n_padded, void* stream) {
     MOFA_REQUIRE(c2w && z && w_packed && bias && y && img_w > 0 && S > 0, "layer0_forward_cam: bad arguments");
+    MOFA_REQUIRE(n_freqs >= 0 && n_freqs <= MOFA_MAX_PE_FREQS, "layer0_forward_cam: n_freqs=%d out of [0, %d]", n_freqs, MOFA_MAX_PE_FREQS);
     MOFA_REQUIRE(n_points > 0 && n_points <= m_padded, "layer0_forward_cam: n_points=%lld m_padded=%lld", (long long)n_points,
                  (long long)m_padded);
     LayerArgs a{};
     a.w = w_packed, a.bias = bias, a.y = y, a.z = z, a.z_row_stride = z_row_stride, a.n_points = n_points, a.S = S;
     a.cam_c2w = c2w, a.cam_pix = (const int*)pixels, a.cam_pix0 = pix0, a.fx = fx, a.fy = fy, a.cx = cx, a.cy = cy, a.cam_w = img_w;
-    a.k1p = 4, a.k2p = 0, a.n_padded = n_padded, a.m_padded = m_padded, a.relu = 1;
+    a.pe_feats = 3 + 6 * n_freqs, a.k1p = mofa_pe_k_padded(n_freqs) / 16;
+    a.k2p = 0, a.n_padded = n_padded, a.m_padded = m_padded, a.relu = 1;
     return dispatch_layer(a, true, (hipStream_t)stream);
 }
 
@@ -530,16 +586,17 @@ int mofa_head_forward(const float* x, int32_t k_padded, int64_t m_padded, const 
     return check_launch("k_head");
 }
 
-int mofa_view_bias(const float* viewdirs, int64_t n_rays, const float* w, int32_t n_out, int32_t ld,
+int mofa_view_bias(const float* viewdirs, int64_t n_rays, int32_t n_freqs, const float* w, int32_t n_out, int32_t ld,
                    const float* bias, float* out, int32_t n_padded, void* stream) {
     MOFA_REQUIRE(viewdirs && w && bias && out && n_rays > 0 && n_padded >= n_out, "view_bias: bad arguments");
+    MOFA_REQUIRE(n_freqs >= 0 && n_freqs <= MOFA_MAX_PE_FREQS && 3 + 6 * n_freqs <= ld, "view_bias: n_freqs=%d (ld=%d)", n_freqs, ld);
     hipLaunchKernelGGL(k_view_bias, dim3((unsigned)((n_rays + 7) / 8)), dim3(256), 0, (hipStream_t)stream, viewdirs,
-                       (long long)n_rays, w, n_out, ld, bias, out, n_padded);
+                       (long long)n_rays, w, n_out, ld, bias, out, n_padded, 3 + 6 * n_freqs);
     return check_launch("k_view_bias");
 }
 
 int mofa_positional_encode(const float* x, int64_t n, int32_t n_freqs, float* out, void* stream) {
-    MOFA_REQUIRE(x && out && n > 0 && n_freqs >= 0 && n_freqs <= 16, "positional_encode: bad arguments");
+    MOFA_REQUIRE(x && out && n > 0 && n_freqs >= 0 && n_freqs <= MOFA_MAX_PE_FREQS, "positional_encode: bad arguments");
     hipLaunchKernelGGL(k_positional_encode, dim3(blocks_for(n * (3 + 6 * n_freqs))), dim3(256), 0,
                        (hipStream_t)stream, x, (long long)n, n_freqs, out);
     return check_launch("k_positional_encode");
@@ -588,7 +645,8 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
                                 const float* z, long long z_row_stride, const float* pts, long long n_points, int S,
                                 long long m_padded, int n_layers, const long long* x1_off, const long long* x2_off,
                                 const long long* y_off, const long long* w_off, const long long* bias_off, const int* k1p,
-                                const int* k2p, const int* n_padded, const int* bias_row_div, void* stream) {
+                                const int* k2p, const int* n_padded, const int* bias_row_div, int pe_feats,
+                                unsigned long long* mask_bits, const long long* mask_off, void* stream) {
     MOFA_REQUIRE(n_layers > 0 && n_layers <= kMaxFusedLayers, "fused_forward: %d layers (max %d)", n_layers, kMaxFusedLayers);
     MOFA_REQUIRE(m_padded > 0 && m_padded % kRowTile == 0, "fused_forward: m_padded=%lld", m_padded);
     FusedArgs a{};
@@ -597,9 +655,10 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
     a.z_row_stride = z_row_stride, a.n_points = n_points, a.m_padded = m_padded, a.bias_rows = bias_rows;
     a.S = S > 0 ? S : 1, a.n_layers = n_layers, a.m_tiles = (int)(m_padded / kRowTile);
     a.pipe = config().pipe != 0 ? 1 : 0;
+    a.pe_feats = pe_feats, a.mask_bits = mask_bits;
     for (int i = 0; i < n_layers; ++i) {
         MOFA_REQUIRE(n_padded[i] > 0 && n_padded[i] % 64 == 0, "fused_forward: layer %d has n_padded=%d", i, n_padded[i]);
-        a.L[i] = FusedLayer{x1_off[i], x2_off[i], y_off[i], w_off[i], bias_off[i], k1p[i], k2p[i], n_padded[i], bias_row_div[i]};
+        a.L[i] = FusedLayer{x1_off[i], x2_off[i], y_off[i], w_off[i], bias_off[i], mask_bits ? mask_off[i] : 0, k1p[i], k2p[i], n_padded[i], bias_row_div[i]};
     }
     hipStream_t st = (hipStream_t)stream;
     if (!prof_enabled()) return launch_fused(a, st);
@@ -609,6 +668,11 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
     const int rc = launch_fused(a, st);
     prof_close(st, 1, flops);
     return rc;
+}
+
+// internal (used by mofa_net.hip): bits of (y > 0) for a panel buffer of n_floats (a multiple of 256) floats
+int mofa_internal_mask_pack(const float* y, long long n_floats, unsigned long long* bits, void* stream) {
+    return launch_mask_pack(y, n_floats, bits, (hipStream_t)stream);
 }
 
 // internal (used by mofa_net.hip)

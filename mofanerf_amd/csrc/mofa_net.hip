@@ -22,26 +22,9 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
                                 const float* z, long long z_row_stride, const float* pts, long long n_points, int S,
                                 long long m_padded, int n_layers, const long long* x1_off, const long long* x2_off,
                                 const long long* y_off, const long long* w_off, const long long* bias_off, const int* k1p,
-                                const int* k2p, const int* n_padded, const int* bias_row_div, void* stream);
-int mofa_layer_backward_data(const float* g, int32_t g_k, const float* wt_packed, const float* mask, int32_t accumulate,
-                             float* dx, int64_t m_padded, int32_t k_out_padded, void* stream);
-int mofa_pack_panels_t(const float* w, int32_t n_out, int32_t ld, int32_t col0, int32_t ncols, float* dst,
-                       int32_t rows_padded, int32_t k_padded, void* stream);
-int mofa_head_backward(const float* d_raw, int32_t raw_off, int32_t n_out, const float* w_dense, int32_t k_padded,
-                       const float* mask, int32_t accumulate, float* dx, int64_t m_padded, int64_t n_points, void* stream);
-int mofa_bias_grad(const float* g, int64_t m_padded, int64_t n_points, int32_t n_padded, float* out, void* stream);
-int mofa_bias_grad_rays(const float* g, int64_t m_padded, int64_t n_rays, int32_t S, int32_t n_padded, float* out,
-                        void* stream);
-int mofa_pe_backward(const float* dpe, int64_t m_padded, const float* rays_o, const float* rays_d, const float* z,
-                     int64_t z_row_stride, int64_t n_rays, int32_t S, float* d_rays_o, float* d_rays_d, void* stream);
-size_t mofa_weight_grad_workspace_floats(int64_t n_points, int32_t n_padded, int32_t k_padded);
-int mofa_weight_grad(const float* g, int32_t n_padded, const float* x, int32_t k_padded, int64_t m_padded,
-                     int64_t n_points, int32_t n_out, int32_t ncols, float* dst, int32_t ld, int32_t col0,
-                     float* bias_out, float* workspace, void* stream);
-int mofa_head_weight_grad(const float* d_raw, int32_t raw_off, int32_t n_out, const float* x, int32_t k_padded,
-                          int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, void* stream);
-int mofa_pe_panels(const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride, int64_t n_points,
-                   int32_t S, int64_t m_padded, float* out, void* stream);
+                                const int* k2p, const int* n_padded, const int* bias_row_div, int pe_feats,
+                                unsigned long long* mask_bits, const long long* mask_off, void* stream);
+int mofa_internal_mask_pack(const float* y, long long n_floats, unsigned long long* bits, void* stream);
 int mofa_internal_head_weight_grad_split(const float* d_raw, int32_t raw_off, int32_t n_out, const float* x, int32_t k_padded,
                                          int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, float* workspace,
                                          void* stream);
@@ -117,6 +100,7 @@ struct Layer {
 
 struct Plan {
     int D, W, Wp, Hp;
+    int pe_k;             // K of layer 0's operand panels: roundup(3 + 6 * multires, 64)
     std::vector<Layer> L;
     size_t packed_floats = 0, folded_floats = 0, packed_t_floats = 0, tape_cols = 0;
     // indices into L
@@ -128,7 +112,8 @@ Plan make_plan(MofaNetShape s) {
     p.D = s.D, p.W = s.W;
     const int W = s.W, Wp = (int)round_up(W, 64), Hp = (int)round_up(W / 2, 64);
     p.Wp = Wp, p.Hp = Hp;
-    const int PE = 3 + 6 * MOFA_PE_POINT_FREQS, PV = 3 + 6 * MOFA_PE_VIEW_FREQS;
+    const int PE = 3 + 6 * s.pe_point_freqs, PV = 3 + 6 * s.pe_view_freqs;
+    p.pe_k = (int)round_up(PE, 64);
     auto plain = [&](int n_out, int ld) {
         Layer l{};
         l.n_out = n_out, l.ld = ld, l.nsrc = 1, l.col0[0] = 0, l.ncols[0] = ld, l.fold = kNone;
@@ -137,8 +122,8 @@ Plan make_plan(MofaNetShape s) {
     };
     // xyzEncode: skipMLP(D=3, skip=None) -> Linear0..3 (models/model.py:97, :220-223)
     {
-        Layer l = plain(W, PE + MOFA_CH_EXP);
-        l.ncols[0] = PE, l.k_padded[0] = 64, l.fold = kExp, l.fold_col0 = PE, l.fold_cols = MOFA_CH_EXP;
+        Layer l = plain(W, PE + s.ch_exp);
+        l.ncols[0] = PE, l.k_padded[0] = p.pe_k, l.fold = kExp, l.fold_col0 = PE, l.fold_cols = s.ch_exp;
         p.xyz0 = (int)p.L.size();
         p.L.push_back(l);
         for (int i = 1; i < 4; ++i) p.L.push_back(plain(W, W));
@@ -156,8 +141,8 @@ Plan make_plan(MofaNetShape s) {
         p.L.push_back(ls);
         for (int i = 1; i < s.D - 5; ++i) p.L.push_back(plain(W, W));
     };
-    cond_stack(MOFA_CH_SHAPE, kShape, p.bim0, p.bim_skip);
-    cond_stack(MOFA_CH_TEX, kTex, p.uv0, p.uv_skip);
+    cond_stack(s.ch_shape, kShape, p.bim0, p.bim_skip);
+    cond_stack(s.ch_tex, kTex, p.uv0, p.uv_skip);
     {
         Layer l = plain(W / 2, PV + W);
         l.col0[0] = PV, l.ncols[0] = W, l.k_padded[0] = Wp, l.fold = kView, l.fold_col0 = 0, l.fold_cols = PV;
@@ -193,7 +178,13 @@ Plan make_plan(MofaNetShape s) {
     return p;
 }
 
-bool shape_ok(MofaNetShape s) { return s.D >= 6 && s.D <= 64 && s.W >= 2 && s.W <= 8192 && s.W % 2 == 0; }
+bool shape_ok(MofaNetShape s) {
+    return s.D >= 6 && s.D <= 64 && s.W >= 2 && s.W <= 8192 && s.W % 2 == 0 && s.pe_point_freqs >= 0 && s.pe_point_freqs <= MOFA_MAX_PE_FREQS &&
+           s.pe_view_freqs >= 0 && s.pe_view_freqs <= MOFA_MAX_PE_FREQS && s.ch_exp >= 0 && s.ch_exp <= MOFA_MAX_CODE && s.ch_shape >= 0 &&
+           s.ch_shape <= MOFA_MAX_CODE && s.ch_tex >= 0 && s.ch_tex <= MOFA_MAX_CODE;
+}
+#define MOFA_SHAPE_FMT "D=%d W=%d multires=%d multires_views=%d ch_exp=%d ch_shape=%d ch_tex=%d"
+#define MOFA_SHAPE_ARGS(s) (s).D, (s).W, (s).pe_point_freqs, (s).pe_view_freqs, (s).ch_exp, (s).ch_shape, (s).ch_tex
 
 }  // namespace
 }  // namespace mofa
@@ -213,6 +204,14 @@ int mofa_config_reload(void) {
 const char* mofa_last_error(void) { return g_err; }
 
 int mofa_net_num_layers(MofaNetShape s) { return shape_ok(s) ? 2 * s.D + 7 : MOFA_EINVAL; }
+
+int mofa_net_layer_dims(MofaNetShape s, int32_t li, int32_t* n_out, int32_t* n_in) {
+    MOFA_REQUIRE(shape_ok(s), "net_layer_dims: unsupported shape " MOFA_SHAPE_FMT, MOFA_SHAPE_ARGS(s));
+    MOFA_REQUIRE(n_out && n_in && li >= 0 && li < 2 * s.D + 7, "net_layer_dims: layer %d of %d", li, 2 * s.D + 7);
+    const Plan p = make_plan(s);
+    *n_out = p.L[li].n_out, *n_in = p.L[li].ld;
+    return MOFA_OK;
+}
 size_t mofa_net_packed_floats(MofaNetShape s) { return shape_ok(s) ? make_plan(s).packed_floats : 0; }
 size_t mofa_net_folded_floats(MofaNetShape s) { return shape_ok(s) ? make_plan(s).folded_floats : 0; }
 
@@ -224,7 +223,7 @@ size_t mofa_net_workspace_floats(MofaNetShape s, int64_t n_points, int64_t n_ray
 }
 
 int mofa_net_pack(MofaNetShape s, const float* const* weights, float* packed, void* stream) {
-    MOFA_REQUIRE(shape_ok(s), "net_pack: unsupported shape D=%d W=%d", s.D, s.W);
+    MOFA_REQUIRE(shape_ok(s), "net_pack: unsupported shape " MOFA_SHAPE_FMT, MOFA_SHAPE_ARGS(s));
     MOFA_REQUIRE(weights && packed, "net_pack: null pointer");
     const Plan p = make_plan(s);
     for (size_t li = 0; li < p.L.size(); ++li) {
@@ -248,8 +247,9 @@ int mofa_net_pack(MofaNetShape s, const float* const* weights, float* packed, vo
 
 int mofa_net_fold(MofaNetShape s, const float* const* weights, const float* const* biases, const float* exp_code,
                   const float* shape_code, const float* tex_code, float* folded, void* stream) {
-    MOFA_REQUIRE(shape_ok(s), "net_fold: unsupported shape D=%d W=%d", s.D, s.W);
-    MOFA_REQUIRE(weights && biases && exp_code && shape_code && tex_code && folded, "net_fold: null pointer");
+    MOFA_REQUIRE(shape_ok(s), "net_fold: unsupported shape " MOFA_SHAPE_FMT, MOFA_SHAPE_ARGS(s));
+    MOFA_REQUIRE(weights && biases && folded && (exp_code || !s.ch_exp) && (shape_code || !s.ch_shape) && (tex_code || !s.ch_tex),
+                 "net_fold: null pointer");
     const Plan p = make_plan(s);
     for (size_t li = 0; li < p.L.size(); ++li) {
         const Layer& l = p.L[li];
@@ -257,7 +257,7 @@ int mofa_net_fold(MofaNetShape s, const float* const* weights, const float* cons
         MOFA_REQUIRE(weights[li] && biases[li], "net_fold: layer %zu has a null weight/bias", li);
         const float* code = l.fold == kExp ? exp_code : l.fold == kShape ? shape_code : l.fold == kTex ? tex_code : nullptr;
         const int rc = mofa_internal_fold_bias(weights[li], l.n_out, l.ld, l.fold_col0, code ? l.fold_cols : 0,
-                                               code ? code : exp_code, biases[li], folded + l.folded_off, l.n_padded,
+                                               code ? code : biases[li], biases[li], folded + l.folded_off, l.n_padded,
                                                stream);
         if (rc != MOFA_OK) return rc;
     }
@@ -271,15 +271,20 @@ size_t mofa_net_tape_floats(MofaNetShape s, int64_t n_points) {
     return (size_t)round_up(n_points, kRowTile) * make_plan(s).tape_cols;
 }
 
+size_t mofa_net_mask_tape_words(MofaNetShape s, int64_t n_points) {
+    if (!shape_ok(s) || n_points <= 0) return 0;
+    return (size_t)round_up(n_points, kRowTile) * make_plan(s).tape_cols / 64;     // one bit per tape float, in 64-bit words
+}
+
 size_t mofa_net_backward_workspace_floats(MofaNetShape s, int64_t n_points) {
     if (!shape_ok(s) || n_points <= 0) return 0;
     const Plan p = make_plan(s);
-    return (size_t)round_up(n_points, kRowTile) * (4 * (size_t)p.Wp + 64) + 64 +
+    return (size_t)round_up(n_points, kRowTile) * (4 * (size_t)p.Wp + (size_t)p.pe_k) + 64 +
            mofa_weight_grad_workspace_floats(n_points, p.Wp, p.Wp) + 64;  // split-M partials of the largest dW block
 }
 
 int mofa_net_pack_t(MofaNetShape s, const float* const* weights, float* packed_t, void* stream) {
-    MOFA_REQUIRE(shape_ok(s), "net_pack_t: unsupported shape D=%d W=%d", s.D, s.W);
+    MOFA_REQUIRE(shape_ok(s), "net_pack_t: unsupported shape " MOFA_SHAPE_FMT, MOFA_SHAPE_ARGS(s));
     MOFA_REQUIRE(weights && packed_t, "net_pack_t: null pointer");
     const Plan p = make_plan(s);
     for (size_t li = 0; li < p.L.size(); ++li) {
@@ -301,9 +306,10 @@ int mofa_net_pack_t(MofaNetShape s, const float* const* weights, float* packed_t
 int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, const float* view_w,
                      const float* view_b, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
                      const float* pts, const float* viewdirs, int64_t n_rays, int32_t S, float* workspace,
-                     float* raw_out, float* tape, const float* view_bias_rows, void* stream) {
-    MOFA_REQUIRE(shape_ok(s), "net_forward: unsupported shape D=%d W=%d", s.D, s.W);
+                     float* raw_out, float* tape, uint64_t* mask_tape, const float* view_bias_rows, void* stream) {
+    MOFA_REQUIRE(shape_ok(s), "net_forward: unsupported shape " MOFA_SHAPE_FMT, MOFA_SHAPE_ARGS(s));
     MOFA_REQUIRE(packed && folded && workspace && raw_out, "net_forward: null pointer");
+    MOFA_REQUIRE(!(tape && mask_tape), "net_forward: give the fp32 tape OR the mask-only tape, not both");
     MOFA_REQUIRE(view_bias_rows || (view_w && view_b && viewdirs),
                  "net_forward: need view_bias_rows or (view_w, view_b, viewdirs)");
     MOFA_REQUIRE(n_rays > 0 && S > 0, "net_forward: n_rays=%lld S=%d", (long long)n_rays, S);
@@ -316,10 +322,14 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     float* t0 = workspace + 2 * act;
     float* t1 = workspace + 3 * act;
     float* vbias = workspace + 4 * act;  // [n_rays, Hp]
-    // with a tape every layer output is kept (fitting / training); otherwise 4 buffers are recycled
+    // with a tape every layer output is kept (training); otherwise 4 buffers are recycled — and with a mask-only tape (fitting)
+    // every layer additionally leaves (output > 0) as one bit per activation (mofa_layer.h, mask_store_block)
     auto slot = [&](int li, float* fallback) -> float* {
         return tape ? tape + (size_t)Mp * p.L[li].tape_cols : fallback;
     };
+    unsigned long long* const mbits = (unsigned long long*)mask_tape;
+    auto mword = [&](int li) -> long long { return (long long)((size_t)Mp * p.L[li].tape_cols / 64); };   // 4 words per 256 floats
+    auto mslot = [&](int li) -> uint64_t* { return mask_tape ? mask_tape + mword(li) : nullptr; };
     // ---- the MFMA layers in execution order: (layer, inputs, output) -------------------------------------------
     struct Step {
         int li;
@@ -364,7 +374,7 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     if (!view_bias_rows) {
         // per-ray bias b + W[:, :27] @ PE(viewdir) from the ORIGINAL (unpacked) view-layer tensors
         const Layer& l = p.L[p.view];
-        MOFA_TRY(mofa_view_bias(viewdirs, n_rays, view_w, l.n_out, l.ld, view_b, vbias, l.n_padded, stream));
+        MOFA_TRY(mofa_view_bias(viewdirs, n_rays, s.pe_view_freqs, view_w, l.n_out, l.ld, view_b, vbias, l.n_padded, stream));
         view_bias_rows = vbias;
     }
     // ---- dispatch: one persistent launch for widths <= 256 (every layer of a point tile lives in one workgroup), else
@@ -374,7 +384,7 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     if (fused) {
         const float* arena = tape ? tape : workspace;
         const int n = (int)steps.size();
-        std::vector<long long> x1(n), x2(n), yo(n), wo(n), bo(n);
+        std::vector<long long> x1(n), x2(n), yo(n), wo(n), bo(n), mo(n);
         std::vector<int> k1(n), k2(n), np(n), div(n);
         for (int i = 0; i < n; ++i) {
             const Layer& l = p.L[steps[i].li];
@@ -386,31 +396,38 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
             bo[i] = view ? 0 : (long long)l.folded_off;
             k1[i] = l.k_padded[0] / 16, k2[i] = steps[i].x2 ? l.k_padded[1] / 16 : 0;
             np[i] = l.n_padded, div[i] = view ? S : 0;
+            mo[i] = mword(steps[i].li);
         }
         MOFA_TRY(mofa_internal_fused_forward(arena, const_cast<float*>(arena), packed, folded, view_bias_rows, n_rays, rays_o,
                                              rays_d, z, z_row_stride, pts, M, S, Mp, n, x1.data(), x2.data(), yo.data(),
-                                             wo.data(), bo.data(), k1.data(), k2.data(), np.data(), div.data(), stream));
+                                             wo.data(), bo.data(), k1.data(), k2.data(), np.data(), div.data(), 3 + 6 * s.pe_point_freqs,
+                                             mbits, mo.data(), stream));
+        if (mask_tape) {  // the view layer's per-ray-bias epilogue is not the contiguous-store one: its bits come from a pass over its output
+            MOFA_TRY(mofa_internal_mask_pack(v, (long long)Mp * p.L[p.view].n_padded, mbits + mword(p.view), stream));
+        }
     } else {
         for (const Step& st : steps) {
             const Layer& l = p.L[st.li];
-            if (!st.x1 && !pts && l.n_padded % 128 == 0 && l.n_padded >= 512 && st.y != t1 && config().pipe != 0) {
-                // Wide first layer: the 63 encoding features of every point are computed ONCE into panels (t1 is free until layer 1
-                // writes it) and the layer runs as an ordinary K = 64 launch of the pipelined kernel.  The generated-operand kernel
+            if (!st.x1 && l.n_padded % 128 == 0 && l.n_padded >= 512 && st.y != t1 && config().pipe != 0) {
+                // Wide first layer: the encoding features of every point are computed ONCE into panels (t1 is free until layer 1
+                // writes it) and the layer runs as an ordinary K = pe_k launch of the pipelined kernel.  The generated-operand kernel
                 // (k_layer<.., L0>) re-derives them in each of the n_padded / 128 feature-tile workgroups of a point tile — 8 times
                 // at width 1024, which bounded that launch at 62 TFLOP/s (414 us per 196,608 points).  Same
-                // features (pe_feature's formula, separately rounded o + d z), same MFMA order, same epilogue: bit-identical.
-                MOFA_TRY(mofa_pe_panels(rays_o, rays_d, z, z_row_stride, M, S, Mp, t1, stream));
-                MOFA_TRY(mofa_layer_forward(t1, 64, nullptr, 0, packed + l.packed_off, folded + l.folded_off, 0, 1, st.y, Mp, l.n_padded,
-                                            1, stream));
+                // features (pe_feature's formula, separately rounded o + d z), same MFMA order, same epilogue: bit-identical for every
+                // point row (the padding rows m >= n_points hold relu(bias) here and a copy of the last point there; no consumer reads
+                // them: heads, compositing and every backward kernel stop at n_points).
+                MOFA_TRY(mofa_pe_panels(rays_o, rays_d, z, z_row_stride, pts, M, S, s.pe_point_freqs, Mp, t1, stream));
+                MOFA_TRY(mofa_layer_forward_masked(t1, l.k_padded[0], nullptr, 0, packed + l.packed_off, folded + l.folded_off, 0, 1, st.y, Mp,
+                                            l.n_padded, 1, mslot(st.li), stream));
             } else if (!st.x1) {
-                MOFA_TRY(mofa_layer0_forward(rays_o, rays_d, z, z_row_stride, pts, M, S, packed + l.packed_off,
-                                             folded + l.folded_off, st.y, Mp, l.n_padded, stream));
+                MOFA_TRY(mofa_layer0_forward(rays_o, rays_d, z, z_row_stride, pts, M, S, s.pe_point_freqs, packed + l.packed_off,
+                                             folded + l.folded_off, st.y, Mp, l.n_padded, mslot(st.li), stream));
             } else if (st.li == p.view) {
-                MOFA_TRY(mofa_layer_forward(st.x1, l.k_padded[0], nullptr, 0, packed + l.packed_off, view_bias_rows, S,
-                                            n_rays, st.y, Mp, l.n_padded, 1, stream));
+                MOFA_TRY(mofa_layer_forward_masked(st.x1, l.k_padded[0], nullptr, 0, packed + l.packed_off, view_bias_rows, S,
+                                            n_rays, st.y, Mp, l.n_padded, 1, mslot(st.li), stream));
             } else {
-                MOFA_TRY(mofa_layer_forward(st.x1, l.k_padded[0], st.x2, st.x2 ? l.k_padded[1] : 0, packed + l.packed_off,
-                                            folded + l.folded_off, 0, 1, st.y, Mp, l.n_padded, 1, stream));
+                MOFA_TRY(mofa_layer_forward_masked(st.x1, l.k_padded[0], st.x2, st.x2 ? l.k_padded[1] : 0, packed + l.packed_off,
+                                            folded + l.folded_off, 0, 1, st.y, Mp, l.n_padded, 1, mslot(st.li), stream));
             }
         }
     }
@@ -425,14 +442,16 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     return MOFA_OK;
 }
 
-int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t, const float* tape,
-                      const float* d_raw, const float* rays_o, const float* rays_d, const float* z,
-                      int64_t z_row_stride, int64_t n_rays, int32_t S, float* workspace, float* d_folded,
-                      float* d_view_bias_rows, float* d_rays_o, float* d_rays_d, float* const* d_weights, void* stream) {
-    MOFA_REQUIRE(shape_ok(s), "net_backward: unsupported shape D=%d W=%d", s.D, s.W);
-    MOFA_REQUIRE(packed && packed_t && tape && d_raw && rays_o && rays_d && z && workspace && d_folded &&
-                     d_view_bias_rows && d_rays_o && d_rays_d,
-                 "net_backward: null pointer");
+int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t, const float* tape, const uint64_t* mask_tape,
+                      const float* d_raw, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
+                      const float* pts, int64_t n_rays, int32_t S, float* workspace, float* d_folded,
+                      float* d_view_bias_rows, float* d_rays_o, float* d_rays_d, float* d_pts, float* const* d_weights, void* stream) {
+    MOFA_REQUIRE(shape_ok(s), "net_backward: unsupported shape " MOFA_SHAPE_FMT, MOFA_SHAPE_ARGS(s));
+    MOFA_REQUIRE(packed && packed_t && d_raw && workspace && d_folded && d_view_bias_rows, "net_backward: null pointer");
+    MOFA_REQUIRE((tape != nullptr) != (mask_tape != nullptr), "net_backward: need the fp32 tape OR the mask-only tape");
+    MOFA_REQUIRE(!(mask_tape && d_weights), "net_backward: weight gradients need the fp32 tape (the layer inputs), not the mask-only tape");
+    MOFA_REQUIRE(pts ? d_pts != nullptr : (rays_o && rays_d && z && d_rays_o && d_rays_d),
+                 "net_backward: need (pts, d_pts) or (rays_o, rays_d, z, d_rays_o, d_rays_d)");
     MOFA_REQUIRE(n_rays > 0 && S > 0, "net_backward: n_rays=%lld S=%d", (long long)n_rays, S);
     const Plan p = make_plan(s);
     const int64_t M = n_rays * S, Mp = round_up(M, kRowTile);
@@ -441,9 +460,18 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
     float* g1 = workspace + act;
     float* gS = workspace + 2 * act;   // accumulates d sigmaCodes
     float* gX = workspace + 3 * act;   // accumulates d xyz_code
-    float* dpe = workspace + 4 * act;  // [Mp, 64]
-    float* wws = dpe + (size_t)Mp * 64 + 64;  // split-M partial sums of the weight-gradient GEMM
-    auto T = [&](int li) -> const float* { return tape + (size_t)Mp * p.L[li].tape_cols; };
+    float* dpe = workspace + 4 * act;  // [Mp, pe_k]
+    float* wws = dpe + (size_t)Mp * p.pe_k + 64;  // split-M partial sums of the weight-gradient GEMM
+    // (output > 0) of layer li: the saved fp32 activation itself, or its bits in the mask-only tape — never both
+    struct Mask {
+        const float* act;
+        const uint64_t* bits;
+    };
+    const Mask kNoMask{nullptr, nullptr};
+    auto T = [&](int li) -> const float* { return tape ? tape + (size_t)Mp * p.L[li].tape_cols : nullptr; };
+    auto Mk = [&](int li) -> Mask {
+        return tape ? Mask{T(li), nullptr} : Mask{nullptr, mask_tape + (size_t)Mp * p.L[li].tape_cols / 64};
+    };
     int rc;
     // dW[li][:, col0[part] : +ncols[part]] = G^T X   (training only: d_weights != NULL; the constant columns are the host's)
     auto wgrad = [&](int li, int part, const float* g, const float* x) -> int {
@@ -462,10 +490,16 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
         return mofa_bias_grad(g, Mp, M, p.L[li].n_padded, d_folded + p.L[li].folded_off, stream);
     };
     // dX = G @ W[:, part]
-    auto bdata = [&](int li, int part, const float* g, const float* mask, int accumulate, float* dx) -> int {
+    auto bdata = [&](int li, int part, const float* g, Mask mask, int accumulate, float* dx) -> int {
         const Layer& l = p.L[li];
-        return mofa_layer_backward_data(g, l.n_padded, packed_t + l.packed_t_off[part], mask, accumulate, dx, Mp,
-                                        l.k_padded[part], stream);
+        if (mask.bits)
+            return mofa_layer_backward_data_bits(g, l.n_padded, packed_t + l.packed_t_off[part], mask.bits, accumulate, dx, Mp,
+                                                 l.k_padded[part], stream);
+        return mofa_layer_backward_data(g, l.n_padded, packed_t + l.packed_t_off[part], mask.act, accumulate, dx, Mp, l.k_padded[part], stream);
+    };
+    auto hbwd = [&](const float* dr, int off, int n, const float* w, int kp, Mask mask, int accumulate, float* dx) -> int {
+        if (mask.bits) return mofa_head_backward_bits(dr, off, n, w, kp, mask.bits, accumulate, dx, Mp, M, stream);
+        return mofa_head_backward(dr, off, n, w, kp, mask.act, accumulate, dx, Mp, M, stream);
     };
     const int n2 = s.D - 5;
     if (!d_weights && hipMemsetAsync(d_folded, 0, p.folded_floats * sizeof(float), (hipStream_t)stream) != hipSuccess)
@@ -476,7 +510,7 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
     // rgb head -> gradient at the view layer's output (masked by its ReLU); its per-ray sums are d(view bias rows)
     {
         const Layer& r = p.L[p.rgb];
-        MOFA_TRY(mofa_head_backward(d_raw, 0, 3, packed + r.packed_off, r.k_padded[0], T(p.view), 0, g0, Mp, M, stream));
+        MOFA_TRY(hbwd(d_raw, 0, 3, packed + r.packed_off, r.k_padded[0], Mk(p.view), 0, g0));
         MOFA_TRY(mofa_bias_grad_rays(g0, Mp, n_rays, S, p.L[p.view].n_padded, d_view_bias_rows, stream));
         if (d_weights) {
             MOFA_REQUIRE(d_weights[p.rgb] && d_weights[p.alpha], "net_backward: head d_weights are null");
@@ -489,29 +523,29 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
         MOFA_TRY(wgrad(p.view, 0, g0, T(p.uv_skip + n2 - 1)));
     }
     // view layer -> d rgbCodes, masked by the last uv layer's ReLU
-    MOFA_TRY(bdata(p.view, 0, g0, T(p.uv_skip + n2 - 1), 0, g1));
+    MOFA_TRY(bdata(p.view, 0, g0, Mk(p.uv_skip + n2 - 1), 0, g1));
     float *cur = g1, *spare = g0;
     // One conditioned stack, walked backwards.  `cur` = masked gradient at its output.  The gradient w.r.t. the stack's
     // input x has two contributions (the skip concat and linears1.Linear0): the first overwrites gx, the second
     // accumulates and applies `final_mask` (the ReLU of the layer that produced x) if given.
-    auto stack_bwd = [&](int first, int skip, const float* xin, float* gx, const float* final_mask) -> int {
+    auto stack_bwd = [&](int first, int skip, const float* xin, float* gx, Mask final_mask) -> int {
         const int last = skip + n2 - 1;
         for (int li = last; li > skip; --li) {
             MOFA_TRY(bgrad(li, cur));
             MOFA_TRY(wgrad(li, 0, cur, T(li - 1)));
-            MOFA_TRY(bdata(li, 0, cur, T(li - 1), 0, spare));
+            MOFA_TRY(bdata(li, 0, cur, Mk(li - 1), 0, spare));
             std::swap(cur, spare);
         }
         MOFA_TRY(bgrad(skip, cur));
         MOFA_TRY(wgrad(skip, 0, cur, xin));
         MOFA_TRY(wgrad(skip, 1, cur, T(skip - 1)));
-        MOFA_TRY(bdata(skip, 0, cur, nullptr, 0, gx));               // x part of [x | h]
-        MOFA_TRY(bdata(skip, 1, cur, T(skip - 1), 0, spare));        // h part, masked by linears1's last ReLU
+        MOFA_TRY(bdata(skip, 0, cur, kNoMask, 0, gx));               // x part of [x | h]
+        MOFA_TRY(bdata(skip, 1, cur, Mk(skip - 1), 0, spare));       // h part, masked by linears1's last ReLU
         std::swap(cur, spare);
         for (int li = skip - 1; li > first; --li) {
             MOFA_TRY(bgrad(li, cur));
             MOFA_TRY(wgrad(li, 0, cur, T(li - 1)));
-            MOFA_TRY(bdata(li, 0, cur, T(li - 1), 0, spare));
+            MOFA_TRY(bdata(li, 0, cur, Mk(li - 1), 0, spare));
             std::swap(cur, spare);
         }
         MOFA_TRY(bgrad(first, cur));
@@ -520,31 +554,34 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
         return MOFA_OK;
     };
     // uv stack (input sigmaCodes); the sigma head adds the third contribution and applies the bim stack's last ReLU
-    MOFA_TRY(stack_bwd(p.uv0, p.uv_skip, T(p.bim_skip + n2 - 1), gS, nullptr));
+    MOFA_TRY(stack_bwd(p.uv0, p.uv_skip, T(p.bim_skip + n2 - 1), gS, kNoMask));
     {
         const Layer& a = p.L[p.alpha];
-        MOFA_TRY(mofa_head_backward(d_raw, 3, 1, packed + a.packed_off, a.k_padded[0], T(p.bim_skip + n2 - 1), 1, gS, Mp,
-                                    M, stream));
+        MOFA_TRY(hbwd(d_raw, 3, 1, packed + a.packed_off, a.k_padded[0], Mk(p.bim_skip + n2 - 1), 1, gS));
     }
     // bim stack (input xyz_code)
     cur = gS, spare = g0;
-    MOFA_TRY(stack_bwd(p.bim0, p.bim_skip, T(p.xyz0 + 3), gX, T(p.xyz0 + 3)));
+    MOFA_TRY(stack_bwd(p.bim0, p.bim_skip, T(p.xyz0 + 3), gX, Mk(p.xyz0 + 3)));
     // xyzEncode Linear3..1, then Linear0 -> gradient w.r.t. the encoding features -> rays
     cur = gX, spare = g0;
     for (int li = p.xyz0 + 3; li > p.xyz0; --li) {
         MOFA_TRY(bgrad(li, cur));
         MOFA_TRY(wgrad(li, 0, cur, T(li - 1)));
-        MOFA_TRY(bdata(li, 0, cur, T(li - 1), 0, spare));
+        MOFA_TRY(bdata(li, 0, cur, Mk(li - 1), 0, spare));
         std::swap(cur, spare);
         if (spare == gX) spare = g1;
     }
     MOFA_TRY(bgrad(p.xyz0, cur));
     if (d_weights) {   // layer 0's input is the positional encoding itself: regenerate it as panels, then reuse the buffer
-        MOFA_TRY(mofa_pe_panels(rays_o, rays_d, z, z_row_stride, M, S, Mp, dpe, stream));
+        MOFA_TRY(mofa_pe_panels(rays_o, rays_d, z, z_row_stride, pts, M, S, s.pe_point_freqs, Mp, dpe, stream));
         MOFA_TRY(wgrad(p.xyz0, 0, cur, dpe));
     }
-    MOFA_TRY(bdata(p.xyz0, 0, cur, nullptr, 0, dpe));
-    MOFA_TRY(mofa_pe_backward(dpe, Mp, rays_o, rays_d, z, z_row_stride, n_rays, S, d_rays_o, d_rays_d, stream));
+    MOFA_TRY(bdata(p.xyz0, 0, cur, kNoMask, 0, dpe));
+    if (pts) {
+        MOFA_TRY(mofa_pe_backward_points(dpe, Mp, pts, M, s.pe_point_freqs, d_pts, stream));
+    } else {
+        MOFA_TRY(mofa_pe_backward(dpe, Mp, rays_o, rays_d, z, z_row_stride, n_rays, S, s.pe_point_freqs, d_rays_o, d_rays_d, stream));
+    }
     return MOFA_OK;
 }
 #undef MOFA_TRY

@@ -20,20 +20,53 @@ def unwrap(net):
     return net.module if isinstance(net, torch.nn.DataParallel) else net
 
 
+def _freqs_of(ch: int, what: str) -> int:
+    """Encoding width -> number of frequencies: 3 + 6 L (get_embedder, models/model.py:48-63; L = 0 is i_embed = -1)."""
+    if ch < 3 or (ch - 3) % 6:
+        raise lib.MofaError(f"{what} = {ch} is not a positional-encoding width 3 + 6*L (models/model.py:48-63)")
+    return (ch - 3) // 6
+
+
 class HipNet:
-    def __init__(self, net: NeRF, weak: bool = False):
-        """``weak``: keep only a weak reference to the module (the Linear children are still held) — for caches keyed weakly on the
+    def __init__(self, net: NeRF, point_freqs: int = 10, weak: bool = False):
+        """``point_freqs``: ``multires`` of the point encoding the renderer feeds this network (tools/config_parser.py:53).  The module
+        alone only knows ``input_ch = (3 + 6*multires) + input_ch_expCodes`` (tools/create_model_condition.py:25), so the split between
+        per-point encoding columns and per-call expression-code columns comes from the renderer's ``embed_fn``; every other width is
+        read off the module.  The resulting ``MofaNetShape`` is then checked against EVERY ``Linear`` of the module
+        (``mofa_net_layer_dims``) — a module the plan does not describe is refused here, never mis-read by a kernel.
+
+        ``weak``: keep only a weak reference to the module (the Linear children are still held) — for caches keyed weakly on the
         module itself (model._EMBEDDED_CACHE): a strong back-reference from the value would keep the key alive for ever."""
         if not isinstance(net, NeRF):
             raise lib.MofaError(f"expected mofanerf_amd.model.NeRF, got {type(net).__name__}")
         self._net_strong = None if weak else net
         self._net_weak = weakref.ref(net)
         self.D, self.W = int(net.D), int(net.W)
-        self.shape = lib.NetShape(net.D, net.W)
+        self.point_freqs = int(point_freqs)
+        self.ch_pe = 3 + 6 * self.point_freqs
+        self.ch_exp = int(net.input_ch) - self.ch_pe
+        if self.ch_exp < 0:
+            raise lib.MofaError(f"NeRF.input_ch = {net.input_ch} is narrower than the point encoding it is fed (multires = {point_freqs} "
+                                f"-> {self.ch_pe} columns); input_ch = (3 + 6*multires) + input_ch_expCodes (tools/create_model_condition.py:25)")
+        self.view_freqs = _freqs_of(int(net.input_ch_views), "NeRF.input_ch_views")
+        self.ch_views = 3 + 6 * self.view_freqs
+        self.ch_shape, self.ch_tex = int(net.input_ch_shapeCodes), int(net.input_ch_textureCodes)
+        self.shape = lib.NetShape(net.D, net.W, self.point_freqs, self.view_freqs, self.ch_exp, self.ch_shape, self.ch_tex)
         self._L = lib.load()
         self._linears = net.ordered_linears()
-        if self._L.mofa_net_num_layers(self.shape) != len(self._linears):
-            raise lib.MofaError("layer count mismatch between the module and the C ABI plan")
+        n_plan = self._L.mofa_net_num_layers(self.shape)
+        if n_plan < 0:
+            raise lib.MofaError(f"unsupported network shape {self.shape}: {self._L.mofa_last_error().decode()}")
+        if n_plan != len(self._linears):
+            raise lib.MofaError(f"layer count mismatch: the module has {len(self._linears)} Linear layers, the plan of {self.shape} has {n_plan}")
+        import ctypes as C
+        no, ni = C.c_int32(), C.c_int32()
+        for li, l in enumerate(self._linears):
+            lib.check(self._L.mofa_net_layer_dims(self.shape, li, C.byref(no), C.byref(ni)), "mofa_net_layer_dims")
+            if (l.out_features, l.in_features) != (no.value, ni.value):
+                raise lib.MofaError(f"layer {li} of the module is Linear({l.in_features} -> {l.out_features}) but {self.shape} has "
+                                    f"Linear({ni.value} -> {no.value}) there: the module was not built by NeRF(D, W, input_ch, ...) with "
+                                    "these widths (tools/create_model_condition.py:16-34); refusing to pack it")
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
         self._folded: Optional[torch.Tensor] = None
@@ -97,8 +130,8 @@ class HipNet:
         return self._bws
 
     def fold(self, exp_code: torch.Tensor, shape_code: torch.Tensor, tex_code: torch.Tensor) -> torch.Tensor:
-        """Per-call folded biases from the (already modulated) expression code [30], shape code [50] and
-        texture code [256]."""
+        """Per-call folded biases from the (already modulated) expression code [ch_exp], shape code [ch_shape] and
+        texture code [ch_tex]."""
         ws, bs = self._weights()
         n = self._L.mofa_net_folded_floats(self.shape)
         if self._folded is None or self._folded.device != ws[0].device:
@@ -106,11 +139,17 @@ class HipNet:
         e = exp_code.detach().reshape(-1).float().contiguous()
         s = shape_code.detach().reshape(-1).float().contiguous()
         t = tex_code.detach().reshape(-1).float().contiguous()
-        if e.numel() != 30 or s.numel() != 50 or t.numel() != 256:
-            raise lib.MofaError(f"code sizes must be 30/50/256, got {e.numel()}/{s.numel()}/{t.numel()}")
+        self.check_codes(e, s, t)
         lib.check(self._L.mofa_net_fold(self.shape, lib.ptr_array(ws), lib.ptr_array(bs), lib.ptr(e), lib.ptr(s),
                                         lib.ptr(t), lib.ptr(self._folded), lib.stream()), "mofa_net_fold")
         return self._folded
+
+    def check_codes(self, e, s, t) -> None:
+        """The widths the networks were BUILT for (the reference fails inside the first Linear on a mismatch, model.py:129-133)."""
+        got, want = (e.numel(), s.numel(), t.numel()), (self.ch_exp, self.ch_shape, self.ch_tex)
+        if got != want:
+            raise lib.MofaError(f"expression / shape / texture code widths {got} do not match the network's {want} "
+                                f"(input_ch - (3 + 6*multires), input_ch_shapeCodes, input_ch_textureCodes of {self.shape})")
 
     def workspace(self, n_points: int, n_rays: int, device, slot: int = 0) -> torch.Tensor:
         """Activation buffers of one sub-batch.  ``slot`` > 0: an independent buffer for a sub-batch that runs concurrently on
@@ -138,7 +177,8 @@ class HipNet:
         ws, bs = self._weights()
         dev = ws[0].device
         bim0, bim_skip, uv0, uv_skip, view = 4, 9, 4 + D, 9 + D, 4 + 2 * D
-        cond = {bim0: 50, bim_skip: 50, uv0: 256, uv_skip: 256}
+        cond = {bim0: self.ch_shape, bim_skip: self.ch_shape, uv0: self.ch_tex, uv_skip: self.ch_tex}
+        r16 = lambda v: (v + 15) // 16 * 16
         packed, biases = [], []
         for li, (w, b) in enumerate(zip(ws, bs)):
             n_out, ld = w.shape
@@ -151,12 +191,12 @@ class HipNet:
                 continue
             Np = Hp if li == view else Wp
             if li == 0:
-                parts = [(0, ld, 96)]
+                parts = [(0, ld, r16(ld))]
             elif li in cond:
-                c, cpad = cond[li], (cond[li] + 15) // 16 * 16
-                parts = [(0, c, cpad), (c, W, Wp)] + ([(c + W, W, Wp)] if li in (bim_skip, uv_skip) else [])
+                c, cpad = cond[li], r16(cond[li])
+                parts = ([(0, c, cpad)] if c else []) + [(c, W, Wp)] + ([(c + W, W, Wp)] if li in (bim_skip, uv_skip) else [])
             elif li == view:
-                parts = [(0, 27, 32), (27, W, Wp)]
+                parts = [(0, self.ch_views, r16(self.ch_views)), (self.ch_views, W, Wp)]
             else:
                 parts = [(0, ld, Wp)]
             buf = torch.zeros(Np * sum(p[2] for p in parts), dtype=torch.float32, device=dev)
@@ -173,7 +213,8 @@ class HipNet:
 
     def forward_embedded(self, pts93, bm50, views27, tex256) -> torch.Tensor:
         """``NeRF.forward(input_pts, input_bmCodes, input_views, input_uvCodes)`` (models/model.py:121-137) on per-point,
-        already-embedded inputs ``[n,93] [n,50] [n,27] [n,256] -> [n,4]`` — the call form of the reference's eager
+        already-embedded inputs ``[n,input_ch] [n,ch_shape] [n,input_ch_views] [n,ch_tex] -> [n,4]`` (93 / 50 / 27 / 256 at the shipped
+        configuration) — the call form of the reference's eager
         ``batchify`` (models/render_class.py:96-109).  Same MFMA layer kernel, weights packed without the constant folding
         (nothing is assumed constant here); the concatenations are free because a panel buffer IS a K-major concat: the
         producer of ``xyz`` / ``sigma`` / ``rgbCodes`` writes behind the code panels of one buffer.  Inference only."""
@@ -195,17 +236,26 @@ class HipNet:
             lib.check(L.mofa_layer_forward(lib.ptr(x1), k1, lib.ptr(x2) if x2 is not None else None, k2, lib.ptr(packed[li]),
                                            lib.ptr(biases[li]), 0, 1, lib.ptr(y), Mp, n_pad, 1, st), "mofa_layer_forward")
 
-        x93 = buf(96)
-        to_panels(pts93, 93, x93)
-        c_bm, c_tex, c_view = buf(64 + Wp), buf(256 + Wp), buf(32 + Wp)          # [code | producer output] concat buffers
-        to_panels(bm50, 50, c_bm)
-        to_panels(tex256, 256, c_tex)
-        to_panels(views27, 27, c_view)
+        r16 = lambda v_: (v_ + 15) // 16 * 16
+        ch_in, cs, ct, cv = int(pts93.shape[-1]), self.ch_shape, self.ch_tex, self.ch_views
+        if (ch_in, int(bm50.shape[-1]), int(views27.shape[-1]), int(tex256.shape[-1])) != (self.ch_pe + self.ch_exp, cs, cv, ct):
+            raise lib.MofaError(f"NeRF.forward: input widths {ch_in}/{bm50.shape[-1]}/{views27.shape[-1]}/{tex256.shape[-1]} do not match "
+                                f"the module's input_ch / input_ch_shapeCodes / input_ch_views / input_ch_textureCodes = "
+                                f"{self.ch_pe + self.ch_exp}/{cs}/{cv}/{ct}")
+        ks, kt_, kv = r16(cs), r16(ct), r16(cv)
+        x93 = buf(r16(ch_in))
+        to_panels(pts93, ch_in, x93)
+        c_bm, c_tex, c_view = buf(ks + Wp), buf(kt_ + Wp), buf(kv + Wp)          # [code | producer output] concat buffers
+        if cs:
+            to_panels(bm50, cs, c_bm)
+        if ct:
+            to_panels(tex256, ct, c_tex)
+        to_panels(views27, cv, c_view)
         t = [buf(Wp), buf(Wp)]
-        layer(0, x93, 96, None, 0, t[0], Wp)
+        layer(0, x93, r16(ch_in), None, 0, t[0], Wp)
         layer(1, t[0], Wp, None, 0, t[1], Wp)
         layer(2, t[1], Wp, None, 0, t[0], Wp)
-        layer(3, t[0], Wp, None, 0, c_bm[64 * Mp:], Wp)                          # xyz_code lands behind the shape-code panels
+        layer(3, t[0], Wp, None, 0, c_bm[ks * Mp:], Wp)                          # xyz_code lands behind the shape-code panels
 
         def stack(first, skip, cbuf, ck, out):
             layer(first, cbuf, ck + Wp, None, 0, t[0], Wp)
@@ -222,12 +272,12 @@ class HipNet:
                     layer(li, t[cur], Wp, None, 0, dst, Wp)
                 cur ^= 1
 
-        stack(bim0, bim_skip, c_bm, 64, c_tex[256 * Mp:])                        # sigmaCodes land behind the texture-code panels
-        stack(uv0, uv_skip, c_tex, 256, c_view[32 * Mp:])                        # rgbCodes land behind the view-encoding panels
+        stack(bim0, bim_skip, c_bm, ks, c_tex[kt_ * Mp:])                        # sigmaCodes land behind the texture-code panels
+        stack(uv0, uv_skip, c_tex, kt_, c_view[kv * Mp:])                        # rgbCodes land behind the view-encoding panels
         v = buf(Hp)
-        layer(view, c_view, 32 + Wp, None, 0, v, Hp)
+        layer(view, c_view, kv + Wp, None, 0, v, Hp)
         raw = torch.empty(n, 4, dtype=torch.float32, device=dev)
-        lib.check(L.mofa_head_forward(lib.ptr(c_tex[256 * Mp:]), Wp, Mp, lib.ptr(packed[view + 1]), lib.ptr(biases[view + 1]), 1,
+        lib.check(L.mofa_head_forward(lib.ptr(c_tex[kt_ * Mp:]), Wp, Mp, lib.ptr(packed[view + 1]), lib.ptr(biases[view + 1]), 1,
                                       lib.ptr(raw), 3, n, st), "mofa_head_forward(alpha)")
         lib.check(L.mofa_head_forward(lib.ptr(v), Hp, Mp, lib.ptr(packed[view + 2]), lib.ptr(biases[view + 2]), 3, lib.ptr(raw), 0, n,
                                       st), "mofa_head_forward(rgb)")
@@ -245,7 +295,7 @@ class HipNet:
                                            lib.ptr(view.weight.detach().contiguous()),
                                            lib.ptr(view.bias.detach().contiguous()), lib.ptr(rays_o), lib.ptr(rays_d),
                                            lib.ptr(z), z_row_stride, None, lib.ptr(viewdirs), R, S, lib.ptr(ws),
-                                           lib.ptr(raw_out), None, None, lib.stream()), "mofa_net_forward")
+                                           lib.ptr(raw_out), None, None, None, lib.stream()), "mofa_net_forward")
         return raw_out
 
     def forward_points(self, pts, viewdirs, S: int, raw_out: torch.Tensor, folded: Optional[torch.Tensor] = None):
@@ -257,6 +307,6 @@ class HipNet:
                                            lib.ptr(folded if folded is not None else self._folded),
                                            lib.ptr(view.weight.detach().contiguous()),
                                            lib.ptr(view.bias.detach().contiguous()), None, None, None, 0, lib.ptr(pts),
-                                           lib.ptr(viewdirs), R, S, lib.ptr(ws), lib.ptr(raw_out), None, None,
+                                           lib.ptr(viewdirs), R, S, lib.ptr(ws), lib.ptr(raw_out), None, None, None,
                                            lib.stream()), "mofa_net_forward")
         return raw_out

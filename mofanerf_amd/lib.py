@@ -19,8 +19,21 @@ _fp = C.c_void_p      # device pointers travel as integers
 _i32, _i64, _sz = C.c_int32, C.c_int64, C.c_size_t
 
 
+ABI_VERSION = 2
+
+
 class NetShape(C.Structure):
-    _fields_ = [("D", C.c_int32), ("W", C.c_int32)]
+    """``MofaNetShape``: depth / width plus the encoding and code widths the reference's flags fix (tools/config_parser.py:51-56,
+    113-118); the defaults are the shipped configuration (configs/exp_mofanerf.txt)."""
+    _fields_ = [("D", C.c_int32), ("W", C.c_int32), ("pe_point_freqs", C.c_int32), ("pe_view_freqs", C.c_int32),
+                ("ch_exp", C.c_int32), ("ch_shape", C.c_int32), ("ch_tex", C.c_int32)]
+
+    def __init__(self, D, W, pe_point_freqs=10, pe_view_freqs=4, ch_exp=30, ch_shape=50, ch_tex=256):
+        super().__init__(int(D), int(W), int(pe_point_freqs), int(pe_view_freqs), int(ch_exp), int(ch_shape), int(ch_tex))
+
+    def __repr__(self):
+        return (f"NetShape(D={self.D}, W={self.W}, multires={self.pe_point_freqs}, multires_views={self.pe_view_freqs}, "
+                f"ch_exp={self.ch_exp}, ch_shape={self.ch_shape}, ch_tex={self.ch_tex})")
 
 
 # name -> (restype, argtypes); mirrors include/mofanerf_hip.h one to one
@@ -29,29 +42,35 @@ SIGNATURES = {
     "mofa_last_error": (C.c_char_p, []),
     "mofa_config_reload": (C.c_int, []),
     "mofa_net_num_layers": (C.c_int, [NetShape]),
+    "mofa_net_layer_dims": (C.c_int, [NetShape, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
+    "mofa_pe_k_padded": (C.c_int, [_i32]),
     "mofa_net_packed_floats": (_sz, [NetShape]),
     "mofa_net_folded_floats": (_sz, [NetShape]),
     "mofa_net_workspace_floats": (_sz, [NetShape, _i64, _i64]),
     "mofa_net_pack": (C.c_int, [NetShape, C.POINTER(_fp), _fp, _fp]),
     "mofa_net_fold": (C.c_int, [NetShape, C.POINTER(_fp), C.POINTER(_fp), _fp, _fp, _fp, _fp, _fp]),
     "mofa_net_forward": (C.c_int, [NetShape, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _fp, _fp, _i64, _i32, _fp, _fp,
-                                   _fp, _fp, _fp]),
+                                   _fp, _fp, _fp, _fp]),
     "mofa_net_packed_t_floats": (_sz, [NetShape]),
     "mofa_net_tape_floats": (_sz, [NetShape, _i64]),
+    "mofa_net_mask_tape_words": (_sz, [NetShape, _i64]),
     "mofa_net_backward_workspace_floats": (_sz, [NetShape, _i64]),
     "mofa_net_pack_t": (C.c_int, [NetShape, C.POINTER(_fp), _fp, _fp]),
-    "mofa_net_backward": (C.c_int, [NetShape, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _i64, _i32, _fp, _fp, _fp, _fp,
-                                    _fp, C.POINTER(_fp), _fp]),
+    "mofa_net_backward": (C.c_int, [NetShape, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _fp, _i64, _i32, _fp, _fp, _fp, _fp,
+                                    _fp, _fp, C.POINTER(_fp), _fp]),
     "mofa_weight_grad_workspace_floats": (_sz, [_i64, _i32, _i32]),
     "mofa_weight_grad": (C.c_int, [_fp, _i32, _fp, _i32, _i64, _i64, _i32, _i32, _fp, _i32, _i32, _fp, _fp, _fp]),
     "mofa_head_weight_grad": (C.c_int, [_fp, _i32, _i32, _fp, _i32, _i64, _i64, _i32, _fp, _i32, _fp]),
-    "mofa_pe_panels": (C.c_int, [_fp, _fp, _fp, _i64, _i64, _i32, _i64, _fp, _fp]),
+    "mofa_pe_panels": (C.c_int, [_fp, _fp, _fp, _i64, _fp, _i64, _i32, _i32, _i64, _fp, _fp]),
     "mofa_pack_panels_t": (C.c_int, [_fp, _i32, _i32, _i32, _i32, _fp, _i32, _i32, _fp]),
     "mofa_layer_backward_data": (C.c_int, [_fp, _i32, _fp, _fp, _i32, _fp, _i64, _i32, _fp]),
+    "mofa_layer_backward_data_bits": (C.c_int, [_fp, _i32, _fp, _fp, _i32, _fp, _i64, _i32, _fp]),
     "mofa_head_backward": (C.c_int, [_fp, _i32, _i32, _fp, _i32, _fp, _i32, _fp, _i64, _i64, _fp]),
+    "mofa_head_backward_bits": (C.c_int, [_fp, _i32, _i32, _fp, _i32, _fp, _i32, _fp, _i64, _i64, _fp]),
     "mofa_bias_grad": (C.c_int, [_fp, _i64, _i64, _i32, _fp, _fp]),
     "mofa_bias_grad_rays": (C.c_int, [_fp, _i64, _i64, _i32, _i32, _fp, _fp]),
-    "mofa_pe_backward": (C.c_int, [_fp, _i64, _fp, _fp, _fp, _i64, _i64, _i32, _fp, _fp, _fp]),
+    "mofa_pe_backward": (C.c_int, [_fp, _i64, _fp, _fp, _fp, _i64, _i64, _i32, _i32, _fp, _fp, _fp]),
+    "mofa_pe_backward_points": (C.c_int, [_fp, _i64, _fp, _i64, _i32, _fp, _fp]),
     "mofa_composite_backward": (C.c_int, [_fp, _fp, _i64, _fp, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
                                           _fp]),
     "mofa_panel_floats": (_sz, [_i64, _i32]),
@@ -59,11 +78,12 @@ SIGNATURES = {
     "mofa_to_panels": (C.c_int, [_fp, _i64, _i32, _fp, _i64, _fp]),
     "mofa_from_panels": (C.c_int, [_fp, _i64, _i64, _i32, _fp, _fp]),
     "mofa_layer_forward": (C.c_int, [_fp, _i32, _fp, _i32, _fp, _fp, _i32, _i64, _fp, _i64, _i32, _i32, _fp]),
-    "mofa_layer0_forward": (C.c_int, [_fp, _fp, _fp, _i64, _fp, _i64, _i32, _fp, _fp, _fp, _i64, _i32, _fp]),
+    "mofa_layer_forward_masked": (C.c_int, [_fp, _i32, _fp, _i32, _fp, _fp, _i32, _i64, _fp, _i64, _i32, _i32, _fp, _fp]),
+    "mofa_layer0_forward": (C.c_int, [_fp, _fp, _fp, _i64, _fp, _i64, _i32, _i32, _fp, _fp, _fp, _i64, _i32, _fp, _fp]),
     "mofa_layer0_forward_cam": (C.c_int, [_i32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _i64, _fp, _i64, _i64, _i32,
-                                          _fp, _fp, _fp, _i64, _i32, _fp]),
+                                          _i32, _fp, _fp, _fp, _i64, _i32, _fp]),
     "mofa_head_forward": (C.c_int, [_fp, _i32, _i64, _fp, _fp, _i32, _fp, _i32, _i64, _fp]),
-    "mofa_view_bias": (C.c_int, [_fp, _i64, _fp, _i32, _i32, _fp, _fp, _i32, _fp]),
+    "mofa_view_bias": (C.c_int, [_fp, _i64, _i32, _fp, _i32, _i32, _fp, _fp, _i32, _fp]),
     "mofa_positional_encode": (C.c_int, [_fp, _i64, _i32, _fp, _fp]),
     "mofa_prof_begin": (C.c_int, []),
     "mofa_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -105,8 +125,8 @@ def load() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if lib.mofa_abi_version() != 1:
-            raise MofaError(f"ABI version mismatch: library {lib.mofa_abi_version()} != binding 1")
+        if lib.mofa_abi_version() != ABI_VERSION:
+            raise MofaError(f"ABI version mismatch: library {lib.mofa_abi_version()} != binding {ABI_VERSION}")
         _lib = lib
     return _lib
 

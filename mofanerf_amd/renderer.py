@@ -69,9 +69,12 @@ class Renderer(torch.nn.Module):
     def __init__(self, embed_fn=None, embeddirs_fn=None, netchunk=1024 * 64, uvCodesLen=256, expCodesLen=4,
                  input_ch=3, shapeCodes=50):
         super().__init__()
-        # embed_fn / embeddirs_fn are accepted for signature compatibility; the encoding is fused into the
-        # first-layer kernel (L=10 for points, L=4 for view directions: tools/config_parser.py defaults).
+        # embed_fn / embeddirs_fn (get_embedder's objects): the encoding itself is fused into the first-layer kernel; what the
+        # renderer takes from them is HOW MANY frequencies they encode (multires / multires_views, tools/config_parser.py:51-56),
+        # which it hands to the C plan.  None = the shipped 10 / 4.
         self.embed_fn, self.embeddirs_fn = embed_fn, embeddirs_fn
+        self.point_freqs = self._freqs(embed_fn, 10, "embed_fn")
+        self.view_freqs = self._freqs(embeddirs_fn, 4, "embeddirs_fn")
         self.netchunk = netchunk
         self.texEncoder = EnDeUVmap(uvCodesLen)
         self.lossList = ["loss_deformReg", "loss_kldiv", "loss_offsets"]
@@ -89,6 +92,9 @@ class Renderer(torch.nn.Module):
         # (run_fit.py never steps the networks); set fit_weight_grads=True to populate weight.grad there too
         self.fit_weight_grads = False
         self._weight_grads = False
+        # what a fitting step (no weight gradients) keeps for its backward: "mask" = one bit per activation (all it needs; 1/32 of the
+        # fp32 tape, bit-identical gradients), "fp32" = every layer output (the A/B arm; what a step WITH weight gradients always keeps)
+        self.fit_tape = os.environ.get("MOFA_FIT_TAPE", "mask")
         self._tex_cache = None
         self._cache: Dict[tuple, torch.Tensor] = {}
         # training / fitting memory: False (default) keeps every layer output of every sub-batch for the backward (nothing is
@@ -99,6 +105,21 @@ class Renderer(torch.nn.Module):
         self.n_streams = int(os.environ.get("MOFA_STREAMS", "1"))   # concurrent sub-batches of the inference path (render_rays)
         self._streams = {}
         self.png_sink = None      # optional mofanerf_amd.io.PngSink shared by consecutive render_path calls (bulk renders)
+
+    @staticmethod
+    def _freqs(fn, default, what):
+        """Number of encoding frequencies of a ``get_embedder`` result (models/model.py:48-63): ``Embedder.n_freqs``; ``nn.Identity``
+        (i_embed = -1) encodes nothing: 0; ``None``: the shipped default.  Any other callable is refused — the kernel generates the
+        encoding itself and would silently disagree with an encoder it cannot see into."""
+        if fn is None:
+            return default
+        if isinstance(fn, torch.nn.Identity):
+            return 0
+        n = getattr(fn, "n_freqs", None)
+        if n is None:
+            raise lib.MofaError(f"{what} must come from mofanerf_amd.embedder.get_embedder (or be None / nn.Identity): the positional "
+                                "encoding is generated inside the first-layer kernel from its frequency count")
+        return int(n)
 
     def _side_streams(self, n, dev):
         key = (str(dev), n)
@@ -146,8 +167,12 @@ class Renderer(torch.nn.Module):
     def _hip(self, net) -> HipNet:
         net = unwrap(net)
         h = self._hipnets.get(id(net))
-        if h is None or h.net is not net:
-            h = self._hipnets[id(net)] = HipNet(net)
+        if h is None or h.net is not net or h.point_freqs != self.point_freqs:
+            h = self._hipnets[id(net)] = HipNet(net, point_freqs=self.point_freqs)
+            if h.view_freqs != self.view_freqs:
+                raise lib.MofaError(f"NeRF.input_ch_views = {net.input_ch_views} (multires_views = {h.view_freqs}) but the renderer's "
+                                    f"embeddirs_fn encodes {self.view_freqs} frequencies (tools/create_model_condition.py:16-22 builds "
+                                    "both from args.multires_views)")
         return h
 
     def _device(self):
@@ -177,14 +202,26 @@ class Renderer(torch.nn.Module):
 
     # ------------------------------------------------------------------------------------------------
     def run_network(self, inputs, viewdirs, fn=None):
-        """``inputs [R,S,3]`` points, ``viewdirs [R,3]`` -> raw ``[R,S,4]`` (render_class.py:69-94)."""
+        """``inputs [R,S,3]`` points, ``viewdirs [R,3]`` -> raw ``[R,S,4]`` (render_class.py:69-94; also ``network_query_fn``,
+        tools/create_model_condition.py:50).  Under autograd it is differentiable like the reference's: gradients reach
+        ``inputs``, ``viewdirs``, the shape / texture / expression codes (through ``self.shapeCodes``, ``self.decoding_texCodes``,
+        ``self.expCodes_Sigma``) and, when ``self._weight_grads`` is set (``render()`` sets it; ``render_fitting()`` sets
+        ``fit_weight_grads``), the network weights — HIP backward (``mofa_net_backward`` with explicit points)."""
         if viewdirs is None:
             raise NotImplementedError(_NO_VIEWDIRS)
         R, S = int(inputs.shape[0]), int(inputs.shape[1])
         h = self._hip(fn)
         folded = self._fold_codes(fn, self.decoding_texCodes)
-        raw = torch.empty(R, S, 4, dtype=torch.float32, device=inputs.device)
         rays_per = max(1, int(self.netchunk) // S)
+        if torch.is_grad_enabled():
+            h.tape_recompute, h.force_fp32_tape = bool(self.tape_recompute), self.fit_tape == "fp32"
+            pts = inputs.reshape(-1, 3).float()
+            vb = view_bias_torch(h, viewdirs.float(), detach_params=not self._weight_grads)
+            wts = [l.weight for l in h._linears] if self._weight_grads else []
+            parts = [NetFn.apply(h, None, None, None, 0, S, folded, vb[i:i + rays_per], pts[i * S:(i + rays_per) * S], *wts)
+                     for i in range(0, R, rays_per)]
+            return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+        raw = torch.empty(R, S, 4, dtype=torch.float32, device=inputs.device)
         pts = inputs.detach().reshape(-1, 3).float().contiguous()
         vd = viewdirs.detach().float().contiguous()
         for i in range(0, R, rays_per):
@@ -302,11 +339,11 @@ class Renderer(torch.nn.Module):
             h = self._hip(net)
             rays_per = max(1, int(self.netchunk) // n_s)
             if grad:     # tape-keeping forward per sub-batch; the per-ray view bias is a differentiable torch expression
-                h.tape_recompute = bool(self.tape_recompute)
+                h.tape_recompute, h.force_fp32_tape = bool(self.tape_recompute), self.fit_tape == "fp32"
                 vb = view_bias_torch(h, vd, detach_params=not self._weight_grads)
                 wts = [l.weight for l in h._linears] if self._weight_grads else []
                 parts = [NetFn.apply(h, rays_o[i:i + rays_per], rays_d[i:i + rays_per],
-                                     zv[i:i + rays_per] if zs else zv, zs, n_s, folded, vb[i:i + rays_per], *wts)
+                                     zv[i:i + rays_per] if zs else zv, zs, n_s, folded, vb[i:i + rays_per], None, *wts)
                          for i in range(0, R, rays_per)]
                 return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
             raw = torch.empty(R, n_s, 4, dtype=torch.float32, device=dev)
@@ -381,8 +418,10 @@ class Renderer(torch.nn.Module):
         def gen(pose):
             n = int(H) * int(W)
             o, d, v = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(3))
-            pose_t = torch.as_tensor(np.asarray(pose.detach().cpu() if torch.is_tensor(pose) else pose),
-                                     dtype=torch.float32)[:3, :4].contiguous().to(dev)
+            if torch.is_tensor(pose):        # stays on the device when it is there already: no device->host->device hop, no host sync
+                pose_t = pose.detach()[:3, :4].to(device=dev, dtype=torch.float32).contiguous()
+            else:
+                pose_t = torch.as_tensor(np.asarray(pose), dtype=torch.float32)[:3, :4].contiguous().to(dev)
             lib.check(L.mofa_get_rays(int(H), int(W), _scalar(K[0][0]), _scalar(K[1][1]), _scalar(K[0][2]),
                                       _scalar(K[1][2]), lib.ptr(pose_t), 0, n, lib.ptr(o), lib.ptr(d), lib.ptr(v),
                                       lib.stream()), "mofa_get_rays")

@@ -40,8 +40,12 @@ def make_state(shapes: Dict[str, Tuple[int, ...]], seed: int = 0, tag: str = "")
     return out
 
 
-def nerf_state(D: int, W: int, seed: int = 0, tag: str = "nerf") -> Dict[str, torch.Tensor]:
-    return make_state(schema.linear_shapes(schema.nerf_layers(D, W)), seed, f"{tag}/{D}x{W}/")
+def nerf_state(D: int, W: int, seed: int = 0, tag: str = "nerf", **widths) -> Dict[str, torch.Tensor]:
+    """``widths``: ``ch_pts / ch_shape / ch_tex / ch_views`` of :func:`schema.nerf_layers` for networks built from non-shipped
+    flags (multires, multires_views, input_ch_*Codes); the shipped widths keep their round-1 key tags, so existing fixtures
+    regenerate byte for byte."""
+    suffix = "".join(f"{k}={v}/" for k, v in sorted(widths.items()))
+    return make_state(schema.linear_shapes(schema.nerf_layers(D, W, **widths)), seed, f"{tag}/{D}x{W}/{suffix}")
 
 
 def style_state(seed: int = 0) -> Dict[str, torch.Tensor]:

@@ -256,6 +256,7 @@ class OracleRenderer:
             if u is None:
                 u = torch.linspace(0.0, 1.0, steps=N_importance)
             zs = sample_pdf(zmid, (w0 if w0_perturb is None else w0 * w0_perturb)[..., 1:-1], u)
+            zs = zs.detach()                                   # render_class.py:326: no gradient through the resampling
             zf, _ = torch.sort(torch.cat([z, zs], -1), -1)
             pts = o[..., None, :] + d[..., None, :] * zf[..., :, None]
             raw1 = self.run_network(pts, vd, self.fine if self.fine is not None else self.coarse, shape_codes,

@@ -668,8 +668,89 @@ def g14_samplers():
     save("kat_samplers.npz", out)
 
 
+def g16_flags():
+    """Networks built from NON-SHIPPED flags (tools/config_parser.py:51-56,113-118; tools/create_model_condition.py:16-34).
+
+    ``kat_flags.npz`` — ``run_network``'s own arithmetic (embed_fn, cat the expression code, expand the codes, embeddirs_fn,
+    ``NeRF.forward``; models/render_class.py:69-94) on explicit points for three flag sets, with the reference's autograd gradients
+    of ``sum(raw * G)`` w.r.t. the points, the view directions and the three codes:
+      * ``parser``: the parser's own defaults the shipped config overrides — input_ch_shapeCodes=80, input_ch_expCodes=6
+        (multires=10, multires_views=4, texture 256).  (``myRenderer`` itself cannot run these two widths: its StyleModule is a fixed
+        50 -> 30 map, models/render_class.py:51, models/model.py:175 — so this level, below the StyleModule, is where they can be pinned.)
+      * ``low``: multires=6, multires_views=2, shape 80, exp 6, texture 256.
+      * ``noembed``: i_embed=-1 (nn.Identity: 3 raw coordinates for points and directions), shape 50, exp 30, texture 64.
+    ``flags_e2e.npz`` — the whole ``render_fitting`` path (StyleModule, coarse + fine, resampling, compositing) with multires=6,
+    multires_views=2, texture code 128 (shape 50 / exp 30 as the StyleModule fixes them), all intermediates, and the gradients of the
+    g4 loss w.r.t. the codes."""
+    out = {}
+    rng = np.random.default_rng(16)
+    for tag, mr, mv, i_embed, ce, cs, ct, D, W in (("parser", 10, 4, 0, 6, 80, 256, 8, 64), ("low", 6, 2, 0, 6, 80, 256, 10, 64),
+                                                   ("noembed", 10, 4, -1, 30, 50, 64, 8, 128)):
+        embed_fn, ch = get_embedder(mr, i_embed)
+        embeddirs_fn, chv = get_embedder(mv, i_embed)
+        net = NeRF(D=D, W=W, input_ch_shapeCodes=cs, input_ch_textureCodes=ct, input_ch=ch + ce, output_ch=5, skips=[4],
+                   input_ch_views=chv, use_viewdirs=True)
+        net.load_state_dict(synth.nerf_state(D, W, 16, "flags", ch_pts=ch + ce, ch_shape=cs, ch_tex=ct, ch_views=chv))
+        R, S = 9, 24
+        pts = torch.from_numpy(rng.uniform(-8, 8, (R, S, 3)).astype(np.float32)).requires_grad_(True)
+        vd = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=(R, 3)).astype(np.float32)), dim=-1).requires_grad_(True)
+        e = torch.from_numpy(rng.uniform(-1, 1, (1, ce)).astype(np.float32)).requires_grad_(True)
+        bm = torch.from_numpy(rng.normal(0, 0.05, (1, cs)).astype(np.float32)).requires_grad_(True)
+        tex = torch.from_numpy(rng.normal(0.2, 0.3, (1, ct)).astype(np.float32)).requires_grad_(True)
+        G = torch.from_numpy(rng.normal(size=(R, S, 4)).astype(np.float32))
+        n = R * S
+        flat = pts.reshape(-1, 3)
+        emb = torch.cat([embed_fn(flat), e.expand(n, -1)], -1)                                   # render_class.py:77-83
+        dirs = embeddirs_fn(vd[:, None].expand(pts.shape).reshape(-1, 3))                       # :88-90
+        raw = net(emb, bm.expand(n, -1), dirs, tex.expand(n, -1)).reshape(R, S, 4)              # :74,104 + model.py:121-137
+        (raw * G).sum().backward()
+        out.update({f"{tag}_flags": np.array([mr if i_embed != -1 else 0, mv if i_embed != -1 else 0, ce, cs, ct, D, W]),
+                    f"{tag}_pts": pts, f"{tag}_vd": vd, f"{tag}_e": e, f"{tag}_bm": bm, f"{tag}_tex": tex, f"{tag}_G": G, f"{tag}_raw": raw,
+                    f"{tag}_g_pts": pts.grad, f"{tag}_g_vd": vd.grad, f"{tag}_g_e": e.grad, f"{tag}_g_bm": bm.grad, f"{tag}_g_tex": tex.grad})
+        print(f"kat_flags {tag}: input_ch={ch + ce} views={chv} raw absmax {float(raw.abs().max()):.3f}")
+    save("kat_flags.npz", out)
+
+    # ---- end to end
+    mr, mv, ct = 6, 2, 128
+    embed_fn, ch = get_embedder(mr, 0)
+    embeddirs_fn, chv = get_embedder(mv, 0)
+    r = render_class.myRenderer(embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=4096, uvCodesLen=ct, expCodesLen=30)
+    r.idSpecificMod.load_state_dict(synth.style_state(0))
+    for dst, src in zip(r.expCodes_Sigma, synth.exp_sigma(0)):
+        dst.data[:] = src
+    r.eval()
+    nets = []
+    for D, W, tg in ((8, 64, "coarse"), (10, 64, "fine")):
+        m = NeRF(D=D, W=W, input_ch_shapeCodes=50, input_ch_textureCodes=ct, input_ch=ch + 30, output_ch=5, skips=[4],
+                 input_ch_views=chv, use_viewdirs=True)
+        m.load_state_dict(synth.nerf_state(D, W, 16, tg, ch_pts=ch + 30, ch_shape=50, ch_tex=ct, ch_views=chv))
+        nets.append(m.eval())
+    kw = kwargs_for(r, nets[0], nets[1])
+    bm, tex, exp = synth.codes(0)
+    tex = tex[:ct].clone()
+    bm, tex, exp = [t.clone().requires_grad_(True) for t in (bm, tex, exp)]
+    K16 = np.array([[37.5, 0, 8.0], [0, 37.5, 8.0], [0, 0, 1]])
+    c2w = pose_spherical(35.0, 0.0, 16.0)[:3, :4]
+    with Recorder() as rec:
+        rgb, disp, acc, ex = r.render_fitting(16, 16, K16, chunk=96, c2w=c2w, shapeCodes=bm, uvCodes=tex, expType=20, expCodes=exp,
+                                              retraw=True, **kw)
+    loss = (rgb - 0.5).abs().mean() + (ex["rgb0"] ** 2).mean()
+    loss.backward()
+    o = dict(c2w=c2w, K=K16, bm=bm, tex=tex, exp=exp, H=16, chunk=96, netchunk=4096, multires=mr, multires_views=mv, ch_tex=ct,
+             arch=np.array([8, 64, 10, 64]), seed=16, rgb=rgb, disp=disp, acc=acc, rgb0=ex["rgb0"], disp0=ex["disp0"], acc0=ex["acc0"],
+             z_std=ex["z_std"], loss=loss, g_bm=bm.grad, g_tex=tex.grad, g_exp=exp.grad)
+    nch = len(rec.spdf)
+    o["z_coarse"] = torch.cat([rec.r2o[2 * i]["z"] for i in range(nch)])
+    o["raw_coarse"] = torch.cat([rec.r2o[2 * i]["raw"] for i in range(nch)])
+    o["weights_coarse"] = torch.cat([rec.r2o[2 * i]["weights"] for i in range(nch)])
+    o["z_fine"] = torch.cat([rec.r2o[2 * i + 1]["z"] for i in range(nch)])
+    o["raw_fine"] = torch.cat([rec.r2o[2 * i + 1]["raw"] for i in range(nch)])
+    o["z_samples"] = torch.cat([s_["samples"] for s_ in rec.spdf])
+    save("flags_e2e.npz", o)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     for w in which:
         {"g1": g1_kats, "g2": g2_small, "g3": g3_true, "g4": g4_grads, "g5": g5_render_tex, "g6": g6_schema, "g7": g7_config1, "g8": g8_true_grads, "g9": g9_run_network_kat,
-         "g10": g10_checkpoint, "g11": g11_envelopes, "g12": g12_pose_grads, "g13": g13_ndc, "g14": g14_samplers, "g15": g15_long_rays}[w]()
+         "g10": g10_checkpoint, "g11": g11_envelopes, "g12": g12_pose_grads, "g13": g13_ndc, "g14": g14_samplers, "g15": g15_long_rays, "g16": g16_flags}[w]()

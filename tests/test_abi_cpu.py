@@ -44,7 +44,7 @@ def test_library_exports_nothing_but_the_declared_abi():
 
 def test_plan_sizes_and_argument_validation():
     L = lib.load()
-    assert L.mofa_abi_version() == 1
+    assert L.mofa_abi_version() == 2 == lib.ABI_VERSION
     for D, W in ((8, 256), (10, 1024), (8, 64)):
         s = lib.NetShape(D, W)
         assert L.mofa_net_num_layers(s) == 2 * D + 7 == len(schema.nerf_layers(D, W))
@@ -54,7 +54,10 @@ def test_plan_sizes_and_argument_validation():
         assert want <= L.mofa_net_packed_floats(s) <= want + 64 * (2 * D + 7)
         assert L.mofa_net_folded_floats(s) == (2 * D + 4) * Wp + 8
         assert L.mofa_net_workspace_floats(s, 1000, 10) == 4 * 1024 * Wp + 10 * Hp + 64
+        assert L.mofa_net_mask_tape_words(s, 1000) * 64 == L.mofa_net_tape_floats(s, 1000)      # one bit per tape float
     assert L.mofa_net_num_layers(lib.NetShape(3, 256)) == -1
+    assert L.mofa_net_num_layers(lib.NetShape(8, 256, pe_point_freqs=17)) == -1
+    assert L.mofa_net_num_layers(lib.NetShape(8, 256, ch_tex=-1)) == -1
     assert L.mofa_layer_forward(None, 16, None, 0, None, None, 0, 1, None, 256, 64, 1, None) == -1
     assert b"null pointer" in L.mofa_last_error()
     assert L.mofa_composite_forward(1, 1, 0, 1, None, 4, 1, 0, 1, 1, 1, 1, 1, None) == -1
@@ -62,6 +65,63 @@ def test_plan_sizes_and_argument_validation():
     assert L.mofa_sample_pdf_merge(1, 0, 1, 1, 0, 4, 5000, 5000, 1, 1, 1, None) == -1      # 3 S + Ni floats of LDS per ray: 64 KiB
     assert b"3 S + Ni" in L.mofa_last_error()
     assert L.mofa_composite_backward(1, 1, 0, 1, None, 4, 20000, 0, 1, None, None, None, None, 1, None, None) == -1
+    assert L.mofa_layer0_forward(1, 1, 1, 0, None, 4, 1, 99, 1, 1, 1, 256, 64, None, None) == -1
+    assert b"n_freqs" in L.mofa_last_error()
+    assert [L.mofa_pe_k_padded(f) for f in (0, 6, 10, 11, 16, 17)] == [64, 64, 64, 128, 128, -1]
+
+
+def test_plan_follows_every_reference_flag():
+    """MofaNetShape carries multires / multires_views / the three code widths (tools/config_parser.py:51-56,113-118): the layer shapes
+    the C plan assumes equal the reference module's for ANY setting (schema.nerf_layers restates models/model.py:80-114)."""
+    import ctypes as C
+    L = lib.load()
+    no, ni = C.c_int32(), C.c_int32()
+    for D, W, mr, mv, ce, cs, ct in ((8, 64, 6, 2, 6, 80, 256), (10, 128, 0, 0, 30, 50, 64), (8, 256, 16, 16, 0, 0, 0), (8, 256, 10, 4, 30, 50, 256)):
+        s = lib.NetShape(D, W, mr, mv, ce, cs, ct)
+        want = list(schema.nerf_layers(D, W, ch_pts=3 + 6 * mr + ce, ch_shape=cs, ch_tex=ct, ch_views=3 + 6 * mv).values())
+        assert L.mofa_net_num_layers(s) == len(want)
+        for li, (o, i) in enumerate(want):
+            assert L.mofa_net_layer_dims(s, li, C.byref(no), C.byref(ni)) == 0 and (no.value, ni.value) == (o, i), (s, li)
+        assert L.mofa_net_layer_dims(s, len(want), C.byref(no), C.byref(ni)) == -1
+
+
+def test_hipnet_refuses_a_module_the_plan_does_not_describe():
+    """VERDICT r3 'boundary hole': NeRF(input_ch=81) (multires=8) used to be accepted and mis-read with the shipped 63/30 split.
+    Now the shape is DERIVED from the module + the renderer's embedder, checked against every Linear, and anything else is refused."""
+    import pytest
+    import torch
+    from mofanerf_amd import factory
+    from mofanerf_amd.hipnet import HipNet
+    from mofanerf_amd.model import NeRF
+    mk = lambda **k: NeRF(**{**dict(D=8, W=64, input_ch=93, input_ch_views=27, input_ch_textureCodes=256, input_ch_shapeCodes=50,
+                                    use_viewdirs=True), **k})
+    h = HipNet(mk(input_ch=81), point_freqs=8)                       # multires = 8 -> 51 + 30
+    assert (h.shape.pe_point_freqs, h.shape.ch_exp) == (8, 30)
+    h = HipNet(mk(input_ch=81))                                      # fed by the shipped 63-wide encoding: 63 + 18, also a valid network
+    assert (h.shape.pe_point_freqs, h.shape.ch_exp) == (10, 18)
+    h = HipNet(mk(input_ch_views=15, input_ch_shapeCodes=80, input_ch_textureCodes=64))
+    assert (h.shape.pe_view_freqs, h.shape.ch_shape, h.shape.ch_tex) == (2, 80, 64)
+    with pytest.raises(lib.MofaError, match="narrower than the point encoding"):
+        HipNet(mk(input_ch=45))                                      # 39 + 6 fed by a 63-wide encoding
+    with pytest.raises(lib.MofaError, match="not a positional-encoding width"):
+        HipNet(mk(input_ch_views=16))
+    bad = mk()
+    bad.linear_BiM_xyz.linears1.Linear0 = torch.nn.Linear(64 + 80, 64)         # a module edited after construction
+    with pytest.raises(lib.MofaError, match="refusing to pack"):
+        HipNet(bad)
+    # the renderer hands its embedder's frequency count to the plan; create_nerf builds both from the same flags
+    args = factory.default_args(netdepth=8, netwidth=64, netdepth_fine=8, netwidth_fine=64, multires=6, multires_views=2,
+                                input_ch_textureCodes=128, no_reload=True, device="cpu", basedir="/nonexistent")
+    _, kw, _, _, _, _, render = factory.create_nerf(args)
+    assert (render.point_freqs, render.view_freqs) == (6, 2)
+    h = render._hip(kw["network_fn"])
+    assert (h.shape.pe_point_freqs, h.shape.pe_view_freqs, h.shape.ch_exp, h.shape.ch_shape, h.shape.ch_tex) == (6, 2, 30, 50, 128)
+    render.view_freqs = 4
+    render._hipnets.clear()
+    with pytest.raises(lib.MofaError, match="embeddirs_fn encodes 4"):
+        render._hip(kw["network_fn"])
+    with pytest.raises(lib.MofaError, match="must come from mofanerf_amd.embedder.get_embedder"):
+        type(render)(embed_fn=lambda x: x)
 
 
 def test_product_never_imports_the_oracle():

@@ -129,7 +129,7 @@ def test_net_backward_teacher_forced(D, W, S):
     og, dg = o.to(DEV).requires_grad_(True), d.to(DEV).requires_grad_(True)
     bmg, texg, eg = bm.to(DEV).requires_grad_(True), tex.to(DEV).requires_grad_(True), e.to(DEV).requires_grad_(True)
     vdg = dg / torch.norm(dg, dim=-1, keepdim=True)
-    raw = NetFn.apply(h, og, dg, z.to(DEV), S, S, fold_torch(h, eg, bmg, texg), view_bias_torch(h, vdg),
+    raw = NetFn.apply(h, og, dg, z.to(DEV), S, S, fold_torch(h, eg, bmg, texg), view_bias_torch(h, vdg), None,
                       *[l.weight for l in h._linears])            # training form: weight gradients requested
     (raw * G.to(DEV)).sum().backward()
     torch.cuda.synchronize()
@@ -165,7 +165,7 @@ def test_tape_forward_is_bit_identical_to_inference_forward():
     h.forward_rays(o, d, z, S, vd, S, raw0, folded)
     with torch.enable_grad():
         f2 = fold_torch(h, e.to(DEV), bm.to(DEV), tex.to(DEV))
-        raw1 = NetFn.apply(h, o, d, z, S, S, f2, view_bias_torch(h, vd))
+        raw1 = NetFn.apply(h, o, d, z, S, S, f2, view_bias_torch(h, vd), None)
     nan_equal_close(f2.detach().cpu().numpy(), folded.cpu().numpy(), 1e-6)
     nan_equal_close(raw1.detach().cpu().numpy(), raw0.cpu().numpy(), 2e-5)
 
@@ -230,7 +230,7 @@ def test_net_backward_shipped_width_vs_reference_fixture(golden, tag):
     scale, bias = style(bm[0:1])
     e = scale * exp + bias
     vd = d / torch.norm(d, dim=-1, keepdim=True)
-    raw = NetFn.apply(h, o, d, z, S, S, fold_torch(h, e, bm, tex), view_bias_torch(h, vd), *[l.weight for l in h._linears])
+    raw = NetFn.apply(h, o, d, z, S, S, fold_torch(h, e, bm, tex), view_bias_torch(h, vd), None, *[l.weight for l in h._linears])
     (raw * G).sum().backward()
     torch.cuda.synchronize()
     # Yardstick = the fp64 truth in the fixture (the reference's modules run in double on the same fp32 points).  The reference's
@@ -291,7 +291,7 @@ def test_tape_run_4096_rays_shipped_width_offsets_and_determinism():
         folded = fold_torch(h, e, bm, tex).detach().requires_grad_(True)
         vb = view_bias_torch(h, vd[lo:hi]).detach().requires_grad_(True)
         ws = [l.weight.detach().clone().requires_grad_(True) for l in h._linears]
-        raw = NetFn.apply(h, og, dg, z[lo:hi], S, S, folded, vb, *[l.weight for l in h._linears])
+        raw = NetFn.apply(h, og, dg, z[lo:hi], S, S, folded, vb, None, *[l.weight for l in h._linears])
         grads = torch.autograd.grad((raw * G[lo:hi]).sum(), [og, dg, folded, vb] + [l.weight for l in h._linears])
         torch.cuda.synchronize()
         del ws

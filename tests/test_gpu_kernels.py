@@ -239,12 +239,12 @@ def test_layer0_positional_encoding_fused():
     lib.check(L().mofa_pack_panels(lib.ptr(w), N, 63, 0, 63, lib.ptr(wp), N, 0, 64, st), "pack")
     yp = torch.empty(Mp * N, device=DEV)
     y, y2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
-    lib.check(L().mofa_layer0_forward(lib.ptr(o), lib.ptr(d), lib.ptr(z), S, None, M, S, lib.ptr(wp), lib.ptr(b),
-                                      lib.ptr(yp), Mp, N, st), "layer0")
+    lib.check(L().mofa_layer0_forward(lib.ptr(o), lib.ptr(d), lib.ptr(z), S, None, M, S, 10, lib.ptr(wp), lib.ptr(b),
+                                      lib.ptr(yp), Mp, N, None, st), "layer0")
     lib.check(L().mofa_from_panels(lib.ptr(yp), Mp, M, N, lib.ptr(y), st), "from_panels")
     pts = (o.cpu()[:, None, :] + d.cpu()[:, None, :] * z.cpu()[:, :, None]).reshape(-1, 3)
-    lib.check(L().mofa_layer0_forward(None, None, None, 0, lib.ptr(dev(pts)), M, S, lib.ptr(wp), lib.ptr(b), lib.ptr(yp),
-                                      Mp, N, st), "layer0/pts")
+    lib.check(L().mofa_layer0_forward(None, None, None, 0, lib.ptr(dev(pts)), M, S, 10, lib.ptr(wp), lib.ptr(b), lib.ptr(yp),
+                                      Mp, N, None, st), "layer0/pts")
     lib.check(L().mofa_from_panels(lib.ptr(yp), Mp, M, N, lib.ptr(y2), st), "from_panels")
     pe = orc.positional_encode(pts, 10).double()
     ref = torch.relu(pe @ w.double().cpu().T + b.double().cpu()).float().numpy()
@@ -277,7 +277,7 @@ def test_head_and_view_bias():
     wv = dev((rng.normal(size=(n_out, ld)) / 5).astype(np.float32))
     bv = dev(rng.normal(size=(n_out,)).astype(np.float32))
     out = torch.full((R, 128), float("nan"), device=DEV)
-    lib.check(L().mofa_view_bias(lib.ptr(vd), R, lib.ptr(wv), n_out, ld, lib.ptr(bv), lib.ptr(out), 128, st), "view_bias")
+    lib.check(L().mofa_view_bias(lib.ptr(vd), R, 4, lib.ptr(wv), n_out, ld, lib.ptr(bv), lib.ptr(out), 128, st), "view_bias")
     ref = (orc.positional_encode(vd.cpu(), 4).double() @ wv[:, :27].double().cpu().T + bv.double().cpu()).float().numpy()
     nan_equal_close(out[:, :n_out].cpu().numpy(), ref, 2e-6)
     assert (out[:, n_out:] == 0).all()
@@ -605,7 +605,7 @@ def test_persistent_fused_network_is_bit_identical_to_per_layer_launches(D, W, R
         h.forward_rays(o, d, z, S, vd, S, raw, folded)
         outs[mode] = raw.clone()
         with torch.enable_grad():
-            tapes[mode] = NetFn.apply(h, o, d, z, S, S, folded, view_bias_torch(h, vd).detach()).detach().clone()
+            tapes[mode] = NetFn.apply(h, o, d, z, S, S, folded, view_bias_torch(h, vd).detach(), None).detach().clone()
         torch.cuda.synchronize()
     assert torch.equal(outs["0"], outs["1"]) and torch.isfinite(outs["1"]).all()
     assert torch.equal(tapes["0"], tapes["1"])
@@ -637,7 +637,7 @@ def test_wide_first_layer_through_encoding_panels_is_bit_identical(D, W, R, S, k
         h.forward_rays(o, d, z, S, vd, S, raw, folded)
         outs[mode] = raw.clone()
         with torch.enable_grad():
-            tapes[mode] = NetFn.apply(h, o, d, z, S, S, folded, view_bias_torch(h, vd).detach()).detach().clone()
+            tapes[mode] = NetFn.apply(h, o, d, z, S, S, folded, view_bias_torch(h, vd).detach(), None).detach().clone()
         torch.cuda.synchronize()
     assert torch.equal(outs["0"], outs["1"]) and torch.isfinite(outs["1"]).all()
     assert torch.equal(tapes["0"], tapes["1"])

@@ -60,10 +60,10 @@ def test_layer0_camera_mode_is_bit_identical_to_materialised_rays():
                 lib.check(L.mofa_get_rays(W_, W_, fx, fy, cx, cy, lib.ptr(c2w), pix0, n, lib.ptr(o), lib.ptr(d), None, lib.stream()),
                           "get_rays")
             ya, yb = torch.full((Mp * Wn,), float("nan"), device=DEV), torch.full((Mp * Wn,), float("nan"), device=DEV)
-            lib.check(L.mofa_layer0_forward(lib.ptr(o), lib.ptr(d), lib.ptr(z), zs, None, M, S, lib.ptr(wp), lib.ptr(bias), lib.ptr(ya),
-                                            Mp, Wn, lib.stream()), "layer0")
+            lib.check(L.mofa_layer0_forward(lib.ptr(o), lib.ptr(d), lib.ptr(z), zs, None, M, S, 10, lib.ptr(wp), lib.ptr(bias), lib.ptr(ya),
+                                            Mp, Wn, None, lib.stream()), "layer0")
             lib.check(L.mofa_layer0_forward_cam(W_, fx, fy, cx, cy, lib.ptr(c2w), None if pix is None else pix.data_ptr(), pix0,
-                                                lib.ptr(z), zs, M, S, lib.ptr(wp), lib.ptr(bias), lib.ptr(yb), Mp, Wn, lib.stream()),
+                                                lib.ptr(z), zs, M, S, 10, lib.ptr(wp), lib.ptr(bias), lib.ptr(yb), Mp, Wn, lib.stream()),
                       "layer0_cam")
             torch.cuda.synchronize()
             a, b = torch.empty(M, Wn, device=DEV), torch.empty(M, Wn, device=DEV)

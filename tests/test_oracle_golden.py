@@ -266,3 +266,61 @@ def test_ndc_rays(golden):
     po, pd = mrays.ndc_rays(16, 16, float(g["K"][0][0]), 1., T(g["rays_o"]), T(g["rays_d"]))
     nan_equal_close(po.numpy(), g["ndc_o"], 1e-6, 1e-6)
     nan_equal_close(pd.numpy(), g["ndc_d"], 1e-6, 1e-6)
+
+
+FLAG_TAGS = ("parser", "low", "noembed")
+
+
+def flags_net_state(g, tag):
+    """The seeded weights g16_flags loaded into the reference's NeRF for flag set ``tag`` (tests/golden/make_golden.py)."""
+    mr, mv, ce, cs, ct, D, W = [int(v) for v in g[f"{tag}_flags"]]
+    return (mr, mv, ce, cs, ct, D, W), synth.nerf_state(D, W, 16, "flags", ch_pts=3 + 6 * mr + ce, ch_shape=cs, ch_tex=ct,
+                                                       ch_views=3 + 6 * mv)
+
+
+def test_non_shipped_flags_run_network_level(golden):
+    """multires / multires_views / i_embed / input_ch_*Codes off their shipped values (incl. the parser's own 80 / 6 defaults):
+    the oracle's encoding + network on explicit points against the reference's, forward and every input gradient."""
+    g = golden("kat_flags.npz")
+    for tag in FLAG_TAGS:
+        (mr, mv, ce, cs, ct, D, W), st = flags_net_state(g, tag)
+        leaf = lambda k: T(g[f"{tag}_{k}"]).clone().requires_grad_(True)
+        pts, vd, e, bm, tex = leaf("pts"), leaf("vd"), leaf("e"), leaf("bm"), leaf("tex")
+        R, S = pts.shape[:2]
+        n = R * S
+        emb = torch.cat([orc.positional_encode(pts.reshape(-1, 3), mr), e.expand(n, -1)], -1)
+        dirs = orc.positional_encode(vd[:, None].expand(R, S, 3).reshape(-1, 3), mv)
+        raw = orc.nerf_forward(st, emb, bm.expand(n, -1), dirs, tex.expand(n, -1)).reshape(R, S, 4)
+        (raw * T(g[f"{tag}_G"])).sum().backward()
+        nan_equal_close(raw.detach().numpy(), g[f"{tag}_raw"], 1e-6, 1e-6)
+        for k, v in (("pts", pts), ("vd", vd), ("e", e), ("bm", bm), ("tex", tex)):
+            nan_equal_close(v.grad.numpy(), g[f"{tag}_g_{k}"], 1e-5 * float(np.abs(g[f"{tag}_g_{k}"]).max()), 1e-5)
+
+
+def flags_e2e_oracle(g):
+    mr, mv, ct = int(g["multires"]), int(g["multires_views"]), int(g["ch_tex"])
+    Dc, Wc, Df, Wf = [int(v) for v in g["arch"]]
+    w = dict(ch_pts=3 + 6 * mr + 30, ch_shape=50, ch_tex=ct, ch_views=3 + 6 * mv)
+    return orc.OracleRenderer(synth.nerf_state(Dc, Wc, 16, "coarse", **w), synth.nerf_state(Df, Wf, 16, "fine", **w), synth.style_state(0),
+                              synth.exp_sigma(0), netchunk=int(g["netchunk"]), multires=mr, multires_views=mv)
+
+
+def test_non_shipped_flags_end_to_end(golden):
+    """render_fitting with multires=6, multires_views=2 and a 128-wide texture code: outputs, intermediates and code gradients."""
+    g = golden("flags_e2e.npz")
+    r = flags_e2e_oracle(g)
+    H = int(g["H"])
+    ro, rd = orc.get_rays(H, H, g["K"], T(g["c2w"]))
+    bm, tex, exp = [T(g[k]).clone().requires_grad_(True) for k in ("bm", "tex", "exp")]
+    rgb, disp, acc, ex = r.render(ro, rd, int(g["chunk"]), bm, 20, 8.0, 26.0, tex_code=tex, exp_codes=exp, N_samples=64,
+                                  N_importance=64, retraw=True, keep=True)
+    for n, v in (("rgb", rgb), ("disp", disp), ("acc", acc), ("rgb0", ex["rgb0"]), ("disp0", ex["disp0"]), ("acc0", ex["acc0"]),
+                 ("z_std", ex["z_std"])):
+        nan_equal_close(v.detach().numpy(), g[n], 2e-6, 2e-6)
+    nan_equal_close(ex["_dbg"]["z_samples"].detach().numpy(), g["z_samples"], 2e-6)
+    nan_equal_close(ex["raw"].detach().reshape(-1, 128, 4).numpy(), g["raw_fine"], 2e-5, 2e-6)
+    loss = (rgb - 0.5).abs().mean() + (ex["rgb0"] ** 2).mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-6
+    for k, v in (("bm", bm), ("tex", tex), ("exp", exp)):
+        nan_equal_close(v.grad.numpy(), g["g_" + k], 2e-5 * float(np.abs(g["g_" + k]).max()), 1e-4)
