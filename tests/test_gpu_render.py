@@ -185,6 +185,76 @@ def test_run_network_api():
     nan_equal_close(raw.cpu().numpy(), ref.numpy(), 2e-5, 1e-5)
 
 
+@pytest.mark.parametrize("weight_grads", [False, True])
+def test_run_network_is_differentiable_like_the_reference(weight_grads):
+    """``run_network`` / ``network_query_fn`` under autograd (models/render_class.py:69-94 is an ordinary autograd graph, exported at
+    tools/create_model_condition.py:50): gradients of sum(raw * G) reach the points, the view directions, the shape / texture codes,
+    the expression latent and the StyleModule — and the network weights when weight gradients are on — against the oracle's fp32
+    autograd of the same arithmetic.  netchunk = 200 forces several sub-batches (explicit-point HIP backward per sub-batch)."""
+    render, kw, _ = make_product((8, 64, 10, 64), 0, 200, DEV)
+    render._weight_grads = weight_grads
+    rng = np.random.default_rng(8)
+    pts = T(rng.uniform(-8, 8, (19, 33, 3)).astype(np.float32))
+    vd = torch.nn.functional.normalize(T(rng.normal(size=(19, 3)).astype(np.float32)), dim=-1)
+    G = T(rng.normal(size=(19, 33, 4)).astype(np.float32))
+    bm, tex, _ = synth.codes(0)
+    # ---- oracle, fp32 autograd
+    o = make_oracle((8, 64, 10, 64), 0, 200)
+    o.fine = {k: v.clone().requires_grad_(True) for k, v in o.fine.items()}
+    o.style = {k: v.clone().requires_grad_(True) for k, v in o.style.items()}
+    o.exp_sigma = [e.clone().requires_grad_(True) for e in o.exp_sigma]
+    lv = lambda t: t.clone().requires_grad_(True)
+    pts_r, vd_r, bm_r, tex_r = lv(pts), lv(vd), lv(bm), lv(tex)
+    ref = o.run_network(pts_r, vd_r, o.fine, bm_r, tex_r, 3)
+    (ref * G).sum().backward()
+    # ---- product
+    dv = lambda t: t.to(DEV).requires_grad_(True)
+    pts_g, vd_g, bm_g, tex_g = dv(pts), dv(vd), dv(bm), dv(tex)
+    render.shapeCodes, render.expType, render.decoding_texCodes = bm_g, 3, tex_g
+    raw = kw["network_query_fn"](pts_g, vd_g, kw["network_fine"])
+    assert raw.grad_fn is not None and raw.shape == (19, 33, 4)
+    (raw * G.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    nan_equal_close(raw.detach().cpu().numpy(), ref.detach().numpy(), 2e-5, 1e-5)
+    rel = lambda a, b: float((a.detach().cpu().double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+    errs = dict(pts=rel(pts_g.grad, pts_r.grad), vd=rel(vd_g.grad, vd_r.grad), bm=rel(bm_g.grad, bm_r.grad), tex=rel(tex_g.grad, tex_r.grad),
+                sigma3=rel(render.expCodes_Sigma[3].grad, o.exp_sigma[3].grad),
+                style=rel(render.idSpecificMod.linears_scale.weight.grad, o.style["linears_scale.weight"].grad))
+    fine = kw["network_fine"]
+    if weight_grads:
+        for key, p in fine.named_parameters():
+            errs["w:" + key] = rel(p.grad, o.fine[key].grad)
+    else:
+        assert all(p.grad is None for p in fine.parameters())        # fitting: no network parameter receives a partial .grad
+    print({k: f"{v:.1e}" for k, v in errs.items() if not k.startswith("w:")}, "max weight err",
+          max([v for k, v in errs.items() if k.startswith("w:")] or [0.0]))
+    for k, v in errs.items():       # the point gradient passes through d/dx sin(2^9 x): fp32 activations limit it to ~1e-3 relative
+        assert v < (5e-3 if k == "pts" else 1e-3), (k, v)
+
+
+def test_render_under_no_grad_issues_no_host_sync():
+    """One render_fitting(c2w=<device pose>) under no_grad must not synchronise the host anywhere (eight ranks would each stall per
+    frame): every const row is cached after the first call, the pose stays on the device, nothing calls .item() / .cpu()."""
+    render, kw, _ = make_product((8, 64, 10, 64), 0, 4096, DEV)
+    bm, tex, exp = [t.to(DEV) for t in synth.codes(0)]
+    K = synth.intrinsics(16, 16)
+    from mofanerf_amd import rays
+    poses = [rays.pose_spherical(a, 0.0, 16.0)[:3, :4].to(DEV) for a in (0.0, 30.0)]
+    call = lambda pose: render.render_fitting(16, 16, K, chunk=96, c2w=pose, shapeCodes=bm, uvCodes=tex, expType=20, expCodes=exp, **kw)
+    with torch.no_grad():
+        ref = [t.clone() if torch.is_tensor(t) else t for t in call(poses[1])[:3]]      # warm-up: packs weights, caches the sample rows
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            call(poses[0])
+            out = call(poses[1])
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) or (torch.isnan(a) == torch.isnan(b)).all() for a, b in zip(out[:3], ref))
+    assert torch.equal(out[0], ref[0])
+
+
 def test_integration_md_ctypes_stub_runs_as_written():
     """The reference-side binding printed in INTEGRATION.md (section 2) is executed verbatim (only the library path is
     substituted) and must reproduce run_network bit for bit: the documented C-ABI usage is live documentation."""
