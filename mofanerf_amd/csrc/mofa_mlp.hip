@@ -7,6 +7,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -213,7 +214,7 @@ struct FusedArgs {
 };
 
 template <bool MASKW>      // MASKW: also leave (y > 0) of every layer as bits (fitting's mask-only tape); the inference kernel is MASKW = false
-__global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
+__global__ __launch_bounds__(256, 2) void k_mlp_fused_generic(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // 4 waves side by side over the (<= 256) features, each 64 features x 128 points (8 accumulators of 32x32): a workgroup
     // owns ALL features of a 128-point half tile.  48 KiB of LDS and <= 256 VGPRs -> two INDEPENDENT workgroups per CU, so
@@ -323,14 +324,387 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
     }
 }
 
+
+// ======================================================================================================
+// k_mlp_fused: the persistent kernel for the shape the north star names — every ordinary layer 256 wide (width 193..256 pads to
+// it), a 128-wide view layer last, the generated-operand layer first — with the layer BOUNDARIES taken off the critical path.
+//
+// In the generic kernel above a boundary is a chain of exposed latencies: the epilogue's bias fetch (one L2 round trip), the drain
+// of its 128 KiB of stores (`__threadfence_block`), the barrier, and the next layer's first two operand panels (another L2 round
+// trip) with nothing in flight — 21 times per 128-point tile, ~15 % of the kernel (PMC).  Here:
+//   * the next layer's weight panel 0 is requested inside the LAST half panel of this layer's K loop (its stage is free by then),
+//     panel 1 and the next layer's bias row right after the loop's closing barrier — all before the epilogue starts;
+//   * the next layer's activation panels 0 and 1 never travel: they are the first two 16-feature slices of THIS layer's output,
+//     which the contiguous-store epilogue already forms in LDS in exactly the operand layout — wave 0 forms them directly in the
+//     two stages' X regions (and stores them to global from there like every other slice);
+//   * the epilogue reads its bias row from LDS (requested one layer earlier);
+//   * so the next K loop starts on resident operands straight after one barrier, and nothing waits for the stores: the loop's
+//     first `vmcnt(0)` + barrier (half a panel later, before the first global activation panel is requested) is what orders
+//     this workgroup's stores before its own loads — the same guarantee the fence gave;
+//   * the view layer maps its 128 features x 128 points onto 2 x 2 waves (the generic kernel leaves two waves idle there) and
+//     runs the same pipelined loop.
+// Same panels, same MFMA order, same epilogue arithmetic: bit-identical to the generic kernel and to per-layer launches.
+// LDS: two 24 KiB stages + four 4 KiB wave-private windows + two 1 KiB bias rows = 66 KiB, two workgroups per CU.
+// ======================================================================================================
+constexpr int kFsStage = (128 + 256) * 16;         // floats per stage: X [128][16] then W [<= 256][16]
+constexpr int kFsWin = 2 * kFsStage;               // float offset of the four wave-private 1024-float windows
+constexpr int kFsBias = kFsWin + 4 * 1024;         // float offset of the two 256-float bias rows (layer parity)
+constexpr int kFsFloats = kFsBias + 2 * 256;       // 16,896 floats = 67,584 B
+
+// Pipelined K loop on PRE-LOADED first panels: panels 0 and 1 are resident in stages 0 / 1 on entry (weights by LDS-DMA,
+// activations by LDS-DMA or straight from the previous epilogue), everything else is kloop_pipelined (mofa_layer.h) — same stages,
+// same MFMA order.  The tail's first half panel additionally carries the requests of the NEXT layer's panel 0 into stage 0 (free
+// after the tail's barrier): NWR rounds of weights (4: 256 rows, 2: 128 rows, 0: none) and NXR rounds of activations (2 when
+// the next layer's first source is not this layer's output — the skip layers — else 0).
+template <int NI, int NJ, int BN, int NWR, int NXR>
+__device__ __forceinline__ void kloop_fused(const float* xb, const float* x2b, const float* wb, long long xstep, long long wstep, int k1p,
+                                            int KT, float* smem, int tid, int wave, int lane, int xrow0, int wrow0,
+                                            f32x16 (&acc)[NI][NJ], const float* nwb, const float* nxb) {
+    constexpr int BM = 128, STAGE = kFsStage, XR = BM / 64, WR = BN / 64;
+    const int lr = lane & 31, g = lane >> 5, sw = (lane >> 2) & 3;
+    unsigned toff = (unsigned)tid * 4u;
+    asm volatile("" : "+v"(toff));     // per-lane offsets are formed per call (hoisted out of the tile loop they cost registers for the whole kernel)
+    float* const lds_wave = smem + wave * 256;
+    int pq = 2;                                  // panels 0 and 1 are resident
+    xb = (k1p > 2 || !x2b) ? xb + 2 * xstep : x2b + (2 - k1p) * xstep;
+    wb += 2 * wstep;
+
+    struct Frag {
+        f32x4 a[NI], b[NJ];
+    };
+    auto request = [&](int stage) {
+        float* xs = lds_wave + stage * STAGE;
+        float* ws = xs + BM * 16;
+#pragma unroll
+        for (int r = 0; r < XR; ++r) glds16(xb + (r * 1024u + toff), xs + r * 1024);
+#pragma unroll
+        for (int r = 0; r < WR; ++r) glds16(wb + (r * 1024u + toff), ws + r * 1024);
+        ++pq;
+        wb += wstep;
+        xb = pq == k1p ? x2b : xb + xstep;
+    };
+    auto request_next = [&]() {                  // the next layer's panel 0 into stage 0
+        float* xs = lds_wave;
+        float* ws = xs + BM * 16;
+#pragma unroll
+        for (int r = 0; r < NXR; ++r) glds16(nxb + (r * 1024u + toff), xs + r * 1024);
+#pragma unroll
+        for (int r = 0; r < NWR; ++r) glds16(nwb + (r * 1024u + toff), ws + r * 1024);
+    };
+    auto read = [&](int stage, int h, Frag& f) {
+        const float* Xt = smem + stage * STAGE;
+        const float* Wt = Xt + BM * 16;
+        const int p = ((2 * h + g) ^ sw) << 2;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) f.a[i] = *(const f32x4*)(Wt + (wrow0 + 32 * i + lr) * 16 + p);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) f.b[j] = *(const f32x4*)(Xt + (xrow0 + 32 * j + lr) * 16 + p);
+    };
+    auto mfma_half = [&](const Frag& f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[j][e], acc[i][j], 0, 0, 0);
+    };
+    auto half_a = [&](int stage, Frag& cur, Frag& nxt) {
+        __builtin_amdgcn_sched_barrier(0);
+        read(stage, 1, nxt);
+        mfma_half(cur);
+#pragma unroll
+        for (int q = 0; q < NI + NJ; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NI * NJ, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto sync_point = [&]() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    // kind 0: no requests; 1: this layer's panel pq; 2: the next layer's panel 0
+    auto half_b = [&](int stage, auto kind_c, bool do_read, Frag& cur, Frag& nxt) {
+        constexpr int kind = decltype(kind_c)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_read) read(stage ^ 1, 0, nxt);
+        if constexpr (kind == 1) request(stage);
+        if constexpr (kind == 2) request_next();
+        mfma_half(cur);
+        if (do_read) {
+#pragma unroll
+            for (int q = 0; q < NI + NJ; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        constexpr int nreq = kind == 1 ? XR + WR : (kind == 2 ? NXR + NWR : 0);
+        if constexpr (nreq > 0) {
+            constexpr int gap = (4 * NI * NJ - (NI + NJ)) / nreq;
+            static_assert(gap >= 1, "the half panel has too few MFMAs to carry its memory instructions");
+#pragma unroll
+            for (int q = 0; q < nreq; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, gap, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NI * NJ, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    Frag fa, fb;
+    read(0, 0, fa);
+    for (int kt = 0; kt + 2 < KT; kt += 2) {
+        half_a(0, fa, fb);
+        sync_point();
+        half_b(0, std::integral_constant<int, 1>{}, true, fb, fa);
+        half_a(1, fa, fb);
+        sync_point();
+        half_b(1, std::integral_constant<int, 1>{}, true, fb, fa);
+    }
+    half_a(0, fa, fb);
+    sync_point();
+    half_b(0, std::integral_constant<int, ((NWR + NXR) > 0 ? 2 : 0)>{}, true, fb, fa);
+    half_a(1, fa, fb);
+    half_b(1, std::integral_constant<int, 0>{}, false, fb, fa);
+}
+
+// The contiguous-store epilogue of mofa_layer.h (same values, same stores) with two additions: the bias row may come from LDS
+// (LDSBIAS), and the slices (i = 0, qh = 0 / 1) — features [0,16) and [16,32) of the wave's 64 — may be formed in the caller's
+// regions pass0 / pass1 instead of the wave's window: for wave 0 those are the next layer's operand panels 0 and 1.
+template <int NI, int NJ, bool LDSBIAS, bool MASKW>
+__device__ __forceinline__ void store_tile_fused(const f32x16 (&acc)[NI][NJ], const float* __restrict__ bias, float* __restrict__ y,
+                                                 long long m_padded, long long m_first, int n_first, int lane, float* win, float* pass0,
+                                                 float* pass1, unsigned long long* __restrict__ mask_out) {
+    static_assert(NJ % 2 == 0, "row halves of 64 points");
+    const int lr = lane & 31, g = lane >> 5, msw = (lr >> 2) & 3;
+    // per-lane LDS offsets, formed per call: hoisted out of the layer / tile loops (they are invariant) the address of every
+    // (window, fragment) pair would live in a register for the whole kernel
+    int wo0 = lr * 16 + (((0 + g) ^ msw) << 2), wo1 = lr * 16 + (((2 + g) ^ msw) << 2), ro = lane * 4;
+    asm volatile("" : "+v"(wo0), "+v"(wo1), "+v"(ro));
+    f32x4 bv[NI][4];
+    if constexpr (LDSBIAS) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(bias + 4 * g + 32 * i + 8 * q);   // `bias`: this wave's 64 floats in LDS
+    } else {
+        bias_fetch<NI>(bias, n_first, lane, bv);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh) {
+            float* __restrict__ panel = y + ((long long)((n_first >> 4) + 2 * i + qh) * m_padded + m_first) * 16;
+            float* const pass = (i == 0) ? (qh == 0 ? pass0 : pass1) : nullptr;      // wave-uniform
+#pragma unroll
+            for (int jh = 0; jh < NJ / 2; ++jh) {
+                float* const w = pass ? pass + jh * 1024 : win;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const int j = 2 * jh + jj, q = 2 * qh + qq;
+                        f32x4 v;
+                        v.x = acc[i][j][4 * q + 0] + bv[i][q].x, v.y = acc[i][j][4 * q + 1] + bv[i][q].y;
+                        v.z = acc[i][j][4 * q + 2] + bv[i][q].z, v.w = acc[i][j][4 * q + 3] + bv[i][q].w;
+                        v.x = relu_np(v.x), v.y = relu_np(v.y), v.z = relu_np(v.z), v.w = relu_np(v.w);
+                        *(f32x4*)(w + 32 * jj * 16 + (qq ? wo1 : wo0)) = v;
+                    }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const f32x4 v = *(const f32x4*)(w + it * 256 + ro);
+                    *(f32x4*)(panel + jh * 1024 + it * 256 + ro) = v;
+                    if constexpr (MASKW) mask_store_block(mask_out, (panel - y) + jh * 1024 + it * 256, lane, v);
+                }
+            }
+        }
+}
+
+template <bool MASKW>
+__global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TM = 128, NI = 2, STAGE = kFsStage;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half_tiles = a.m_tiles * 2;
+    const int nl = a.n_layers;
+    float* const win = smem + kFsWin + wn * 1024;
+    float* const lds_wave = smem + wn * 256;
+
+    // everything of layer `nx` that can be requested BEFORE this layer's epilogue, once both stages are free: its weight panel 1
+    // (panel 0 went out in the K loop's tail; `both`: layer 0 has no such tail, so panel 0 goes here too), its activation panels when
+    // they do not come from this layer's output, and its bias row (ordinary layers; wave 0)
+    auto prefetch = [&](const FusedLayer& nx, int nxi, bool x_indep, bool both, long long m0) {
+        unsigned toff = (unsigned)tid * 4u;
+        asm volatile("" : "+v"(toff));                                    // (formed here, not hoisted out of the tile loop)
+        const int wr = nx.n_padded >> 6;                                  // 4 (256 rows) or 2 (the 128-row view layer): wave-uniform
+        const float* wsrc = a.packed + nx.w_off;
+        for (int p = both ? 0 : 1; p < 2; ++p) {
+            float* xs = lds_wave + p * STAGE;
+            float* ws = xs + TM * 16;
+            if (x_indep) {
+                const float* xsrc = a.arena + nx.x1_off + ((long long)p * a.m_padded + m0) * 16;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) glds16(xsrc + (r * 1024u + toff), xs + r * 1024);
+            }
+            const float* wp = wsrc + (long long)p * nx.n_padded * 16;
+            for (int r = 0; r < wr; ++r) glds16(wp + (r * 1024u + toff), ws + r * 1024);
+        }
+        if (wn == 0 && !nx.bias_row_div) glds16(a.folded + nx.bias_off + toff, smem + kFsBias + (nxi & 1) * 256);   // (wave 0: toff = lane * 4)
+    };
+
+    for (int ht = blockIdx.x; ht < half_tiles; ht += gridDim.x) {
+        const long long m0 = (long long)ht * TM;
+        // ---------------- layer 0: operand generated from the point (positional encoding), plain double-buffered loop ----------------
+        {
+            float px = 0.f, py = 0.f, pz = 0.f;
+            long long m = m0 + (tid & (TM - 1));
+            if (m >= a.n_points) m = a.n_points - 1;
+            if (a.pts) {
+                px = a.pts[m * 3 + 0], py = a.pts[m * 3 + 1], pz = a.pts[m * 3 + 2];
+            } else {
+                const long long r = m / a.S;
+                const int s = (int)(m - r * a.S);
+                const float zz = a.z[r * a.z_row_stride + s];
+                px = __fadd_rn(a.rays_o[r * 3 + 0], __fmul_rn(a.rays_d[r * 3 + 0], zz));
+                py = __fadd_rn(a.rays_o[r * 3 + 1], __fmul_rn(a.rays_d[r * 3 + 1], zz));
+                pz = __fadd_rn(a.rays_o[r * 3 + 2], __fmul_rn(a.rays_d[r * 3 + 2], zz));
+            }
+            const FusedLayer& l = a.L[0];
+            const float* wbase = a.packed + l.w_off;
+            auto stage_issue = [&](int buf, int kt) {
+                float* xs = smem + buf * STAGE;
+                float* ws = xs + TM * 16;
+                const int row = tid & (TM - 1), k0 = (tid >> 7) * 8;
+                const int swz = (row >> 2) & 3;
+#pragma unroll 1
+                for (int kk = k0; kk < k0 + 8; ++kk) {
+                    const float v = pe_feature(kt * 16 + kk, px, py, pz, a.pe_feats);
+                    xs[row * 16 + ((((kk >> 2) & 3) ^ swz) << 2) + (kk & 3)] = v;
+                }
+                const float* wsrc = wbase + (long long)kt * 256 * 16;
+                unsigned toff = (unsigned)tid * 4u;
+                asm volatile("" : "+v"(toff));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) glds16(wsrc + (r * 1024u + toff), ws + (r * 256 + wn * 64) * 4);
+            };
+            f32x16 acc[NI][4];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            stage_issue(0, 0);
+            __syncthreads();
+            for (int kt = 0; kt < l.k1p; ++kt) {
+                const int cur = kt & 1;
+                if (kt + 1 < l.k1p) stage_issue(cur ^ 1, kt + 1);
+                const float* xs = smem + cur * STAGE;
+                mma_panel<NI, 4>(xs, xs + TM * 16, 0, wn * 64, lane, acc);
+                __syncthreads();
+            }
+            prefetch(a.L[1], 1, false, true, m0);
+            store_tile_fused<NI, 4, false, MASKW>(acc, a.folded + l.bias_off, const_cast<float*>(a.arena) + l.y_off, a.m_padded, m0, wn * 64, lane, win,
+                                                  wn == 0 ? smem : nullptr, wn == 0 ? smem + STAGE : nullptr,
+                                                  MASKW ? a.mask_bits + l.mask_off : nullptr);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // layer 1's panels 0 / 1 (and this tile's first stores): once per tile
+            __builtin_amdgcn_s_barrier();
+        }
+        // ---------------- the ordinary layers: 256 features, resident first panels, boundary work before the epilogue ----------------
+        for (int li = 1; li < nl - 1; ++li) {
+            const FusedLayer& l = a.L[li];
+            const FusedLayer& nx = a.L[li + 1];
+            const bool x_indep = nx.x1_off != l.y_off;                     // the skip layers read the stack's input first
+            const int KT = l.k1p + l.k2p;
+            f32x16 acc[NI][4];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            const float* xb = a.arena + l.x1_off + m0 * 16;
+            const float* x2b = l.k2p ? a.arena + l.x2_off + m0 * 16 : nullptr;
+            const float* wb = a.packed + l.w_off;
+            const float* nwb = a.packed + nx.w_off;
+            const float* nxb = a.arena + nx.x1_off + m0 * 16;
+            if (nx.n_padded == 256) {
+                if (x_indep) kloop_fused<NI, 4, 256, 4, 2>(xb, x2b, wb, a.m_padded * 16, 256 * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc, nwb, nxb);
+                else kloop_fused<NI, 4, 256, 4, 0>(xb, x2b, wb, a.m_padded * 16, 256 * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc, nwb, nxb);
+            } else {
+                kloop_fused<NI, 4, 256, 2, 0>(xb, x2b, wb, a.m_padded * 16, 256 * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc, nwb, nxb);
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next layer's panel 0 (requested half a panel ago) has landed;
+            __builtin_amdgcn_s_barrier();                                 // everybody is done reading both stages
+            prefetch(nx, li + 1, x_indep, false, m0);
+            const bool pass = wn == 0 && !x_indep;
+            store_tile_fused<NI, 4, true, MASKW>(acc, smem + kFsBias + (li & 1) * 256 + wn * 64, const_cast<float*>(a.arena) + l.y_off, a.m_padded, m0, wn * 64,
+                                                 lane, win, pass ? smem : nullptr, pass ? smem + STAGE : nullptr,
+                                                 MASKW ? a.mask_bits + l.mask_off : nullptr);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // my LDS writes (the handed-over panels) are done; the stores drain
+            __builtin_amdgcn_s_barrier();                                 // behind the next loop's first half panel (its vmcnt(0) + barrier)
+        }
+        // ---------------- the view layer: 128 features x 128 points on 2 x 2 waves, per-ray bias rows ----------------
+        {
+            const FusedLayer& l = a.L[nl - 1];
+            f32x16 acc[NI][2];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            const int wn2 = wn & 1, wm2 = wn >> 1;
+            kloop_fused<NI, 2, 128, 0, 0>(a.arena + l.x1_off + m0 * 16, nullptr, a.packed + l.w_off, a.m_padded * 16, 128 * 16, l.k1p, l.k1p, smem,
+                                          tid, wn, lane, wm2 * 64, wn2 * 64, acc, nullptr, nullptr);
+            f32x4 bv[NI][4];
+            store_tile<NI, 2, true>(acc, a.view_bias_rows + l.bias_off, a.bias_rows, l.bias_row_div, 128, const_cast<float*>(a.arena) + l.y_off, a.m_padded,
+                                    m0 + wm2 * 64, wn2 * 64, 1, lane, bv);
+            __threadfence_block();
+            __syncthreads();          // the stages are free for the next tile's first layer
+        }
+    }
+}
+
+// can this launch take the pipelined persistent kernel?  (the shape the north star names; everything else runs the generic one)
+bool fused_fast_shape(const FusedArgs& a) {
+    if (!a.pipe || a.n_layers < 3) return false;
+    const FusedLayer& f = a.L[0];
+    if (f.x1_off >= 0 || f.n_padded != 256 || f.k2p != 0 || f.bias_row_div != 0) return false;
+    for (int i = 1; i < a.n_layers - 1; ++i) {
+        const FusedLayer& l = a.L[i];
+        if (l.x1_off < 0 || l.n_padded != 256 || l.k1p != 16 || (l.k2p != 0 && l.k2p != 16) || l.bias_row_div != 0) return false;
+    }
+    const FusedLayer& v = a.L[a.n_layers - 1];
+    return v.x1_off >= 0 && v.n_padded == 128 && v.k1p == 16 && v.k2p == 0 && v.bias_row_div != 0 && v.x1_off == a.L[a.n_layers - 2].y_off;
+}
+std::atomic<int> g_fused_attr[kMaxDevices];
+
 int launch_fused(const FusedArgs& a, hipStream_t st) {
-    const int cus = compute_units(current_device());
+    const int dev = current_device();
+    const int cus = compute_units(dev);
     const int half_tiles = a.m_tiles * 2;
     const int grid = half_tiles < 2 * cus ? half_tiles : 2 * cus;      // two resident workgroups per CU
+    if (fused_fast_shape(a)) {
+        const size_t lds = (size_t)kFsFloats * sizeof(float);          // 66 KiB: above the 64 KiB default limit of dynamic LDS
+        if (!g_fused_attr[dev].load(std::memory_order_acquire)) {      // one-time function attribute per device
+            if (hipFuncSetAttribute((const void*)k_mlp_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_mlp_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return check_launch("hipFuncSetAttribute(k_mlp_fused)");
+            g_fused_attr[dev].store(1, std::memory_order_release);
+        }
+        if (a.mask_bits) hipLaunchKernelGGL(k_mlp_fused<true>, dim3(grid), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(k_mlp_fused<false>, dim3(grid), dim3(256), lds, st, a);
+        return check_launch("k_mlp_fused");
+    }
     const size_t lds = 2 * (size_t)(128 + 256) * 16 * sizeof(float);   // 48 KiB
-    if (a.mask_bits) hipLaunchKernelGGL(k_mlp_fused<true>, dim3(grid), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(k_mlp_fused<false>, dim3(grid), dim3(256), lds, st, a);
-    return check_launch("k_mlp_fused");
+    if (a.mask_bits) hipLaunchKernelGGL(k_mlp_fused_generic<true>, dim3(grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(k_mlp_fused_generic<false>, dim3(grid), dim3(256), lds, st, a);
+    return check_launch("k_mlp_fused_generic");
 }
 
 // Optional per-launch timing of the dominant kernels with HIP events recorded on the launch stream; used by bench.py for the

@@ -578,7 +578,8 @@ def test_layer_pipeline_race_screen_full_size():
     nan_equal_close(yr.cpu().numpy(), want.cpu().numpy(), 3e-5)
 
 
-@pytest.mark.parametrize("D,W,R,S", [(8, 256, 40, 64), (10, 96, 9, 128), (8, 64, 130, 64), (8, 192, 17, 32), (10, 512, 300, 64), (8, 320, 150, 64)])
+@pytest.mark.parametrize("D,W,R,S", [(8, 256, 40, 64), (10, 96, 9, 128), (8, 64, 130, 64), (8, 192, 17, 32), (10, 512, 300, 64), (8, 320, 150, 64),
+                                     (10, 256, 1201, 64), (8, 256, 700, 128)])
 def test_persistent_fused_network_is_bit_identical_to_per_layer_launches(D, W, R, S, knob):
     """Widths <= 256 run the whole MLP as ONE persistent launch (k_mlp_fused); it must reproduce the per-layer path
     bit for bit, in inference mode (recycled buffers) and in tape mode (every layer output kept).  Widths 512 / 320: several
@@ -610,6 +611,63 @@ def test_persistent_fused_network_is_bit_identical_to_per_layer_launches(D, W, R
     assert torch.equal(outs["0"], outs["1"]) and torch.isfinite(outs["1"]).all()
     assert torch.equal(tapes["0"], tapes["1"])
     nan_equal_close(tapes["1"].cpu().numpy(), outs["1"].cpu().numpy(), 2e-5)
+
+
+@pytest.mark.parametrize("D,W,R,S", [(8, 256, 300, 64), (10, 256, 90, 128), (8, 192, 77, 64), (8, 64, 50, 64), (10, 1024, 40, 128)])
+def test_mask_tape_equals_fp32_tape_across_kernels(D, W, R, S, knob):
+    """The mask-only tape (one bit per activation) against the fp32 tape, per-layer launches against the persistent kernels (the
+    pipelined one at 256-wide layers, the generic one elsewhere): the mask words are bit-identical between the launch forms, equal
+    (activation > 0) of the fp32 tape, and the fitting gradients computed from the bits equal the ones computed from the tape."""
+    from mofanerf_amd.autograd import NetFn, fold_torch, view_bias_torch
+    from mofanerf_amd.hipnet import HipNet
+    from mofanerf_amd.model import NeRF
+    rng = np.random.default_rng(D + W + R + 7)
+    net = NeRF(D=D, W=W, input_ch=93, input_ch_views=27, input_ch_textureCodes=256, input_ch_shapeCodes=50, use_viewdirs=True)
+    net.load_state_dict(synth.nerf_state(D, W, 1))
+    h = HipNet(net.to(DEV))
+    o = dev(rng.uniform(-2, 2, (R, 3)).astype(np.float32))
+    d = dev(rng.normal(0, 0.3, (R, 3)).astype(np.float32))
+    z = dev(np.sort(rng.uniform(8, 26, (R, S)).astype(np.float32), -1))
+    vd = torch.nn.functional.normalize(d, dim=-1).contiguous()
+    bm, tex, e = synth.codes(3)
+    folded = h.fold(e.to(DEV), bm.to(DEV), tex.to(DEV)).clone()
+    vb = view_bias_torch(h, vd).detach().contiguous()
+    G = dev(rng.normal(size=(R, S, 4)).astype(np.float32))
+    Lb, st = L(), lib.stream()
+    n_tape, n_mask = Lb.mofa_net_tape_floats(h.shape, R * S), Lb.mofa_net_mask_tape_words(h.shape, R * S)
+    assert n_mask * 64 == n_tape
+    masks, grads = {}, {}
+    for fused in ("0", "1"):
+        knob("MOFA_FUSED", fused)
+        ws = h.workspace(R * S, R, DEV)
+        raw_m, raw_t = torch.empty(R, S, 4, device=DEV), torch.empty(R, S, 4, device=DEV)
+        mask = torch.zeros(n_mask, dtype=torch.int64, device=DEV)
+        tape = torch.empty(n_tape, device=DEV)
+        for raw, tp, mk in ((raw_m, None, mask), (raw_t, tape, None)):
+            lib.check(Lb.mofa_net_forward(h.shape, lib.ptr(h.packed()), lib.ptr(folded), None, None, lib.ptr(o), lib.ptr(d), lib.ptr(z), S, None,
+                                          None, R, S, lib.ptr(ws), lib.ptr(raw), lib.ptr(tp), mk.data_ptr() if mk is not None else None, lib.ptr(vb),
+                                          st), "net_forward")
+        torch.cuda.synchronize()
+        assert torch.equal(raw_m, raw_t)
+        masks[fused] = mask.clone()
+        # the bits against the fp32 tape: word 4 b + c, bit l  <->  float 256 b + 4 l + c   (Mp x tape_cols floats, valid rows only matter
+        # downstream, but the padding rows are written by both forms too)
+        t = (tape.reshape(-1, 64, 4) > 0)                                         # [block, lane, comp]
+        bits = (mask.reshape(-1, 4)[:, None, :] >> torch.arange(64, device=DEV)[None, :, None]) & 1
+        assert torch.equal(bits.bool(), t)
+        for mode in ("mask", "tape"):
+            h.force_fp32_tape = mode == "tape"
+            og, dg = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
+            fo, vbg = folded.clone().requires_grad_(True), vb.clone().requires_grad_(True)
+            raw = NetFn.apply(h, og, dg, z, S, S, fo, vbg, None)
+            (raw * G).sum().backward()
+            grads[(fused, mode)] = [t_.grad.clone() for t_ in (og, dg, fo, vbg)]
+        h.force_fp32_tape = False
+    assert torch.equal(masks["0"], masks["1"])
+    ref = grads[("0", "tape")]
+    for k, g in grads.items():
+        for a_, b_ in zip(g, ref):
+            assert torch.equal(a_, b_), k
 
 
 @pytest.mark.parametrize("D,W,R,S", [(10, 1024, 70, 128), (8, 512, 33, 64)])
