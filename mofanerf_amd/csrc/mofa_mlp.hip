@@ -356,10 +356,28 @@ constexpr int kFsFloats = kFsBias + 2 * 256;       // 16,896 floats = 67,584 B
 // same MFMA order.  The tail's first half panel additionally carries the requests of the NEXT layer's panel 0 into stage 0 (free
 // after the tail's barrier): NWR rounds of weights (4: 256 rows, 2: 128 rows, 0: none) and NXR rounds of activations (2 when
 // the next layer's first source is not this layer's output — the skip layers — else 0).
-template <int NI, int NJ, int BN, int NWR, int NXR>
+// What the merged tail needs to write a layer's output (EPI = true).
+struct FusedEpi {
+    const float* bias_lds;            // this wave's 64 bias floats in LDS
+    float* y;                         // the layer's output panels
+    long long m_padded, m_first;
+    int n_first;
+    float* win;                       // wave-private 1024-float window
+    float* pass0;                     // wave 0 (when the next layer reads this output first): the two stages' X regions, where output
+    float* pass1;                     //   slices 0 / 1 are formed — they ARE the next layer's operand panels 0 / 1; else nullptr
+    unsigned long long* mask_out;     // mask-only tape bits of this layer (MASKW) or nullptr
+};
+
+// EPI = true (the ordinary layers): the epilogue runs INSIDE the tail.  After the last panel's first half every wave has read its
+// last fragments, so one barrier frees both stages; the requests for the next layer's panel 1 and bias row go out, and the last 32
+// MFMAs are issued accumulator pair by accumulator pair (each accumulator still sees its k-updates in the same order: bit-identical)
+// with the bias + ReLU + staging + stores of the pair BEFORE in their shadow — a timing-only build without any epilogue says the
+// epilogue is worth 5.3 % of this kernel when it runs by itself after the loop (profiles/r04_ab_fused_epilogue.txt).
+template <int NI, int NJ, int BN, int NWR, int NXR, bool EPI = false, class Pre = int>
 __device__ __forceinline__ void kloop_fused(const float* xb, const float* x2b, const float* wb, long long xstep, long long wstep, int k1p,
                                             int KT, float* smem, int tid, int wave, int lane, int xrow0, int wrow0,
-                                            f32x16 (&acc)[NI][NJ], const float* nwb, const float* nxb) {
+                                            f32x16 (&acc)[NI][NJ], const float* nwb, const float* nxb, const FusedEpi* ep = nullptr,
+                                            Pre pre = Pre()) {
     constexpr int BM = 128, STAGE = kFsStage, XR = BM / 64, WR = BN / 64;
     const int lr = lane & 31, g = lane >> 5, sw = (lane >> 2) & 3;
     unsigned toff = (unsigned)tid * 4u;
@@ -468,7 +486,65 @@ __device__ __forceinline__ void kloop_fused(const float* xb, const float* x2b, c
     sync_point();
     half_b(0, std::integral_constant<int, ((NWR + NXR) > 0 ? 2 : 0)>{}, true, fb, fa);
     half_a(1, fa, fb);
-    half_b(1, std::integral_constant<int, 0>{}, false, fb, fa);
+    if constexpr (!EPI) {
+        half_b(1, std::integral_constant<int, 0>{}, false, fb, fa);
+    } else {
+        static_assert(NI == 2 && NJ == 4, "merged tail: 64 features x 128 points per wave");
+        // every wave holds its last fragments in registers: both stages are free after this barrier (and the next layer's panel 0,
+        // requested half a panel ago, has landed)
+        sync_point();
+        pre();                                   // the next layer's panel 1 + bias row: LDS-DMA requests under the MFMAs below
+        const int wg = lane >> 5, msw = ((lane & 31) >> 2) & 3;
+        int wo0 = (lane & 31) * 16 + (((0 + wg) ^ msw) << 2), wo1 = (lane & 31) * 16 + (((2 + wg) ^ msw) << 2), ro = lane * 4;
+        asm volatile("" : "+v"(wo0), "+v"(wo1), "+v"(ro));
+        // the wave's bias quads, fetched (LDS) before the MFMAs they hide under: the epilogue below is a chain of LDS round trips, and
+        // every wait in it would stall the in-order MFMA issue behind it
+        f32x4 bv[NI][4];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(ep->bias_lds + 4 * wg + 32 * i + 8 * q);
+        // output slices of accumulator pair G = (i, jh): features 32 i + 16 qh .. + 15 (qh = 0, 1), points 64 jh .. + 63
+        auto slices = [&](int i, int jh) {
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh) {
+                float* __restrict__ panel = ep->y + ((long long)((ep->n_first >> 4) + 2 * i + qh) * ep->m_padded + ep->m_first) * 16 + jh * 1024;
+                float* const pass = (i == 0) ? (qh == 0 ? ep->pass0 : ep->pass1) : nullptr;          // wave-uniform
+                float* const w = pass ? pass + jh * 1024 : ep->win;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const int j = 2 * jh + jj, q = 2 * qh + qq;
+                        f32x4 v;
+                        v.x = acc[i][j][4 * q + 0] + bv[i][q].x, v.y = acc[i][j][4 * q + 1] + bv[i][q].y;
+                        v.z = acc[i][j][4 * q + 2] + bv[i][q].z, v.w = acc[i][j][4 * q + 3] + bv[i][q].w;
+                        v.x = relu_np(v.x), v.y = relu_np(v.y), v.z = relu_np(v.z), v.w = relu_np(v.w);
+                        *(f32x4*)(w + 32 * jj * 16 + (qq ? wo1 : wo0)) = v;
+                    }
+                f32x4 r[4];                      // all four read-backs in flight together, then the four stores
+#pragma unroll
+                for (int it = 0; it < 4; ++it) r[it] = *(const f32x4*)(w + it * 256 + ro);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    *(f32x4*)(panel + it * 256 + ro) = r[it];
+                }
+            }
+        };
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+            const int i = G >> 1, jh = G & 1;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    acc[i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb.a[i][e], fb.b[2 * jh + jj][e], acc[i][2 * jh + jj], 0, 0, 0);
+            if (G > 0) slices((G - 1) >> 1, (G - 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        slices(1, 1);
+    }
 }
 
 // The contiguous-store epilogue of mofa_layer.h (same values, same stores) with two additions: the bias row may come from LDS
@@ -632,19 +708,25 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
             const float* wb = a.packed + l.w_off;
             const float* nwb = a.packed + nx.w_off;
             const float* nxb = a.arena + nx.x1_off + m0 * 16;
-            if (nx.n_padded == 256) {
-                if (x_indep) kloop_fused<NI, 4, 256, 4, 2>(xb, x2b, wb, a.m_padded * 16, 256 * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc, nwb, nxb);
-                else kloop_fused<NI, 4, 256, 4, 0>(xb, x2b, wb, a.m_padded * 16, 256 * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc, nwb, nxb);
-            } else {
-                kloop_fused<NI, 4, 256, 2, 0>(xb, x2b, wb, a.m_padded * 16, 256 * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc, nwb, nxb);
-            }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next layer's panel 0 (requested half a panel ago) has landed;
-            __builtin_amdgcn_s_barrier();                                 // everybody is done reading both stages
-            prefetch(nx, li + 1, x_indep, false, m0);
             const bool pass = wn == 0 && !x_indep;
-            store_tile_fused<NI, 4, true, MASKW>(acc, smem + kFsBias + (li & 1) * 256 + wn * 64, const_cast<float*>(a.arena) + l.y_off, a.m_padded, m0, wn * 64,
-                                                 lane, win, pass ? smem : nullptr, pass ? smem + STAGE : nullptr,
-                                                 MASKW ? a.mask_bits + l.mask_off : nullptr);
+            const FusedEpi ep{smem + kFsBias + (li & 1) * 256 + wn * 64, const_cast<float*>(a.arena) + l.y_off, a.m_padded, m0, wn * 64, win,
+                              pass ? smem : nullptr, pass ? smem + STAGE : nullptr, MASKW ? a.mask_bits + l.mask_off : nullptr};
+            auto pre = [&]() { prefetch(nx, li + 1, x_indep, false, m0); };
+            // inference: the epilogue inside the loop's tail.  MASKW (a fitting forward): the four ballots per KiB on top of it do not
+            // fit the register file next to the loop's fragments — the epilogue follows the loop there.
+            constexpr bool EPI = !MASKW;
+            if (nx.n_padded == 256) {
+                if (x_indep) kloop_fused<NI, 4, 256, 4, 2, EPI>(xb, x2b, wb, a.m_padded * 16, 256 * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc, nwb, nxb, &ep, pre);
+                else kloop_fused<NI, 4, 256, 4, 0, EPI>(xb, x2b, wb, a.m_padded * 16, 256 * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc, nwb, nxb, &ep, pre);
+            } else {
+                kloop_fused<NI, 4, 256, 2, 0, EPI>(xb, x2b, wb, a.m_padded * 16, 256 * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc, nwb, nxb, &ep, pre);
+            }
+            if constexpr (!EPI) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next layer's panel 0 (requested half a panel ago) has landed;
+                __builtin_amdgcn_s_barrier();                                 // everybody is done reading both stages
+                pre();
+                store_tile_fused<NI, 4, true, MASKW>(acc, ep.bias_lds, ep.y, a.m_padded, m0, wn * 64, lane, win, ep.pass0, ep.pass1, ep.mask_out);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // my LDS writes (the handed-over panels) are done; the stores drain
             __builtin_amdgcn_s_barrier();                                 // behind the next loop's first half panel (its vmcnt(0) + barrier)
         }
@@ -689,16 +771,16 @@ int launch_fused(const FusedArgs& a, hipStream_t st) {
     const int cus = compute_units(dev);
     const int half_tiles = a.m_tiles * 2;
     const int grid = half_tiles < 2 * cus ? half_tiles : 2 * cus;      // two resident workgroups per CU
-    if (fused_fast_shape(a)) {
+    // (a fitting forward — mask-only tape — takes the generic kernel: its four ballots per KiB of output do not fit the register file
+    //  next to the pipelined kernel's fragments without spilling, and it runs 1,024 rays, not frames)
+    if (fused_fast_shape(a) && !a.mask_bits) {
         const size_t lds = (size_t)kFsFloats * sizeof(float);          // 66 KiB: above the 64 KiB default limit of dynamic LDS
         if (!g_fused_attr[dev].load(std::memory_order_acquire)) {      // one-time function attribute per device
-            if (hipFuncSetAttribute((const void*)k_mlp_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_mlp_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            if (hipFuncSetAttribute((const void*)k_mlp_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return check_launch("hipFuncSetAttribute(k_mlp_fused)");
             g_fused_attr[dev].store(1, std::memory_order_release);
         }
-        if (a.mask_bits) hipLaunchKernelGGL(k_mlp_fused<true>, dim3(grid), dim3(256), lds, st, a);
-        else hipLaunchKernelGGL(k_mlp_fused<false>, dim3(grid), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(k_mlp_fused<false>, dim3(grid), dim3(256), lds, st, a);
         return check_launch("k_mlp_fused");
     }
     const size_t lds = 2 * (size_t)(128 + 256) * 16 * sizeof(float);   // 48 KiB
