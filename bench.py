@@ -48,7 +48,7 @@ ARCH = (8, 256, 10, 1024)
 N_SAMPLES, N_IMPORTANCE = 64, 64
 # (symbol, role, description) per profiler kind of libmofanerf_hip.so; k_layer's template = <BN, L0, BWD, PERRAY, PIPE, policy>
 KERNELS = [("mofa::k_layer<128,false,false,false,true,mofa::ShippedPolicy>", "forward", "fp32 MFMA Linear+bias+ReLU, software-pipelined K loop"),
-           ("mofa::k_mlp_fused", "forward, persistent", "persistent fp32-MFMA network kernel, widths <= 256"),
+           ("mofa::k_mlp_fused<false>", "forward, persistent", "persistent fp32-MFMA network kernel, 256-wide layers pipelined across layer boundaries"),
            ("mofa::k_layer<128,false,true,false,true,mofa::ShippedPolicy>", "BWD backward-data", "fp32 MFMA backward-data GEMM + ReLU mask, the same K loop"),
            ("mofa::k_wgrad<128,256>", "weight gradient", "fp32 MFMA weight-gradient GEMM, contraction over points"),
            ("mofa::k_layer<128,false,false,true,true,mofa::ShippedPolicy>", "forward, PERRAY view layer", "the same kernel with the view layer's per-ray bias")]
@@ -188,18 +188,72 @@ def parity_sample(render, kw, args, K, frame, angle, bm, tex, exp, dev, n=256, s
         zf = ex["_z_fine"].cpu()
         raw1 = o.run_network(ro[:, None, :] + rd[:, None, :] * zf[:, :, None], vd, o.fine, bm_c, tex_c, 20)
         rgb_r, disp_r, acc_r, _, _ = orc.raw2outputs(raw1, zf, rd)
+    # the resampler itself (k_sample_pdf_merge), which teacher forcing by construction does not exercise: the oracle's sample_pdf on the
+    # DEVICE's own coarse weights (identical input) against the device's positions — every position must agree within a few ulp of z or
+    # be explained by the algorithm's own `denom < 1e-5` branch / conditioning (tests/harness.py::classify_samples)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from harness import classify_samples
+    w_dev, zs_dev = ex["_weights0"].cpu(), ex["_z_samples"].cpu()
+    zs_ref = orc.sample_pdf(.5 * (zc[:, 1:] + zc[:, :-1]), w_dev[:, 1:-1], torch.linspace(0., 1., N_IMPORTANCE))
+    agree, expl = classify_samples(zc, w_dev, torch.linspace(0., 1., N_IMPORTANCE), zs_dev, zs_ref, w_err=0.0)
+    zf_sorted = bool((zf[:, 1:] >= zf[:, :-1]).all())
     err = lambda a_, b_: float((a_.cpu() - b_).abs().max())
     out = {"tolerance": 1e-4, "rays": n, "rgb_max_abs": err(rgb, rgb_r), "acc_max_abs": err(acc, acc_r),
            "coarse_rgb_max_abs": err(ex["rgb0"], rgb0_r), "coarse_acc_max_abs": err(ex["acc0"], acc0_r),
            "disp_nan_pattern_equal": bool(torch.equal(torch.isnan(disp.cpu()), torch.isnan(disp_r))),
            "pixels_bit_identical_to_timed_frame": same,
-           "method": "teacher-forced vs the CPU oracle (oracle/mofa_oracle.py, pinned to the reference by tests/golden): coarse pass "
-                     "ray by ray; the device's resampled positions fed to the oracle's fine network + raw2outputs",
+           "resampler": {"positions": int(agree.numel()), "frac_within_6e-6_of_oracle_on_same_weights": round(float(agree.float().mean()), 6),
+                         "frac_agree_or_explained": round(float((agree | expl).float().mean()), 6), "merged_positions_sorted": zf_sorted},
+           "method": "TEACHER-FORCED vs the CPU oracle (oracle/mofa_oracle.py, pinned to the reference by tests/golden): coarse pass "
+                     "ray by ray; the device's resampled positions fed to the oracle's fine network + raw2outputs; the resampler is "
+                     "checked separately on identical coarse weights (`resampler`)",
            "seconds": round(time.perf_counter() - t0, 1)}
     out = {k: (float(f"{v:.3e}") if isinstance(v, float) and k.endswith("max_abs") else v) for k, v in out.items()}
-    out["pass"] = bool(same and out["disp_nan_pattern_equal"] and max(out["rgb_max_abs"], out["acc_max_abs"], out["coarse_rgb_max_abs"],
-                                                                     out["coarse_acc_max_abs"]) <= 1e-4)
+    out["pass_teacher_forced"] = bool(same and out["disp_nan_pattern_equal"] and max(out["rgb_max_abs"], out["acc_max_abs"], out["coarse_rgb_max_abs"],
+                                                                                    out["coarse_acc_max_abs"]) <= 1e-4)
+    out["pass_resampler"] = bool(zf_sorted and out["resampler"]["frac_agree_or_explained"] == 1.0)
+    out["pass"] = out["pass_teacher_forced"] and out["pass_resampler"]
     return out
+
+
+def variant_series(arch, steps, dev, L, bm, tex, exp, K, rays, angles, args):
+    """The labelled second series of BASELINE.md section 2 — the same frames with the fine network as small as the coarse one (256 x 8,
+    the size BASELINE.json's prose assumes) — timed AFTER the headline's region with the same barrier + synchronize bracket and its own
+    HIP-event session: rays/s, ms per frame and the roofline of ITS dominant kernel (the persistent k_mlp_fused)."""
+    global ARCH
+    keep = ARCH
+    ARCH = tuple(arch)
+    try:
+        render, kw, _ = build_product(dev)
+
+        def frame(i):
+            with torch.no_grad():
+                return render.render_fitting(H, W, K, chunk=args.chunk, rays=rays[angles[i % len(angles)]], shapeCodes=bm, uvCodes=tex,
+                                             expType=20, expCodes=exp, **kw)[0]
+        frame(0)
+        torch.cuda.synchronize()
+        lib.check(L.mofa_prof_begin(), "mofa_prof_begin")
+        t0 = time.perf_counter()
+        for i in range(steps):
+            last = frame(1 + i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        NK = lib.PROF_KINDS
+        ms, launches, pflops = (ctypes.c_double * NK)(), (ctypes.c_int64 * NK)(), (ctypes.c_double * NK)()
+        lib.check(L.mofa_prof_end(ms, launches, pflops), "mofa_prof_end")
+        assert bool(torch.isfinite(last).all())
+        dom = max(range(NK), key=lambda k: ms[k])
+        ach = pflops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+        return {"workload": f"{H}x{W} novel view, 64 coarse + 128 fine samples/ray, coarse {arch[1]}x{arch[0]} + fine {arch[3]}x{arch[2]} (VARIANT: "
+                            "BASELINE.json's prose size; the headline is the shipped 1024x10 fine network)",
+                "value": round(H * W * steps / dt, 1), "unit": "rays/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2),
+                "gflop_per_ray_folded": round(flops_per_ray(True) / 1e9, 4),
+                "roofline": {"bound": "mfma", "kernel": f"{KERNELS[dom][0]} ({KERNELS[dom][2]})", "achieved": round(ach, 2),
+                             "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                             "launches": int(launches[dom]), "avg_launch_ms": round(ms[dom] / max(1, launches[dom]), 4),
+                             "share_of_timed_region": round(ms[dom] * 1e-3 / dt, 4)}}
+    finally:
+        ARCH = keep
 
 
 def self_spawn(n):
@@ -235,6 +289,8 @@ def main():
                     help="fit / train: keep every layer output for the backward (default) or re-run each sub-batch's forward inside its "
                          "backward (labelled variant: Renderer.tape_recompute)")
     ap.add_argument("--size", type=int, default=512, help="image side (512 = the benchmark; smaller only for functional tests)")
+    ap.add_argument("--variant-steps", type=int, default=3, help="frames of the labelled fine-256x8 series after the headline loop (BASELINE.md "
+                    "section 2 asks for both series; render mode, N = 1, shipped --arch only; 0 = skip)")
     ap.add_argument("--rays", type=int, default=None, help="fit / train: N_rand per GPU (default 1024 / 4096)")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -416,6 +472,8 @@ def main():
             out["collective"] = {"what": {"render": "all_gather_into_tensor of the [rays/N,5] fp32 tiles, written straight into the frame",
                                           "fit": "none (replicas)", "train": "all_reduce of the flat fp32 gradient bucket"}[a.mode],
                                  "avg_ms_per_step_rank0": round(comm, 4)}
+        if world == 1 and a.mode == "render" and a.variant_steps > 0 and ARCH == (8, 256, 10, 1024) and (H, W) == (512, 512) and not a.netchunk:
+            out["variants"] = {"fine256x8": variant_series((8, 256, 8, 256), a.variant_steps, dev, L, bm, tex, exp, K, rays, angles, args)}
         if world == 1 and a.mode == "render" and a.parity_rays > 0:
             out["parity"] = parity_sample(render, kw, args, K, last, angles[(a.warmup + a.steps - 1) % len(angles)], bm, tex, exp, dev,
                                           n=a.parity_rays)

@@ -151,6 +151,36 @@ def test_net_backward_teacher_forced(D, W, S):
         assert v < (5e-3 if k.startswith("rays") else 5e-4), (k, v)
 
 
+@pytest.mark.parametrize("D,W,R,S", [(8, 512, 7, 33), (10, 1024, 3, 128), (8, 256, 9, 64)])
+def test_training_step_is_bit_identical_across_the_loop_forms_with_ragged_point_counts(D, W, R, S, knob):
+    """MOFA_PIPE=0 (plain K loops; at width >= 512 also the generated-operand first layer instead of the encoding panels)
+    and MOFA_PIPE=1 differ in what they leave in the PADDING rows of the activation panels (m >= n_points: relu(bias) vs a copy of the
+    last point) when the point count is not a multiple of 256.  No consumer may read those rows: the whole training step — raw, the
+    gradients to rays / folded biases / view-bias rows and EVERY weight gradient (contractions over the points) — must agree bit for bit."""
+    assert (R * S) % 256 != 0
+    h, _ = _mk(D, W)
+    rng = np.random.default_rng(D + W + R)
+    o = T(rng.uniform(-2, 2, (R, 3)).astype(np.float32)).to(DEV)
+    d = T(rng.normal(0, 0.3, (R, 3)).astype(np.float32)).to(DEV)
+    z = T(np.sort(rng.uniform(8, 26, (R, S)).astype(np.float32), -1)).to(DEV)
+    vd = (d / torch.norm(d, dim=-1, keepdim=True)).contiguous()
+    bm, tex, e = synth.codes(2)
+    G = T(rng.normal(size=(R, S, 4)).astype(np.float32)).to(DEV)
+    runs = {}
+    for mode in ("0", "1"):
+        knob("MOFA_PIPE", mode)
+        og, dg = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
+        fo = fold_torch(h, e.to(DEV), bm.to(DEV), tex.to(DEV)).detach().requires_grad_(True)
+        vb = view_bias_torch(h, vd).detach().requires_grad_(True)
+        ws = [l.weight.detach().clone().requires_grad_(True) for l in h._linears]
+        raw = NetFn.apply(h, og, dg, z, S, S, fo, vb, None, *ws)
+        (raw * G).sum().backward()
+        torch.cuda.synchronize()
+        runs[mode] = [raw.detach().clone(), og.grad, dg.grad, fo.grad, vb.grad] + [w.grad for w in ws]
+    for k, (a, b) in enumerate(zip(runs["0"], runs["1"])):
+        assert torch.isfinite(a).all() and torch.equal(a, b), k
+
+
 def test_tape_forward_is_bit_identical_to_inference_forward():
     h, _ = _mk(8, 64)
     rng = np.random.default_rng(0)

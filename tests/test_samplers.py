@@ -69,6 +69,31 @@ def test_fitting_sampler_matches_the_reference_bit_for_bit(tag, dev):
         rays.fit_pixels(lm, n, target, scale=2, draws={"rand": G[f"fit_{tag}_rand"][:-1], "rand_outline": G[f"fit_{tag}_rand_outline"], "choice": None})
 
 
+def test_samplers_fail_like_the_reference_instead_of_returning_short_or_piled_up_batches():
+    """(i) a uniform part larger than its window raised in the reference (np.random.choice(replace=False), run_train.py:146) —
+    never a silently short batch; (ii) ``strict=True`` raises IndexError for a sample outside [-size, size) like the reference's gather,
+    instead of clamping it onto a border pixel."""
+    H = int(G["train_H"])
+    lm2d = torch.from_numpy(G["train_a_lm2d"]).long()
+    with pytest.raises(ValueError, match="distinct pixels"):
+        rays.train_pixels(lm2d, 4096, H, H, precrop_frac=0.05)                  # 5 % window: 12 x 12 pixels for ~1,600 uniform draws
+    with pytest.raises(ValueError, match="draws\\['choice'\\]"):
+        rays.train_pixels(lm2d, int(G["train_a_n"]), H, H, draws={"rand": G["train_a_rand"], "choice": G["train_a_choice"][:-5]})
+    far = lm2d.clone()
+    far[0, 0] = 5 * H                                                           # a landmark projected far outside the frame (bad pose)
+    q = rays.train_pixels(far, 1024, H, H, generator=torch.Generator().manual_seed(0))
+    assert q.min() >= 0 and q.max() < H                                         # default: clamped to the border, no host sync
+    with pytest.raises(IndexError, match="outside"):
+        rays.train_pixels(far, 1024, H, H, generator=torch.Generator().manual_seed(0), strict=True)
+    lm = torch.from_numpy(G["fit_lm"])
+    target = torch.from_numpy(G["fit_target"])
+    far = lm.clone()
+    far[3] = torch.tensor([4000, 4000])
+    with pytest.raises(IndexError, match="outside"):
+        rays.fit_pixels(far, 1024, target, scale=2, generator=torch.Generator().manual_seed(0), strict=True)
+    assert rays.fit_pixels(far, 1024, target, scale=2, generator=torch.Generator().manual_seed(0)).shape == (1024, 2)
+
+
 @pytest.mark.gpu
 def test_batch_construction_on_the_device_matches_the_scripts_gather():
     """steps.sample_train_batch / sample_fit_batch: landmarks -> pixels -> rays -> target colours without the H x W ray grid.  With the
