@@ -285,9 +285,10 @@ def main():
                     help="network sizes; default = shipped config (8 256 10 1024).  '8 256 8 256' is the labelled variant "
                          "BASELINE.md lists (fine net as small as the coarse one)")
     ap.add_argument("--netchunk", type=int, default=None, help="labelled variant: points per network launch (default 196608, the reference's)")
-    ap.add_argument("--tape", choices=["keep", "recompute"], default="keep",
-                    help="fit / train: keep every layer output for the backward (default) or re-run each sub-batch's forward inside its "
-                         "backward (labelled variant: Renderer.tape_recompute)")
+    ap.add_argument("--tape", choices=["keep", "recompute", "fp32"], default="keep",
+                    help="fit / train: what the forward keeps for the backward.  keep (default) = training: every layer output (fp32 tape); "
+                         "fitting: one bit per activation (mask-only tape).  fp32 = fitting with the fp32 tape (labelled A/B arm).  recompute = "
+                         "re-run each sub-batch's forward inside its backward (labelled variant: Renderer.tape_recompute)")
     ap.add_argument("--size", type=int, default=512, help="image side (512 = the benchmark; smaller only for functional tests)")
     ap.add_argument("--variant-steps", type=int, default=3, help="frames of the labelled fine-256x8 series after the headline loop (BASELINE.md "
                     "section 2 asks for both series; render mode, N = 1, shipped --arch only; 0 = skip)")
@@ -315,6 +316,8 @@ def main():
     if a.netchunk:
         render.netchunk = int(a.netchunk)
     render.tape_recompute = a.tape == "recompute"
+    if a.tape == "fp32":
+        render.fit_tape = "fp32"
     bm, tex, exp = (t.to(dev) for t in synth.codes(0))
     K = synth.intrinsics(H, W)
     n_total = H * W
@@ -389,6 +392,8 @@ def main():
         step(i)
     sync()
     comm_ms.clear()
+    mem0 = torch.cuda.memory_allocated(dev)
+    torch.cuda.reset_peak_memory_stats(dev)
     lib.check(L.mofa_prof_begin(), "mofa_prof_begin")
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -398,6 +403,7 @@ def main():
     NK = lib.PROF_KINDS
     ms, launches, pflops = (ctypes.c_double * NK)(), (ctypes.c_int64 * NK)(), (ctypes.c_double * NK)()
     lib.check(L.mofa_prof_end(ms, launches, pflops), "mofa_prof_end")
+    peak_extra = torch.cuda.max_memory_allocated(dev) - mem0           # what one step allocates on top of the resident state
     dt = mdist.barrier_max(dt, dev)
     comm = sum(e0.elapsed_time(e1) for e0, e1 in comm_ms) / max(1, len(comm_ms)) if comm_ms else 0.0
     if a.mode == "render":
@@ -453,6 +459,8 @@ def main():
             "config": {"workload": f"{workload}, 64 coarse + 128 fine samples/ray, coarse {ARCH[1]}x{ARCH[0]} + fine {ARCH[3]}x{ARCH[2]}, "
                                    f"chunk=196608, netchunk={int(a.netchunk) if a.netchunk else 196608}{' (VARIANT: the benchmark is netchunk=196608)' if a.netchunk and a.netchunk != 196608 else ''}, seeded Xavier weights (BASELINE.json configs[{ {'render': 1, 'fit': 2, 'train': 4}[a.mode] }])",
                        "mode": a.mode, **({"tape": "recompute (VARIANT: one extra forward per step, tape bounded by netchunk)"} if a.tape == "recompute" else {}),
+                       **({"tape": "fp32 (VARIANT: the fitting default is the mask-only tape, one bit per activation)"} if a.tape == "fp32" else {}),
+                       **({"step_peak_extra_memory_gb": round(peak_extra / 2 ** 30, 3)} if a.mode != "render" else {}),
                        "rays_per_step": units_per_step, "rays_per_rank_per_step": units_per_step // world,
                        "parallelism": par,
                        "gflop_per_ray_folded": round(work / 1e9, 4),
