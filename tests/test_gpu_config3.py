@@ -2,8 +2,8 @@
 expression x two views through ``render_path`` at 256 x 256 (the script halves hwf, render_refine_trainSet.py:288-295), the SHIPPED
 network widths (coarse 256 x 8, fine 1024 x 10), the texture encoder on a 512 x 512 UV map, PNGs through one shared asynchronous sink
 (models/render_class.py:199-237).  Checked: (i) 256 rays of one frame teacher-forced against the CPU oracle at the north star's 1e-4
-(coarse pass ray by ray; the device's own resampled positions through the oracle's fine network + raw2outputs), those rays being
-bit-identical to the frame's pixels; (ii) the PNG files hold exactly ``to8b`` of the returned frames; (iii) a second call skips the
+(coarse pass ray by ray; the device's own resampled positions through the oracle's fine network + raw2outputs), those rays
+reproducing the frame's pixels; (ii) the PNG files hold exactly ``to8b`` of the returned frames; (iii) a second call skips the
 finished files (the bulk job's resume)."""
 import numpy as np
 import pytest
@@ -52,7 +52,9 @@ def test_config3_render_path_full_size_teacher_forced_and_png(tmp_path):
         rgb, disp, acc, ex = render.render(H, H, K, chunk=196608, rays=torch.stack([ro, rd], 0).to(DEV), shapeCodes=bm[:1], uvMap=uv[1], expType=7,
                                            verbose=True, **kw)
     frame = torch.from_numpy(rgbs[1]).reshape(-1, 3)
-    assert torch.equal(rgb.cpu(), frame[idx])                                  # the same pixels, whatever the chunking
+    # the same pixels as the frame's (its rays came from the device's ray kernel, viewdirs = d / |d| with correctly rounded sqrt and
+    # divide; a caller-built ray batch gets them from torch's norm on the GPU, an ulp away — so close, not bit-equal)
+    assert float((rgb.cpu() - frame[idx]).abs().max()) < 2e-5
     o = make_oracle(ARCH, 0, 196608, with_tex=True)
     torch.set_num_threads(min(16, torch.get_num_threads()))
     vd = rd / torch.norm(rd, dim=-1, keepdim=True)
