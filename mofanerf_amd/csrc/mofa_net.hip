@@ -23,7 +23,7 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
                                 long long m_padded, int n_layers, const long long* x1_off, const long long* x2_off,
                                 const long long* y_off, const long long* w_off, const long long* bias_off, const int* k1p,
                                 const int* k2p, const int* n_padded, const int* bias_row_div, int pe_feats,
-                                unsigned long long* mask_bits, const long long* mask_off, void* stream);
+                                unsigned long long* mask_bits, const long long* mask_off, const int* store_out, int resident_ok, void* stream);
 int mofa_internal_mask_pack(const float* y, long long n_floats, unsigned long long* bits, void* stream);
 int mofa_internal_head_weight_grad_split(const float* d_raw, int32_t raw_off, int32_t n_out, const float* x, int32_t k_padded,
                                          int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, float* workspace,
@@ -46,7 +46,8 @@ namespace {
 Config read_env() {
     Config c;
     auto tri = [](const char* name) { const char* e = getenv(name); return e ? (e[0] == '1' ? 1 : 0) : -1; };
-    c.fused = tri("MOFA_FUSED"), c.pipe = tri("MOFA_PIPE");
+    c.fused = tri("MOFA_FUSED"), c.pipe = tri("MOFA_PIPE"), c.resident = tri("MOFA_RESIDENT");
+    if (const char* e = getenv("MOFA_RESIDENT")) c.resident = atoi(e);     // 0: off; 4 / 8 (experiment): waves per workgroup; else the default form
     return c;
 }
 // two slots + an atomic index: readers never see a half-written snapshot, reload is rare and host-side only
@@ -134,8 +135,11 @@ Plan make_plan(MofaNetShape s) {
         first = (int)p.L.size();
         p.L.push_back(l0);
         for (int i = 1; i <= 4; ++i) p.L.push_back(plain(W, W));
-        Layer ls = plain(W, cin + 2 * W);  // input [code | x | h]  (models/model.py:215,229)
-        ls.nsrc = 2, ls.col0[0] = cin, ls.ncols[0] = W, ls.col0[1] = cin + W, ls.ncols[1] = W;
+        // input [code | x | h] (models/model.py:215,229).  The contraction walks h FIRST, then x (part 0 = the h columns, part 1 = the
+        // x columns): h is the previous layer's output — still on chip in the persistent kernels — while x comes back from memory.
+        // (Which half is summed first is a free choice — the reference's GEMM fixes none — but it is ONE choice for every kernel here.)
+        Layer ls = plain(W, cin + 2 * W);
+        ls.nsrc = 2, ls.col0[0] = cin + W, ls.ncols[0] = W, ls.col0[1] = cin, ls.ncols[1] = W;
         ls.k_padded[0] = Wp, ls.k_padded[1] = Wp, ls.fold = fold, ls.fold_col0 = 0, ls.fold_cols = cin;
         skip = (int)p.L.size();
         p.L.push_back(ls);
@@ -360,7 +364,7 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
         const int last = skip + (s.D - 5) - 1;
         for (int li = skip; li <= last; ++li) {
             float* y = slot(li, (li == last) ? out_fb : pp[w]);
-            steps.push_back({li, li == skip ? x : cur, li == skip ? cur : nullptr, y});
+            steps.push_back({li, cur, li == skip ? x : nullptr, y});        // skip layer: [h | x] (see make_plan)
             cur = y, w ^= 1;
         }
         return const_cast<float*>(cur);
@@ -385,7 +389,7 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
         const float* arena = tape ? tape : workspace;
         const int n = (int)steps.size();
         std::vector<long long> x1(n), x2(n), yo(n), wo(n), bo(n), mo(n);
-        std::vector<int> k1(n), k2(n), np(n), div(n);
+        std::vector<int> k1(n), k2(n), np(n), div(n), keep(n);
         for (int i = 0; i < n; ++i) {
             const Layer& l = p.L[steps[i].li];
             x1[i] = steps[i].x1 ? steps[i].x1 - arena : -1;
@@ -397,11 +401,14 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
             k1[i] = l.k_padded[0] / 16, k2[i] = steps[i].x2 ? l.k_padded[1] / 16 : 0;
             np[i] = l.n_padded, div[i] = view ? S : 0;
             mo[i] = mword(steps[i].li);
+            // outputs something OUTSIDE the layer chain reads (the LDS-resident kernel writes only these to memory): the two stack
+            // inputs the skip layers re-read — xyz_code, sigmaCodes (also the alpha head's input) — and the view layer's (rgb head)
+            keep[i] = steps[i].y == xyz || steps[i].y == sigma || view;
         }
         MOFA_TRY(mofa_internal_fused_forward(arena, const_cast<float*>(arena), packed, folded, view_bias_rows, n_rays, rays_o,
                                              rays_d, z, z_row_stride, pts, M, S, Mp, n, x1.data(), x2.data(), yo.data(),
                                              wo.data(), bo.data(), k1.data(), k2.data(), np.data(), div.data(), 3 + 6 * s.pe_point_freqs,
-                                             mbits, mo.data(), stream));
+                                             mbits, mo.data(), keep.data(), !tape && !mask_tape, stream));
         if (mask_tape) {  // the view layer's per-ray-bias epilogue is not the contiguous-store one: its bits come from a pass over its output
             MOFA_TRY(mofa_internal_mask_pack(v, (long long)Mp * p.L[p.view].n_padded, mbits + mword(p.view), stream));
         }
@@ -537,10 +544,10 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
             std::swap(cur, spare);
         }
         MOFA_TRY(bgrad(skip, cur));
-        MOFA_TRY(wgrad(skip, 0, cur, xin));
-        MOFA_TRY(wgrad(skip, 1, cur, T(skip - 1)));
-        MOFA_TRY(bdata(skip, 0, cur, kNoMask, 0, gx));               // x part of [x | h]
-        MOFA_TRY(bdata(skip, 1, cur, Mk(skip - 1), 0, spare));       // h part, masked by linears1's last ReLU
+        MOFA_TRY(wgrad(skip, 0, cur, T(skip - 1)));                  // part 0 = the h columns, part 1 = the x columns (make_plan)
+        MOFA_TRY(wgrad(skip, 1, cur, xin));
+        MOFA_TRY(bdata(skip, 1, cur, kNoMask, 0, gx));               // x part of [x | h]
+        MOFA_TRY(bdata(skip, 0, cur, Mk(skip - 1), 0, spare));       // h part, masked by linears1's last ReLU
         std::swap(cur, spare);
         for (int li = skip - 1; li > first; --li) {
             MOFA_TRY(bgrad(li, cur));

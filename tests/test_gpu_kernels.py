@@ -600,17 +600,26 @@ def test_persistent_fused_network_is_bit_identical_to_per_layer_launches(D, W, R
     bm, tex, e = synth.codes(3)
     folded = h.fold(e.to(DEV), bm.to(DEV), tex.to(DEV)).clone()
     outs, tapes = {}, {}
-    for mode in ("0", "1"):
-        knob("MOFA_FUSED", mode)
+    # per-layer launches / persistent kernels; among the persistent ones, inference of 256-wide layers takes the LDS-resident kernel
+    # (k_mlp_resident) unless MOFA_RESIDENT=0 (then the two-workgroup pipelined k_mlp_fused); tape forwards take k_mlp_fused[_generic]
+    for mode, (fused, resident) in {"0": ("0", "1"), "1": ("1", "1"), "2": ("1", "0")}.items():
+        knob("MOFA_FUSED", fused)
+        knob("MOFA_RESIDENT", resident)
         raw = torch.full((R, S, 4), float("nan"), device=DEV)
         h.forward_rays(o, d, z, S, vd, S, raw, folded)
         outs[mode] = raw.clone()
-        with torch.enable_grad():
-            tapes[mode] = NetFn.apply(h, o, d, z, S, S, folded, view_bias_torch(h, vd).detach(), None).detach().clone()
+        for fp32 in (False, True):
+            h.force_fp32_tape = fp32
+            with torch.enable_grad():
+                tapes[(mode, fp32)] = NetFn.apply(h, o, d, z, S, S, folded, view_bias_torch(h, vd).detach(), None).detach().clone()
+        h.force_fp32_tape = False
         torch.cuda.synchronize()
-    assert torch.equal(outs["0"], outs["1"]) and torch.isfinite(outs["1"]).all()
-    assert torch.equal(tapes["0"], tapes["1"])
-    nan_equal_close(tapes["1"].cpu().numpy(), outs["1"].cpu().numpy(), 2e-5)
+    assert torch.isfinite(outs["1"]).all()
+    for mode in ("1", "2"):
+        assert torch.equal(outs["0"], outs[mode]), mode
+        for fp32 in (False, True):
+            assert torch.equal(tapes[("0", False)], tapes[(mode, fp32)]), (mode, fp32)
+    nan_equal_close(tapes[("1", True)].cpu().numpy(), outs["1"].cpu().numpy(), 2e-5)
 
 
 @pytest.mark.parametrize("D,W,R,S", [(8, 256, 300, 64), (10, 256, 90, 128), (8, 192, 77, 64), (8, 64, 50, 64), (10, 1024, 40, 128)])

@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
-"""Timing-only A/B of the persistent network kernel (k_mlp_fused) on the 256x8 + 256x8 variant: one 512x512 frame per arm per
-round, arms interleaved, rays/s by wall clock around synchronised frames.  MOFA_DEPHASE carries EXPERIMENT bits (timing-only arms
-produce wrong pixels): see the arms list."""
+"""A/B of the persistent network kernels on the 256x8 + 256x8 variant: 512x512 frames, arms interleaved, rays/s by wall clock around
+synchronised frames.  Arms are settings of the library's bit-identical run-time knobs (name=ENV:VALUE[,ENV:VALUE]).
+
+    python tools/ab_fused.py resident=MOFA_RESIDENT:1 pipelined=MOFA_RESIDENT:0 perlayer=MOFA_FUSED:0"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from mofanerf_amd import lib, synth
 
-arms = [a.split("=") for a in (sys.argv[1:] or ["base=0", "nostore=1", "noepi=2"])]
+arms = [a.split("=") for a in (sys.argv[1:] or ["resident=MOFA_RESIDENT:1", "pipelined=MOFA_RESIDENT:0", "perlayer=MOFA_FUSED:0"])]
 bench.ARCH = (8, 256, 8, 256)
 dev = torch.device("cuda", 0)
 render, kw, args = bench.build_product(dev)
@@ -17,14 +18,23 @@ K = synth.intrinsics(512, 512)
 pose = bench.pose_spherical(0.0, 0.0, 16.0)[:3, :4].to(dev)
 def frame():
     with torch.no_grad():
-        render.render_fitting(512, 512, K, chunk=args.chunk, c2w=pose, shapeCodes=bm, uvCodes=tex, expType=20, expCodes=exp, **kw)
+        return render.render_fitting(512, 512, K, chunk=args.chunk, c2w=pose, shapeCodes=bm, uvCodes=tex, expType=20, expCodes=exp, **kw)[0]
+def setenv(spec):
+    for k in ("MOFA_RESIDENT", "MOFA_FUSED", "MOFA_PIPE"):
+        os.environ.pop(k, None)
+    for kv in spec.split(","):
+        k, v = kv.split(":")
+        os.environ[k] = v
+    lib.reload_env()
 res = {n: [] for n, _ in arms}
+ref = None
 for rnd in range(4):
-    for name, val in arms:
-        os.environ["MOFA_DEPHASE"] = val
-        lib.reload_env()
+    for name, spec in arms:
+        setenv(spec)
         if rnd == 0:
-            frame()
+            out = frame()
+            ref = out.clone() if ref is None else ref
+            print(f"{name:12s} bit-identical to the first arm: {bool(torch.equal(out, ref))}", flush=True)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         frame(); frame()
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
