@@ -55,9 +55,8 @@ int mofa_abi_version(void);
 const char* mofa_last_error(void);   /* thread-local text of the calling thread's last failure */
 
 /* Library-wide state is limited to what is listed here; everything else is in caller-owned buffers.
- *   - three run-time knobs, each choosing between BIT-IDENTICAL forms of the exact-fp32 path — MOFA_PIPE=0 (plain instead of
- *     software-pipelined K loops), MOFA_FUSED=0/1 (per-layer launches / persistent network kernel), MOFA_RESIDENT=0 (inference of
- *     256-wide networks through the two-workgroup persistent kernel instead of the LDS-resident one); there is no reduced-precision
+ *   - two run-time knobs, each choosing between BIT-IDENTICAL forms of the exact-fp32 path — MOFA_PIPE=0 (plain instead of
+ *     software-pipelined K loops), MOFA_FUSED=0/1 (per-layer launches / persistent network kernel); there is no reduced-precision
  *     mode: read from the environment ONCE when the library is loaded into an immutable snapshot;
  *     no launch path calls getenv.  mofa_config_reload() re-reads them (tests that change a knob inside one process call it explicitly).
  *     Measurement arms (scheduling experiments, time stamps, ablations) are NOT in this library: csrc/measure/, tools/build_measure.py.

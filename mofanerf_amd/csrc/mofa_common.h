@@ -52,7 +52,6 @@ int check_launch(const char* what);
 // -1 = "not set: use the built-in heuristic".
 struct Config {
     int fused = -1;       // MOFA_FUSED=0/1: persistent whole-network kernel off / on
-    int resident = -1;    // MOFA_RESIDENT=0: inference never takes the LDS-resident persistent kernel (k_mlp_resident); bit-identical
     int pipe = -1;        // MOFA_PIPE=0: the plain K loops (layer kernel, persistent kernel, weight gradient) instead of the pipelined ones
 };
 const Config& config();

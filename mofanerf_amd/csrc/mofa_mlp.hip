@@ -193,7 +193,6 @@ struct FusedLayer {
     long long bias_off;               // into `folded` (bias_row_div == 0) or into `view_bias_rows`
     long long mask_off;               // mask-only tape: 64-bit word offset of this layer's bits (MASKW kernels only)
     int k1p, k2p, n_padded, bias_row_div;
-    int store_out;                    // k_mlp_resident: something outside the tile chain reads this output (a skip layer, a head)
 };
 
 struct FusedArgs {
@@ -210,7 +209,6 @@ struct FusedArgs {
     int S, n_layers, m_tiles;
     int pipe;             // 1: full 256-feature blocks use kloop_pipelined (MOFA_PIPE != 0)
     int pe_feats;         // 3 + 6 * multires
-    int resident_ok;      // inference (no tape of either kind): the activations may stay in LDS (k_mlp_resident)
     unsigned long long* mask_bits;   // mask-only tape (MASKW) or NULL
     FusedLayer L[kMaxFusedLayers];
 };
@@ -754,337 +752,6 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
     }
 }
 
-// ======================================================================================================
-// k_mlp_resident: the whole network of a 128-point tile with the ACTIVATIONS RESIDENT IN LDS (inference; the same 256-wide shape as
-// k_mlp_fused).  One workgroup per CU owns all 160 KiB of LDS: the tile's activations — 16 operand panels [128 points][16 features],
-// 128 KiB, in exactly the layout the MFMA fragments are read from — plus a two-stage ring for the streamed weight panels (2 x 16 KiB).
-// A layer reads its operand panels straight out of the tile, and once every wave holds its last fragments (one barrier) the tile is
-// dead, so the epilogue writes bias + ReLU of the accumulators IN PLACE as the next layer's operand panels: no staging window, no
-// read-back, no global store, no operand re-fetch — the 128 KiB per layer and tile that the two-workgroup kernels push through the
-// CU's vector-memory pipeline twice (profiles/r04_ab_fused_epilogue.txt: +2.9 % without the stores alone) never leave the CU.  Only
-// what something outside the tile chain reads goes to memory: the two stack inputs the skip layers re-read (their contraction walks
-// the resident h first and then the re-loaded x, make_plan), the sigma features (alpha head) and the view layer's output (rgb head).
-// Weights stream through the ring with the pipelined loop's schedule (requests in the MFMA shadow, the next layer's first panels
-// requested before this layer's epilogue); the epilogue itself runs under the last half panel's MFMAs, accumulator pair by pair.
-// One wave per SIMD (a lone wave sustains ~97 % of the matrix pipe inside this loop), up to 512 registers.
-// Same MFMA order and epilogue arithmetic as every other path: bit-identical.
-// ======================================================================================================
-constexpr int kRsTile = 16 * 128 * 16;             // floats: the activation tile (16 panels x 128 points x 16)
-constexpr int kRsStage = 256 * 16;                 // floats per weight-ring stage
-constexpr int kRsFloats = kRsTile + 2 * kRsStage;  // 40,960 floats = 163,840 B = all of a CU's LDS
-
-// NW waves per workgroup (4: one per SIMD, 64 features x 128 points each; 8: two per SIMD, 64 x 64 each — the second wave of a SIMD
-// covers the first one's LDS-DMA issue and barrier waits).  NJ: 32-point blocks per wave.  BN: feature rows of this layer's weight
-// panels.  NBN: rows of the NEXT layer's panel 0, requested in the tail (0: none).  EPI: in-place epilogue inside the tail.
-struct ResidentEpi {
-    int n_first;                      // this wave's first feature
-    float* y;                         // global panels of this layer's output, or nullptr when nothing outside the tile reads it
-    long long m_padded, m_first;      // (m_first: the tile's first point)
-};
-
-template <int NW, int NJ, int BN, int NBN, bool EPI, class Pre, bool XP_NODMA = false>
-__device__ __forceinline__ void kloop_resident(const float* wb, long long wstep, int KT, float* tile, float* ring, int tid, int wave, int lane,
-                                               int xrow0, int wrow0, f32x16 (&acc)[2][NJ], const float* nwb, const ResidentEpi* ep, Pre pre,
-                                               const f32x4 (&bv)[2][4]) {
-    constexpr int NI = 2, WR = BN / 16 / NW, NWR = NBN / 16 / NW;        // 1 KiB pieces per wave and panel
-    static_assert(WR >= 1 && (NBN == 0 || NWR >= 1), "a weight panel has fewer 1 KiB pieces than the workgroup has waves");
-    const int lr = lane & 31, g = lane >> 5, sw = (lane >> 2) & 3;
-    unsigned toff = (unsigned)tid * 4u;
-    asm volatile("" : "+v"(toff));
-    float* const ring_wave = ring + wave * 256;
-    wb += 2 * wstep;                             // weight panels 0 and 1 are resident in the ring
-    const float* xp = tile;                      // operand panel kt of the resident tile
-
-    struct Frag {
-        f32x4 a[NI], b[NJ];
-    };
-    auto request = [&](int stage) {
-        float* ws = ring_wave + stage * kRsStage;
-        if (!XP_NODMA) {
-#pragma unroll
-        for (int r = 0; r < WR; ++r) glds16(wb + (r * (NW * 256u) + toff), ws + r * (NW * 256));
-        }
-        wb += wstep;
-    };
-    auto request_next = [&]() {
-        if (!XP_NODMA) {
-#pragma unroll
-        for (int r = 0; r < NWR; ++r) glds16(nwb + (r * (NW * 256u) + toff), ring_wave + r * (NW * 256));
-        }
-    };
-    auto read = [&](int stage, const float* Xt, int h, Frag& f) {
-        const float* Wt = ring + stage * kRsStage;
-        const int p = ((2 * h + g) ^ sw) << 2;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) f.a[i] = *(const f32x4*)(Wt + (wrow0 + 32 * i + lr) * 16 + p);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) f.b[j] = *(const f32x4*)(Xt + (xrow0 + 32 * j + lr) * 16 + p);
-    };
-    auto mfma_half = [&](const Frag& f) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[j][e], acc[i][j], 0, 0, 0);
-    };
-    auto half_a = [&](int stage, Frag& cur, Frag& nxt) {           // MFMAs of the first half, reads of the second
-        __builtin_amdgcn_sched_barrier(0);
-        read(stage, xp, 1, nxt);
-        mfma_half(cur);
-#pragma unroll
-        for (int q = 0; q < NI + NJ; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NI * NJ, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto sync_point = [&]() {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-    auto half_b = [&](int stage, auto kind_c, bool do_read, Frag& cur, Frag& nxt) {   // MFMAs of the second half; kind 1: my next panel, 2: next layer's
-        constexpr int kind = decltype(kind_c)::value;
-        __builtin_amdgcn_sched_barrier(0);
-        if (do_read) read(stage ^ 1, xp + 128 * 16, 0, nxt);
-        if constexpr (kind == 1) request(stage);
-        if constexpr (kind == 2) request_next();
-        mfma_half(cur);
-        if (do_read) {
-#pragma unroll
-            for (int q = 0; q < NI + NJ; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-        }
-        constexpr int nreq = kind == 1 ? WR : (kind == 2 ? NWR : 0);
-        if constexpr (nreq > 0 && 4 * NI * NJ - (NI + NJ) >= nreq) {
-            constexpr int gap = (4 * NI * NJ - (NI + NJ)) / nreq;
-#pragma unroll
-            for (int q = 0; q < nreq; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, gap, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NI * NJ, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        xp += 128 * 16;
-    };
-
-    Frag fa, fb;
-    read(0, xp, 0, fa);
-    for (int kt = 0; kt + 2 < KT; kt += 2) {
-        half_a(0, fa, fb);
-        sync_point();
-        half_b(0, std::integral_constant<int, 1>{}, true, fb, fa);
-        half_a(1, fa, fb);
-        sync_point();
-        half_b(1, std::integral_constant<int, 1>{}, true, fb, fa);
-    }
-    half_a(0, fa, fb);
-    sync_point();
-    half_b(0, std::integral_constant<int, (NWR > 0 ? 2 : 0)>{}, true, fb, fa);
-    half_a(1, fa, fb);
-    if constexpr (!EPI) {
-        half_b(1, std::integral_constant<int, 0>{}, false, fb, fa);
-    } else {
-        static_assert(NJ % 2 == 0, "in-place epilogue: accumulator pairs of 64 points");
-        // every wave holds its last fragments: the tile and both ring stages are free after this barrier (and the next layer's weight
-        // panel 0, requested half a panel ago, has landed)
-        sync_point();
-        pre();                                   // the next layer's weight panel 1: under the MFMAs below
-        const int msw = (lr >> 2) & 3;
-        int wo0 = (xrow0 + lr) * 16 + (((0 + g) ^ msw) << 2), wo1 = (xrow0 + lr) * 16 + (((2 + g) ^ msw) << 2);
-        asm volatile("" : "+v"(wo0), "+v"(wo1));
-        float* const tw = tile + (ep->n_first >> 4) * (128 * 16);          // this wave's four output panels of the tile
-        auto slices = [&](int i, int jh) {                                 // accumulator pair (i, jh): features 32 i .. + 31, points 64 jh .. + 63 of the wave's
-#pragma unroll
-            for (int qh = 0; qh < 2; ++qh)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int qq = 0; qq < 2; ++qq) {
-                        const int j = 2 * jh + jj, q = 2 * qh + qq;
-                        f32x4 v;
-                        v.x = acc[i][j][4 * q + 0] + bv[i][q].x, v.y = acc[i][j][4 * q + 1] + bv[i][q].y;
-                        v.z = acc[i][j][4 * q + 2] + bv[i][q].z, v.w = acc[i][j][4 * q + 3] + bv[i][q].w;
-                        v.x = relu_np(v.x), v.y = relu_np(v.y), v.z = relu_np(v.z), v.w = relu_np(v.w);
-                        *(f32x4*)(tw + ((2 * i + qh) * 128 + 32 * j) * 16 + (qq ? wo1 : wo0)) = v;
-                    }
-        };
-        constexpr int NG = NI * (NJ / 2);
-#pragma unroll
-        for (int G = 0; G < NG; ++G) {
-            const int i = G / (NJ / 2), jh = G % (NJ / 2);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-                    acc[i][2 * jh + jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb.a[i][e], fb.b[2 * jh + jj][e], acc[i][2 * jh + jj], 0, 0, 0);
-            if (G > 0) slices((G - 1) / (NJ / 2), (G - 1) % (NJ / 2));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        slices((NG - 1) / (NJ / 2), (NG - 1) % (NJ / 2));
-        if (ep->y) {      // (wave-uniform) somebody outside the tile chain reads this output: copy my part of my four panels out, 1 KiB per store
-            int ro = xrow0 * 16 + lane * 4;
-            asm volatile("" : "+v"(ro));
-#pragma unroll 1
-            for (int pnl = 0; pnl < 4; ++pnl) {
-                float* __restrict__ dst = ep->y + ((long long)((ep->n_first >> 4) + pnl) * ep->m_padded + ep->m_first) * 16;
-                f32x4 r[2 * NJ];
-#pragma unroll
-                for (int it = 0; it < 2 * NJ; ++it) r[it] = *(const f32x4*)(tw + pnl * (128 * 16) + it * 256 + ro);
-#pragma unroll
-                for (int it = 0; it < 2 * NJ; ++it) *(f32x4*)(dst + it * 256 + ro) = r[it];
-            }
-        }
-    }
-}
-
-template <int NW, bool XP = false>
-__global__ __launch_bounds__(64 * NW, 1) void k_mlp_resident(const FusedArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TM = 128, NI = 2, WM = NW / 4, NJ = 4 / WM;       // waves: 4 (features) x WM (points); 32-point blocks per wave
-    float* const tile = smem;
-    float* const ring = smem + kRsTile;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 3, wm = wave >> 2;
-    const int half_tiles = a.m_tiles * 2;
-    const int nl = a.n_layers;
-    float* const ring_wave = ring + wave * 256;
-
-    // weight panels [p0, 2) of layer nx into the ring
-    auto w_prefetch = [&](const FusedLayer& nx, int p0) {
-        unsigned toff = (unsigned)tid * 4u;
-        asm volatile("" : "+v"(toff));
-        const int wr = nx.n_padded / 16 / NW;                             // 1 KiB pieces per wave
-        for (int p = p0; p < 2; ++p) {
-            const float* wp = a.packed + nx.w_off + (long long)p * nx.n_padded * 16;
-            for (int r = 0; r < wr; ++r) glds16(wp + (r * (NW * 256u) + toff), ring_wave + p * kRsStage + r * (NW * 256));
-        }
-    };
-    // the 16 operand panels of a stack input back into the tile (the x half of a skip layer): 128 pieces of 1 KiB
-    auto tile_reload = [&](long long x_off, long long m0) {
-        unsigned toff = (unsigned)tid * 4u;
-        asm volatile("" : "+v"(toff));
-#pragma unroll 1
-        for (int p = 0; p < 16; ++p) {
-            const float* src = a.arena + x_off + ((long long)p * a.m_padded + m0) * 16;
-#pragma unroll
-            for (int r = 0; r < 8 / NW; ++r) glds16(src + (r * (NW * 256u) + toff), tile + p * (TM * 16) + wave * 256 + r * (NW * 256));
-        }
-    };
-
-    for (int ht = blockIdx.x; ht < half_tiles; ht += gridDim.x) {
-        const long long m0 = (long long)ht * TM;
-        // ---------------- the point encoding of the tile: operand panels 0 .. pe_k/16 - 1 of the (free) tile ----------------
-        w_prefetch(a.L[0], 0);                                            // layer 0's first two weight panels land meanwhile
-        {
-            float px, py, pz;
-            long long m = m0 + (tid & (TM - 1));
-            if (m >= a.n_points) m = a.n_points - 1;
-            if (a.pts) {
-                px = a.pts[m * 3 + 0], py = a.pts[m * 3 + 1], pz = a.pts[m * 3 + 2];
-            } else {
-                const long long r = m / a.S;
-                const int s = (int)(m - r * a.S);
-                const float zz = a.z[r * a.z_row_stride + s];
-                px = __fadd_rn(a.rays_o[r * 3 + 0], __fmul_rn(a.rays_d[r * 3 + 0], zz));
-                py = __fadd_rn(a.rays_o[r * 3 + 1], __fmul_rn(a.rays_d[r * 3 + 1], zz));
-                pz = __fadd_rn(a.rays_o[r * 3 + 2], __fmul_rn(a.rays_d[r * 3 + 2], zz));
-            }
-            constexpr int KPT = 32 / NW;                                  // features of a 16-wide panel per thread
-            const int row = tid & (TM - 1), k0 = (tid >> 7) * KPT;
-            const int swz = (row >> 2) & 3;
-#pragma unroll 1
-            for (int kt = 0; kt < a.L[0].k1p; ++kt)
-#pragma unroll 1
-                for (int kk = k0; kk < k0 + KPT; ++kk) {
-                    const float v = pe_feature(kt * 16 + kk, px, py, pz, a.pe_feats);
-                    tile[kt * (TM * 16) + row * 16 + ((((kk >> 2) & 3) ^ swz) << 2) + (kk & 3)] = v;
-                }
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // ---------------- layer 0 and the ordinary layers: operands from the tile, output back into the tile ----------------
-        for (int li = 0; li < nl - 1; ++li) {
-            const FusedLayer& l = a.L[li];
-            const FusedLayer& nx = a.L[li + 1];
-            f32x16 acc[NI][NJ];
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-            const float* wb = a.packed + l.w_off;
-            const float* nwb = a.packed + nx.w_off;
-            const ResidentEpi ep{wn * 64, l.store_out ? const_cast<float*>(a.arena) + l.y_off : nullptr, a.m_padded, m0};
-            f32x4 bv[NI][4];                     // the wave's bias quads: fetched now (registers are plentiful here), used in the tail
-            {
-                int boff = wn * 64 + 4 * (lane >> 5);
-                asm volatile("" : "+v"(boff));
-                const float* bias = a.folded + l.bias_off;
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) bv[i][q] = *(const f32x4*)(bias + boff + 32 * i + 8 * q);
-            }
-            auto pre = [&]() { w_prefetch(nx, 1); };
-            auto none = [&]() {};
-            const int xrow0 = wm * (32 * NJ);
-            if (l.k2p) {
-                // skip layer: the resident h half first (no epilogue; its tail requests the x half's first weight panel) ...
-                kloop_resident<NW, NJ, 256, 256, false>(wb, 256 * 16, l.k1p, tile, ring, tid, wave, lane, xrow0, wn * 64, acc,
-                                                        wb + (long long)l.k1p * 256 * 16, nullptr, none, bv);
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                              // the tile is dead: bring the stack input x back into it,
-                tile_reload(l.x2_off, m0);                                 // with the x half's weight panel 1
-                {
-                    unsigned toff = (unsigned)tid * 4u;
-                    asm volatile("" : "+v"(toff));
-                    const float* wp = wb + (long long)(l.k1p + 1) * 256 * 16;
-#pragma unroll
-                    for (int r = 0; r < 16 / NW; ++r) glds16(wp + (r * (NW * 256u) + toff), ring_wave + kRsStage + r * (NW * 256));
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                wb += (long long)l.k1p * 256 * 16;                         // ... then the x half, with the in-place epilogue
-            }
-            const int KT = l.k2p ? l.k2p : l.k1p;
-            if (nx.n_padded == 256) kloop_resident<NW, NJ, 256, 256, true, decltype(pre), XP>(wb, 256 * 16, KT, tile, ring, tid, wave, lane, xrow0, wn * 64, acc, nwb, &ep, pre, bv);
-            else kloop_resident<NW, NJ, 256, 128, true, decltype(pre), XP>(wb, 256 * 16, KT, tile, ring, tid, wave, lane, xrow0, wn * 64, acc, nwb, &ep, pre, bv);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // my part of the new tile is written
-            __builtin_amdgcn_s_barrier();
-        }
-        // ---------------- the view layer: 128 features x 128 points on 2 x (NW / 2) waves, per-ray bias rows, output to memory ----------------
-        {
-            const FusedLayer& l = a.L[nl - 1];
-            constexpr int VJ = 8 / NW;                                     // 32-point blocks per wave: 2 (4 waves) or 1 (8 waves)
-            f32x16 acc[NI][VJ];
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < VJ; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-            const int wn2 = wave & 1, wm2 = wave >> 1;
-            auto none = [&]() {};
-            f32x4 bv[NI][4];
-            kloop_resident<NW, VJ, 128, 0, false>(a.packed + l.w_off, 128 * 16, l.k1p, tile, ring, tid, wave, lane, wm2 * (32 * VJ), wn2 * 64, acc, nullptr,
-                                                  nullptr, none, bv);
-            store_tile<NI, VJ, true>(acc, a.view_bias_rows + l.bias_off, a.bias_rows, l.bias_row_div, 128, const_cast<float*>(a.arena) + l.y_off, a.m_padded,
-                                     m0 + wm2 * (32 * VJ), wn2 * 64, 1, lane, bv);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                                  // tile and ring are free for the next tile
-        }
-    }
-}
-
 // can this launch take the pipelined persistent kernel?  (the shape the north star names; everything else runs the generic one)
 bool fused_fast_shape(const FusedArgs& a) {
     if (!a.pipe || a.n_layers < 3) return false;
@@ -1104,30 +771,14 @@ int launch_fused(const FusedArgs& a, hipStream_t st) {
     const int cus = compute_units(dev);
     const int half_tiles = a.m_tiles * 2;
     const int grid = half_tiles < 2 * cus ? half_tiles : 2 * cus;      // two resident workgroups per CU
-    if (fused_fast_shape(a) && a.resident_ok && config().resident != 0) {
-        const size_t lds = (size_t)kRsFloats * sizeof(float);          // 160 KiB: all of a CU's LDS
-        if (!(g_fused_attr[dev].load(std::memory_order_acquire) & 2)) {
-            if (hipFuncSetAttribute((const void*)k_mlp_resident<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_mlp_resident<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return check_launch("hipFuncSetAttribute(k_mlp_resident)");
-            g_fused_attr[dev].fetch_or(2, std::memory_order_release);
-        }
-        const int g1 = half_tiles < cus ? half_tiles : cus;             // one workgroup per CU
-        if (config().resident == 4) hipLaunchKernelGGL(k_mlp_resident<4>, dim3(g1), dim3(256), lds, st, a);
-        else if (config().resident == 108) {      // TIMING-ONLY experiment (wrong pixels): the ordinary layers' in-loop weight requests skipped
-            (void)hipFuncSetAttribute((const void*)k_mlp_resident<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((k_mlp_resident<8, true>), dim3(g1), dim3(512), lds, st, a);
-        } else hipLaunchKernelGGL(k_mlp_resident<8>, dim3(g1), dim3(512), lds, st, a);
-        return check_launch("k_mlp_resident");
-    }
     // (a fitting forward — mask-only tape — takes the generic kernel: its four ballots per KiB of output do not fit the register file
     //  next to the pipelined kernel's fragments without spilling, and it runs 1,024 rays, not frames)
     if (fused_fast_shape(a) && !a.mask_bits) {
         const size_t lds = (size_t)kFsFloats * sizeof(float);          // 66 KiB: above the 64 KiB default limit of dynamic LDS
-        if (!(g_fused_attr[dev].load(std::memory_order_acquire) & 1)) {      // one-time function attribute per device
+        if (!g_fused_attr[dev].load(std::memory_order_acquire)) {      // one-time function attribute per device
             if (hipFuncSetAttribute((const void*)k_mlp_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return check_launch("hipFuncSetAttribute(k_mlp_fused)");
-            g_fused_attr[dev].fetch_or(1, std::memory_order_release);
+            g_fused_attr[dev].store(1, std::memory_order_release);
         }
         hipLaunchKernelGGL(k_mlp_fused<false>, dim3(grid), dim3(256), lds, st, a);
         return check_launch("k_mlp_fused");
@@ -1451,7 +1102,7 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
                                 long long m_padded, int n_layers, const long long* x1_off, const long long* x2_off,
                                 const long long* y_off, const long long* w_off, const long long* bias_off, const int* k1p,
                                 const int* k2p, const int* n_padded, const int* bias_row_div, int pe_feats,
-                                unsigned long long* mask_bits, const long long* mask_off, const int* store_out, int resident_ok, void* stream) {
+                                unsigned long long* mask_bits, const long long* mask_off, void* stream) {
     MOFA_REQUIRE(n_layers > 0 && n_layers <= kMaxFusedLayers, "fused_forward: %d layers (max %d)", n_layers, kMaxFusedLayers);
     MOFA_REQUIRE(m_padded > 0 && m_padded % kRowTile == 0, "fused_forward: m_padded=%lld", m_padded);
     FusedArgs a{};
@@ -1460,11 +1111,10 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
     a.z_row_stride = z_row_stride, a.n_points = n_points, a.m_padded = m_padded, a.bias_rows = bias_rows;
     a.S = S > 0 ? S : 1, a.n_layers = n_layers, a.m_tiles = (int)(m_padded / kRowTile);
     a.pipe = config().pipe != 0 ? 1 : 0;
-    a.pe_feats = pe_feats, a.mask_bits = mask_bits, a.resident_ok = resident_ok;
+    a.pe_feats = pe_feats, a.mask_bits = mask_bits;
     for (int i = 0; i < n_layers; ++i) {
         MOFA_REQUIRE(n_padded[i] > 0 && n_padded[i] % 64 == 0, "fused_forward: layer %d has n_padded=%d", i, n_padded[i]);
-        a.L[i] = FusedLayer{x1_off[i], x2_off[i], y_off[i], w_off[i], bias_off[i], mask_bits ? mask_off[i] : 0, k1p[i], k2p[i], n_padded[i], bias_row_div[i],
-                            store_out[i]};
+        a.L[i] = FusedLayer{x1_off[i], x2_off[i], y_off[i], w_off[i], bias_off[i], mask_bits ? mask_off[i] : 0, k1p[i], k2p[i], n_padded[i], bias_row_div[i]};
     }
     hipStream_t st = (hipStream_t)stream;
     if (!prof_enabled()) return launch_fused(a, st);

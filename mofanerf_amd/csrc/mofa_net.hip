@@ -23,7 +23,7 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
                                 long long m_padded, int n_layers, const long long* x1_off, const long long* x2_off,
                                 const long long* y_off, const long long* w_off, const long long* bias_off, const int* k1p,
                                 const int* k2p, const int* n_padded, const int* bias_row_div, int pe_feats,
-                                unsigned long long* mask_bits, const long long* mask_off, const int* store_out, int resident_ok, void* stream);
+                                unsigned long long* mask_bits, const long long* mask_off, void* stream);
 int mofa_internal_mask_pack(const float* y, long long n_floats, unsigned long long* bits, void* stream);
 int mofa_internal_head_weight_grad_split(const float* d_raw, int32_t raw_off, int32_t n_out, const float* x, int32_t k_padded,
                                          int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, float* workspace,
@@ -46,8 +46,7 @@ namespace {
 Config read_env() {
     Config c;
     auto tri = [](const char* name) { const char* e = getenv(name); return e ? (e[0] == '1' ? 1 : 0) : -1; };
-    c.fused = tri("MOFA_FUSED"), c.pipe = tri("MOFA_PIPE"), c.resident = tri("MOFA_RESIDENT");
-    if (const char* e = getenv("MOFA_RESIDENT")) c.resident = atoi(e);     // 0: off; 4 / 8 (experiment): waves per workgroup; else the default form
+    c.fused = tri("MOFA_FUSED"), c.pipe = tri("MOFA_PIPE");
     return c;
 }
 // two slots + an atomic index: readers never see a half-written snapshot, reload is rare and host-side only
@@ -389,7 +388,7 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
         const float* arena = tape ? tape : workspace;
         const int n = (int)steps.size();
         std::vector<long long> x1(n), x2(n), yo(n), wo(n), bo(n), mo(n);
-        std::vector<int> k1(n), k2(n), np(n), div(n), keep(n);
+        std::vector<int> k1(n), k2(n), np(n), div(n);
         for (int i = 0; i < n; ++i) {
             const Layer& l = p.L[steps[i].li];
             x1[i] = steps[i].x1 ? steps[i].x1 - arena : -1;
@@ -401,14 +400,11 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
             k1[i] = l.k_padded[0] / 16, k2[i] = steps[i].x2 ? l.k_padded[1] / 16 : 0;
             np[i] = l.n_padded, div[i] = view ? S : 0;
             mo[i] = mword(steps[i].li);
-            // outputs something OUTSIDE the layer chain reads (the LDS-resident kernel writes only these to memory): the two stack
-            // inputs the skip layers re-read — xyz_code, sigmaCodes (also the alpha head's input) — and the view layer's (rgb head)
-            keep[i] = steps[i].y == xyz || steps[i].y == sigma || view;
         }
         MOFA_TRY(mofa_internal_fused_forward(arena, const_cast<float*>(arena), packed, folded, view_bias_rows, n_rays, rays_o,
                                              rays_d, z, z_row_stride, pts, M, S, Mp, n, x1.data(), x2.data(), yo.data(),
                                              wo.data(), bo.data(), k1.data(), k2.data(), np.data(), div.data(), 3 + 6 * s.pe_point_freqs,
-                                             mbits, mo.data(), keep.data(), !tape && !mask_tape, stream));
+                                             mbits, mo.data(), stream));
         if (mask_tape) {  // the view layer's per-ray-bias epilogue is not the contiguous-store one: its bits come from a pass over its output
             MOFA_TRY(mofa_internal_mask_pack(v, (long long)Mp * p.L[p.view].n_padded, mbits + mword(p.view), stream));
         }

@@ -600,11 +600,11 @@ def test_persistent_fused_network_is_bit_identical_to_per_layer_launches(D, W, R
     bm, tex, e = synth.codes(3)
     folded = h.fold(e.to(DEV), bm.to(DEV), tex.to(DEV)).clone()
     outs, tapes = {}, {}
-    # per-layer launches / persistent kernels; among the persistent ones, inference of 256-wide layers takes the LDS-resident kernel
-    # (k_mlp_resident) unless MOFA_RESIDENT=0 (then the two-workgroup pipelined k_mlp_fused); tape forwards take k_mlp_fused[_generic]
-    for mode, (fused, resident) in {"0": ("0", "1"), "1": ("1", "1"), "2": ("1", "0")}.items():
+    # "0": per-layer launches; "1": persistent kernels (256-wide layers: the pipelined k_mlp_fused for inference and fp32-tape forwards,
+    # k_mlp_fused_generic for mask-tape forwards and every other width); "2": the same with the plain K loops (MOFA_PIPE=0: generic only)
+    for mode, (fused, pipe) in {"0": ("0", "1"), "1": ("1", "1"), "2": ("1", "0")}.items():
         knob("MOFA_FUSED", fused)
-        knob("MOFA_RESIDENT", resident)
+        knob("MOFA_PIPE", pipe)
         raw = torch.full((R, S, 4), float("nan"), device=DEV)
         h.forward_rays(o, d, z, S, vd, S, raw, folded)
         outs[mode] = raw.clone()

@@ -2,14 +2,14 @@
 """A/B of the persistent network kernels on the 256x8 + 256x8 variant: 512x512 frames, arms interleaved, rays/s by wall clock around
 synchronised frames.  Arms are settings of the library's bit-identical run-time knobs (name=ENV:VALUE[,ENV:VALUE]).
 
-    python tools/ab_fused.py resident=MOFA_RESIDENT:1 pipelined=MOFA_RESIDENT:0 perlayer=MOFA_FUSED:0"""
+    python tools/ab_fused.py pipelined=MOFA_FUSED:1 generic=MOFA_PIPE:0 perlayer=MOFA_FUSED:0"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from mofanerf_amd import lib, synth
 
-arms = [a.split("=") for a in (sys.argv[1:] or ["resident=MOFA_RESIDENT:1", "pipelined=MOFA_RESIDENT:0", "perlayer=MOFA_FUSED:0"])]
+arms = [a.split("=") for a in (sys.argv[1:] or ["pipelined=MOFA_FUSED:1", "generic=MOFA_PIPE:0", "perlayer=MOFA_FUSED:0"])]
 bench.ARCH = (8, 256, 8, 256)
 dev = torch.device("cuda", 0)
 render, kw, args = bench.build_product(dev)
@@ -20,7 +20,7 @@ def frame():
     with torch.no_grad():
         return render.render_fitting(512, 512, K, chunk=args.chunk, c2w=pose, shapeCodes=bm, uvCodes=tex, expType=20, expCodes=exp, **kw)[0]
 def setenv(spec):
-    for k in ("MOFA_RESIDENT", "MOFA_FUSED", "MOFA_PIPE"):
+    for k in ("MOFA_FUSED", "MOFA_PIPE"):
         os.environ.pop(k, None)
     for kv in spec.split(","):
         k, v = kv.split(":")

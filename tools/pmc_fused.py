@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Driver for rocprofv3 --pmc passes over the persistent network kernels: the shipped coarse network (256 x 8) forward on 196,608
 points (one sub-batch of the 512 x 512 frame: 1,536 tiles of 128 points), four launches per arm.  Arms = the library's bit-identical
-launch forms: `resident` (k_mlp_resident<8>), `pipelined` (k_mlp_fused<false>), `generic` (k_mlp_fused_generic<false>, MOFA_PIPE=0
-keeps its plain loops too).  tools/gpu_profile_fused.sh wraps it, one pass per counter group."""
+launch forms: `pipelined` (k_mlp_fused<false>, the default), `generic` (k_mlp_fused_generic<false> with its plain loops: MOFA_PIPE=0).
+(profiles/r04_pmc_fused_*.csv additionally hold the LDS-resident experiment's kernels, k_mlp_resident<4|8>, of commit a90d63b.)
+tools/gpu_profile_fused.sh wraps it, one pass per counter group."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +11,7 @@ from mofanerf_amd import lib, synth
 from mofanerf_amd.hipnet import HipNet
 from mofanerf_amd.model import NeRF
 
-arms = sys.argv[1:] or ["resident", "pipelined"]
+arms = sys.argv[1:] or ["pipelined", "generic"]
 net = NeRF(D=8, W=256, input_ch=93, input_ch_views=27, input_ch_textureCodes=256, input_ch_shapeCodes=50, use_viewdirs=True)
 net.load_state_dict(synth.nerf_state(8, 256, 0, "coarse"))
 h = HipNet(net.cuda())
@@ -23,10 +24,9 @@ vd = torch.nn.functional.normalize(d, dim=-1).contiguous()
 bm, tex, e = synth.codes(0)
 folded = h.fold(e.cuda(), bm.cuda(), tex.cuda()).clone()
 raw = torch.empty(R, S, 4, device="cuda")
-env = {"resident": {"MOFA_RESIDENT": "1"}, "resident4": {"MOFA_RESIDENT": "4"}, "pipelined": {"MOFA_RESIDENT": "0"},
-       "generic": {"MOFA_RESIDENT": "0", "MOFA_PIPE": "0"}}
+env = {"pipelined": {}, "generic": {"MOFA_PIPE": "0"}}
 for arm in arms:
-    for k in ("MOFA_RESIDENT", "MOFA_PIPE", "MOFA_FUSED"):
+    for k in ("MOFA_PIPE", "MOFA_FUSED"):
         os.environ.pop(k, None)
     os.environ.update(env[arm])
     lib.reload_env()
