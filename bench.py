@@ -48,7 +48,7 @@ ARCH = (8, 256, 10, 1024)
 N_SAMPLES, N_IMPORTANCE = 64, 64
 # (symbol, role, description) per profiler kind of libmofanerf_hip.so; k_layer's template = <BN, L0, BWD, PERRAY, PIPE, policy>
 KERNELS = [("mofa::k_layer<128,false,false,false,true,mofa::ShippedPolicy>", "forward", "fp32 MFMA Linear+bias+ReLU, software-pipelined K loop"),
-           ("mofa::k_mlp_fused<false>", "forward, persistent", "persistent fp32-MFMA network kernel, 256-wide layers pipelined across layer boundaries"),
+           ("mofa::k_mlp_fused", "forward, persistent", "persistent fp32-MFMA network kernel, 256-wide layers pipelined across layer boundaries"),
            ("mofa::k_layer<128,false,true,false,true,mofa::ShippedPolicy>", "BWD backward-data", "fp32 MFMA backward-data GEMM + ReLU mask, the same K loop"),
            ("mofa::k_wgrad<128,256>", "weight gradient", "fp32 MFMA weight-gradient GEMM, contraction over points"),
            ("mofa::k_layer<128,false,false,true,true,mofa::ShippedPolicy>", "forward, PERRAY view layer", "the same kernel with the view layer's per-ray bias")]

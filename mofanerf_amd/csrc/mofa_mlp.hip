@@ -427,10 +427,27 @@ __device__ __forceinline__ void kloop_fused(const float* xb, const float* x2b, c
                 for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[j][e], acc[i][j], 0, 0, 0);
     };
-    auto half_a = [&](int stage, Frag& cur, Frag& nxt) {
+    // the layer's FIRST half panel starts the accumulators: the e = 0 products take a constant-zero C operand (an inline constant of the
+    // MFMA instruction) instead of 128 registers zeroed by 128 VALU moves — VALU issue is time the matrix pipe does not get on this chip
+    auto mfma_half_init = [&](const Frag& f) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][0], f.b[j][0], zero, 0, 0, 0);
+#pragma unroll
+        for (int e = 1; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[j][e], acc[i][j], 0, 0, 0);
+    };
+    auto half_a = [&](int stage, Frag& cur, Frag& nxt, auto init_c) {
         __builtin_amdgcn_sched_barrier(0);
         read(stage, 1, nxt);
-        mfma_half(cur);
+        if constexpr (decltype(init_c)::value) mfma_half_init(cur);
+        else mfma_half(cur);
 #pragma unroll
         for (int q = 0; q < NI + NJ; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -472,20 +489,23 @@ __device__ __forceinline__ void kloop_fused(const float* xb, const float* x2b, c
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    // (the loop is rotated by one half panel against kloop_pipelined so that the peeled first half is the initialising one; the
+    //  sequence of halves, barriers and requests is the same)
     Frag fa, fb;
+    constexpr std::false_type kAcc{};
     read(0, 0, fa);
+    half_a(0, fa, fb, std::true_type{});
     for (int kt = 0; kt + 2 < KT; kt += 2) {
-        half_a(0, fa, fb);
         sync_point();
         half_b(0, std::integral_constant<int, 1>{}, true, fb, fa);
-        half_a(1, fa, fb);
+        half_a(1, fa, fb, kAcc);
         sync_point();
         half_b(1, std::integral_constant<int, 1>{}, true, fb, fa);
+        half_a(0, fa, fb, kAcc);
     }
-    half_a(0, fa, fb);
     sync_point();
     half_b(0, std::integral_constant<int, ((NWR + NXR) > 0 ? 2 : 0)>{}, true, fb, fa);
-    half_a(1, fa, fb);
+    half_a(1, fa, fb, kAcc);
     if constexpr (!EPI) {
         half_b(1, std::integral_constant<int, 0>{}, false, fb, fa);
     } else {
@@ -599,12 +619,11 @@ __device__ __forceinline__ void store_tile_fused(const f32x16 (&acc)[NI][NJ], co
         }
 }
 
-template <bool MASKW>
 __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = 128, NI = 2, STAGE = kFsStage;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid0 = threadIdx.x;
+    const int wn = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int half_tiles = a.m_tiles * 2;
     const int nl = a.n_layers;
     float* const win = smem + kFsWin + wn * 1024;
@@ -613,19 +632,20 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
     // everything of layer `nx` that can be requested BEFORE this layer's epilogue, once both stages are free: its weight panel 1
     // (panel 0 went out in the K loop's tail; `both`: layer 0 has no such tail, so panel 0 goes here too), its activation panels when
     // they do not come from this layer's output, and its bias row (ordinary layers; wave 0)
-    auto prefetch = [&](const FusedLayer& nx, int nxi, bool x_indep, bool both, long long m0) {
-        unsigned toff = (unsigned)tid * 4u;
-        asm volatile("" : "+v"(toff));                                    // (formed here, not hoisted out of the tile loop)
+    // Per-lane indices are re-derived from an OPAQUE copy of the thread id inside every block below: hoisted out of the tile loop
+    // (they are invariant) they would occupy registers — or spill slots — for the whole kernel next to 128 accumulators.
+    auto thread_id = [&]() {
+        int t = tid0;
+        asm volatile("" : "+v"(t));
+        return t;
+    };
+    auto prefetch = [&](const FusedLayer& nx, int nxi, bool both) {
+        unsigned toff = (unsigned)thread_id() * 4u;
         const int wr = nx.n_padded >> 6;                                  // 4 (256 rows) or 2 (the 128-row view layer): wave-uniform
         const float* wsrc = a.packed + nx.w_off;
         for (int p = both ? 0 : 1; p < 2; ++p) {
             float* xs = lds_wave + p * STAGE;
             float* ws = xs + TM * 16;
-            if (x_indep) {
-                const float* xsrc = a.arena + nx.x1_off + ((long long)p * a.m_padded + m0) * 16;
-#pragma unroll
-                for (int r = 0; r < 2; ++r) glds16(xsrc + (r * 1024u + toff), xs + r * 1024);
-            }
             const float* wp = wsrc + (long long)p * nx.n_padded * 16;
             for (int r = 0; r < wr; ++r) glds16(wp + (r * 1024u + toff), ws + r * 1024);
         }
@@ -636,6 +656,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
         const long long m0 = (long long)ht * TM;
         // ---------------- layer 0: operand generated from the point (positional encoding), plain double-buffered loop ----------------
         {
+            const int tid = thread_id(), lane = tid & 63;
             float px = 0.f, py = 0.f, pz = 0.f;
             long long m = m0 + (tid & (TM - 1));
             if (m >= a.n_points) m = a.n_points - 1;
@@ -662,8 +683,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
                     xs[row * 16 + ((((kk >> 2) & 3) ^ swz) << 2) + (kk & 3)] = v;
                 }
                 const float* wsrc = wbase + (long long)kt * 256 * 16;
-                unsigned toff = (unsigned)tid * 4u;
-                asm volatile("" : "+v"(toff));
+                const unsigned toff = (unsigned)tid * 4u;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) glds16(wsrc + (r * 1024u + toff), ws + (r * 256 + wn * 64) * 4);
             };
@@ -683,10 +703,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
                 mma_panel<NI, 4>(xs, xs + TM * 16, 0, wn * 64, lane, acc);
                 __syncthreads();
             }
-            prefetch(a.L[1], 1, false, true, m0);
-            store_tile_fused<NI, 4, false, MASKW>(acc, a.folded + l.bias_off, const_cast<float*>(a.arena) + l.y_off, a.m_padded, m0, wn * 64, lane, win,
-                                                  wn == 0 ? smem : nullptr, wn == 0 ? smem + STAGE : nullptr,
-                                                  MASKW ? a.mask_bits + l.mask_off : nullptr);
+            prefetch(a.L[1], 1, true);
+            store_tile_fused<NI, 4, false, false>(acc, a.folded + l.bias_off, const_cast<float*>(a.arena) + l.y_off, a.m_padded, m0, wn * 64, lane, win,
+                                                  wn == 0 ? smem : nullptr, wn == 0 ? smem + STAGE : nullptr, nullptr);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // layer 1's panels 0 / 1 (and this tile's first stores): once per tile
             __builtin_amdgcn_s_barrier();
         }
@@ -694,52 +713,31 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
         for (int li = 1; li < nl - 1; ++li) {
             const FusedLayer& l = a.L[li];
             const FusedLayer& nx = a.L[li + 1];
-            const bool x_indep = nx.x1_off != l.y_off;                     // the skip layers read the stack's input first
+            const int tid = thread_id(), lane = tid & 63;
             const int KT = l.k1p + l.k2p;
-            f32x16 acc[NI][4];
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            f32x16 acc[NI][4];                                              // (started by the loop's first half panel: no zeroing here)
             const float* xb = a.arena + l.x1_off + m0 * 16;
             const float* x2b = l.k2p ? a.arena + l.x2_off + m0 * 16 : nullptr;
             const float* wb = a.packed + l.w_off;
             const float* nwb = a.packed + nx.w_off;
-            const float* nxb = a.arena + nx.x1_off + m0 * 16;
-            const bool pass = wn == 0 && !x_indep;
+            // every layer's first source is the previous layer's output (the skip layers contract [h | x], make_plan), so the next
+            // layer's operand panels 0 / 1 always come straight from this epilogue: wave 0 forms them in the stages' X regions
+            const bool pass = wn == 0;
             const FusedEpi ep{smem + kFsBias + (li & 1) * 256 + wn * 64, const_cast<float*>(a.arena) + l.y_off, a.m_padded, m0, wn * 64, win,
-                              pass ? smem : nullptr, pass ? smem + STAGE : nullptr, MASKW ? a.mask_bits + l.mask_off : nullptr};
-            auto pre = [&]() { prefetch(nx, li + 1, x_indep, false, m0); };
-            // inference: the epilogue inside the loop's tail.  MASKW (a fitting forward): the four ballots per KiB on top of it do not
-            // fit the register file next to the loop's fragments — the epilogue follows the loop there.
-            constexpr bool EPI = !MASKW;
-            if (nx.n_padded == 256) {
-                if (x_indep) kloop_fused<NI, 4, 256, 4, 2, EPI>(xb, x2b, wb, a.m_padded * 16, 256 * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc, nwb, nxb, &ep, pre);
-                else kloop_fused<NI, 4, 256, 4, 0, EPI>(xb, x2b, wb, a.m_padded * 16, 256 * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc, nwb, nxb, &ep, pre);
-            } else {
-                kloop_fused<NI, 4, 256, 2, 0, EPI>(xb, x2b, wb, a.m_padded * 16, 256 * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc, nwb, nxb, &ep, pre);
-            }
-            if constexpr (!EPI) {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next layer's panel 0 (requested half a panel ago) has landed;
-                __builtin_amdgcn_s_barrier();                                 // everybody is done reading both stages
-                pre();
-                store_tile_fused<NI, 4, true, MASKW>(acc, ep.bias_lds, ep.y, a.m_padded, m0, wn * 64, lane, win, ep.pass0, ep.pass1, ep.mask_out);
-            }
+                              pass ? smem : nullptr, pass ? smem + STAGE : nullptr, nullptr};
+            auto pre = [&]() { prefetch(nx, li + 1, false); };
+            // ONE instantiation for every ordinary layer (three would meet in register copies of the 128 accumulators): the tail always
+            // requests four 1 KiB rounds of the next layer's weight panel 0 — for the 128-row view layer the upper two land in rows the
+            // view layer never reads (they are its panel 1, valid memory)
+            kloop_fused<NI, 4, 256, 4, 0, true>(xb, x2b, wb, a.m_padded * 16, 256 * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc, nwb, nullptr, &ep, pre);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // my LDS writes (the handed-over panels) are done; the stores drain
             __builtin_amdgcn_s_barrier();                                 // behind the next loop's first half panel (its vmcnt(0) + barrier)
         }
         // ---------------- the view layer: 128 features x 128 points on 2 x 2 waves, per-ray bias rows ----------------
         {
             const FusedLayer& l = a.L[nl - 1];
+            const int tid = thread_id(), lane = tid & 63;
             f32x16 acc[NI][2];
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
             const int wn2 = wn & 1, wm2 = wn >> 1;
             kloop_fused<NI, 2, 128, 0, 0>(a.arena + l.x1_off + m0 * 16, nullptr, a.packed + l.w_off, a.m_padded * 16, 128 * 16, l.k1p, l.k1p, smem,
                                           tid, wn, lane, wm2 * 64, wn2 * 64, acc, nullptr, nullptr);
@@ -759,7 +757,7 @@ bool fused_fast_shape(const FusedArgs& a) {
     if (f.x1_off >= 0 || f.n_padded != 256 || f.k2p != 0 || f.bias_row_div != 0) return false;
     for (int i = 1; i < a.n_layers - 1; ++i) {
         const FusedLayer& l = a.L[i];
-        if (l.x1_off < 0 || l.n_padded != 256 || l.k1p != 16 || (l.k2p != 0 && l.k2p != 16) || l.bias_row_div != 0) return false;
+        if (l.x1_off != a.L[i - 1].y_off || l.n_padded != 256 || l.k1p != 16 || (l.k2p != 0 && l.k2p != 16) || l.bias_row_div != 0) return false;
     }
     const FusedLayer& v = a.L[a.n_layers - 1];
     return v.x1_off >= 0 && v.n_padded == 128 && v.k1p == 16 && v.k2p == 0 && v.bias_row_div != 0 && v.x1_off == a.L[a.n_layers - 2].y_off;
@@ -776,11 +774,11 @@ int launch_fused(const FusedArgs& a, hipStream_t st) {
     if (fused_fast_shape(a) && !a.mask_bits) {
         const size_t lds = (size_t)kFsFloats * sizeof(float);          // 66 KiB: above the 64 KiB default limit of dynamic LDS
         if (!g_fused_attr[dev].load(std::memory_order_acquire)) {      // one-time function attribute per device
-            if (hipFuncSetAttribute((const void*)k_mlp_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            if (hipFuncSetAttribute((const void*)k_mlp_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return check_launch("hipFuncSetAttribute(k_mlp_fused)");
             g_fused_attr[dev].store(1, std::memory_order_release);
         }
-        hipLaunchKernelGGL(k_mlp_fused<false>, dim3(grid), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(k_mlp_fused, dim3(grid), dim3(256), lds, st, a);
         return check_launch("k_mlp_fused");
     }
     const size_t lds = 2 * (size_t)(128 + 256) * 16 * sizeof(float);   // 48 KiB
