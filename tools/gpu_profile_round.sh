@@ -26,6 +26,9 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LD
 done
 python tools/make_traffic_json.py gpurun_out/$tag gpurun_out/$tag/hbm_traffic.json > /dev/null 2> gpurun_out/$tag/hbm_traffic.err
 python tools/kernel_resources.py mofanerf_amd/libmofanerf_hip.so gpurun_out/$tag/kernel_resources.md
+# the same counters for the persistent <= 256-wide network kernel (the north star's kernel) and its generic twin
+bash tools/gpu_profile_fused.sh $tag pipelined generic > /dev/null 2>&1
+python tools/make_traffic_fused_json.py gpurun_out/$tag gpurun_out/$tag/hbm_traffic_fused.json > /dev/null 2> gpurun_out/$tag/hbm_traffic_fused.err
 # the RCCL branches on this one GPU (one-rank nccl group, every collective issued): kernel trace of what actually ran
 rm -rf /tmp/prof_rccl
 rocprofv3 --kernel-trace --stats -d /tmp/prof_rccl -o rccl -- python tools/rccl_world1.py > gpurun_out/$tag/rccl_world1.json 2> gpurun_out/$tag/rccl_world1.err
@@ -36,5 +39,5 @@ cp gpurun_out/$tag/hbm_traffic.json profiles/hbm_traffic.json
 python bench.py > gpurun_out/$tag/bench_n1.json 2> gpurun_out/$tag/bench_n1.err
 python bench.py --mode fit > gpurun_out/$tag/bench_fit_n1.json 2> gpurun_out/$tag/bench_fit_n1.err
 python bench.py --mode train > gpurun_out/$tag/bench_train_n1.json 2> gpurun_out/$tag/bench_train_n1.err
-python bench.py --arch 8 256 8 256 --cpu-rays 0 --parity-rays 0 > gpurun_out/$tag/bench_n1_variant_fine256x8.json 2> /dev/null
+python bench.py --arch 8 256 8 256 --cpu-rays 0 > gpurun_out/$tag/bench_n1_variant_fine256x8.json 2> /dev/null
 ls -la gpurun_out/$tag
