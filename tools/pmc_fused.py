@@ -2,7 +2,7 @@
 """Driver for rocprofv3 --pmc passes over the persistent network kernels: the shipped coarse network (256 x 8) forward on 196,608
 points (one sub-batch of the 512 x 512 frame: 1,536 tiles of 128 points), four launches per arm.  Arms = the library's bit-identical
 launch forms: `pipelined` (k_mlp_fused<false>, the default), `generic` (k_mlp_fused_generic<false> with its plain loops: MOFA_PIPE=0).
-(profiles/r04_pmc_fused_*.csv additionally hold the LDS-resident experiment's kernels, k_mlp_resident<4|8>, of commit a90d63b.)
+(profiles/r04_pmc_resident_experiment_*.csv: the same passes on commit a90d63b, incl. the LDS-resident experiment's k_mlp_resident<4|8>.)
 tools/gpu_profile_fused.sh wraps it, one pass per counter group."""
 import os, sys
 import torch
