@@ -167,12 +167,13 @@ class Renderer(torch.nn.Module):
     def _hip(self, net) -> HipNet:
         net = unwrap(net)
         h = self._hipnets.get(id(net))
-        if h is None or h.net is not net or h.point_freqs != self.point_freqs:
-            h = self._hipnets[id(net)] = HipNet(net, point_freqs=self.point_freqs)
-            if h.view_freqs != self.view_freqs:
+        if h is None or h.net is not net or h.point_freqs != self.point_freqs or h.view_freqs != self.view_freqs:
+            h = HipNet(net, point_freqs=self.point_freqs)
+            if h.view_freqs != self.view_freqs:       # (checked BEFORE the entry is cached: a refused network is refused every time)
                 raise lib.MofaError(f"NeRF.input_ch_views = {net.input_ch_views} (multires_views = {h.view_freqs}) but the renderer's "
                                     f"embeddirs_fn encodes {self.view_freqs} frequencies (tools/create_model_condition.py:16-22 builds "
                                     "both from args.multires_views)")
+            self._hipnets[id(net)] = h
         return h
 
     def _device(self):
