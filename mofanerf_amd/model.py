@@ -138,19 +138,6 @@ class _TexEncoderCore(nn.Module):
                                       nn.Linear(code_len, code_len), nn.LeakyReLU(0.1))
         _xavier_relu_(self)
 
-    def _convs(self, x):
-        """im2col + GEMM form of the seven 4x4 / stride-2 / pad-1 convolutions — kept ONLY as the B arm of
-        tools/tex_encoder_ab.py.  Measured on MI355X: MIOpen 1.67 ms vs this 2.11 ms per forward+backward in steady
-        state (0.24 vs 0.41 ms forward); the `naive_conv_*` kernels a profile of the first steps shows are MIOpen's
-        one-off solver search, not the steady state.  The encoder is 0.2 % of a training step, so it stays on MIOpen."""
-        for i in range(7):
-            conv = self.down1[0][2 * i]
-            n, c, h, w = x.shape
-            cols = F.unfold(x, kernel_size=4, padding=1, stride=2)                 # [n, c*16, (h/2)*(w/2)]
-            y = conv.weight.reshape(conv.out_channels, -1) @ cols + conv.bias[None, :, None]
-            x = F.leaky_relu(y.reshape(n, conv.out_channels, h // 2, w // 2), 0.2)
-        return x
-
     def forward(self, x):
         x = self.down1[0](x).reshape(-1, 256 * 4 * 4)
         return self.decoding(self.mu(self.down2(x)))
