@@ -51,7 +51,9 @@ KERNELS = [("mofa::k_layer<128,false,false,false,true,mofa::ShippedPolicy>", "fo
            ("mofa::k_mlp_fused", "forward, persistent", "persistent fp32-MFMA network kernel, 256-wide layers pipelined across layer boundaries"),
            ("mofa::k_layer<128,false,true,false,true,mofa::ShippedPolicy>", "BWD backward-data", "fp32 MFMA backward-data GEMM + ReLU mask, the same K loop"),
            ("mofa::k_wgrad<128,256>", "weight gradient", "fp32 MFMA weight-gradient GEMM, contraction over points"),
-           ("mofa::k_layer<128,false,false,true,true,mofa::ShippedPolicy>", "forward, PERRAY view layer", "the same kernel with the view layer's per-ray bias")]
+           ("mofa::k_layer<128,false,false,true,true,mofa::ShippedPolicy>", "forward, PERRAY view layer", "the same kernel with the view layer's per-ray bias"),
+           ("mofa::k_net_chain", "forward, chained", "every fp32-MFMA layer of a wide network in one launch: the layer kernel's tiles behind per-XCD queues and "
+                                                     "row-tile dependency counters")]
 
 
 def pose_spherical(phi_deg, theta_deg, radius):
@@ -421,8 +423,9 @@ def main():
         kname = f"{ksym} ({kdesc})"
         achieved = pflops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         traffic, tinfo = None, {}
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")       # PMC-derived bytes/launch (separate --pmc passes)
-        if os.path.exists(tpath) and dom == 0 and a.mode == "render" and ARCH == (8, 256, 10, 1024):
+        # PMC-derived bytes/launch (separate --pmc passes), one record per kernel
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_chain.json" if dom == 5 else "hbm_traffic.json")
+        if os.path.exists(tpath) and dom in (0, 5) and a.mode == "render" and ARCH == (8, 256, 10, 1024):
             from mofanerf_amd import build as mbuild
             tj = json.load(open(tpath))
             digest = mbuild.csrc_digest()
@@ -433,10 +436,10 @@ def main():
                 traffic = tj.get("bytes_per_launch")
                 tinfo = {"traffic_shape": tj.get("shape"), "traffic_algorithmic_bytes_same_shape": tj.get("algorithmic_bytes_per_launch"),
                          "mfma_busy_fraction_pmc": tj.get("mfma_busy_fraction"), "traffic_csrc_sha256": digest[:16],
-                         "traffic_source": "profiles/hbm_traffic.json (rocprofv3 --pmc passes on the single-layer driver of this kernel, "
+                         "traffic_source": f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc passes on a driver that launches this kernel alone, "
                                            "same kernel sources by hash; not this run)"}
             else:
-                tinfo = {"traffic_source": f"null: profiles/hbm_traffic.json was taken on kernel sources {str(tj.get('csrc_sha256'))[:16]} / "
+                tinfo = {"traffic_source": f"null: profiles/{os.path.basename(tpath)} was taken on kernel sources {str(tj.get('csrc_sha256'))[:16]} / "
                                            f"{tj.get('kernel')}, this build is {digest[:16]} / {kname.split(' ')[0]} — re-run tools/gpu_profile_round.sh"}
         others = [{"kernel": KERNELS[k][0], "role": KERNELS[k][1], "launches": int(launches[k]), "total_ms": round(ms[k], 2),
                    "tflops": round(pflops[k] / (ms[k] * 1e-3) / 1e12, 2)} for k in range(NK) if k != dom and ms[k] > 0]

@@ -55,8 +55,9 @@ int mofa_abi_version(void);
 const char* mofa_last_error(void);   /* thread-local text of the calling thread's last failure */
 
 /* Library-wide state is limited to what is listed here; everything else is in caller-owned buffers.
- *   - two run-time knobs, each choosing between BIT-IDENTICAL forms of the exact-fp32 path — MOFA_PIPE=0 (plain instead of
- *     software-pipelined K loops), MOFA_FUSED=0/1 (per-layer launches / persistent network kernel); there is no reduced-precision
+ *   - three run-time knobs, each choosing between BIT-IDENTICAL forms of the exact-fp32 path — MOFA_PIPE=0 (plain instead of
+ *     software-pipelined K loops), MOFA_FUSED=0/1 (per-layer launches / persistent network kernel for widths <= 256), MOFA_CHAIN=0
+ *     (per-layer launches instead of the chained launch of the wider networks); there is no reduced-precision
  *     mode: read from the environment ONCE when the library is loaded into an immutable snapshot;
  *     no launch path calls getenv.  mofa_config_reload() re-reads them (tests that change a knob inside one process call it explicitly).
  *     Measurement arms (scheduling experiments, time stamps, ablations) are NOT in this library: csrc/measure/, tools/build_measure.py.
@@ -222,11 +223,12 @@ int mofa_positional_encode(const float* x, int64_t n, int32_t n_freqs, float* ou
  * open the launch paths read one atomic flag).  Between mofa_prof_begin() and mofa_prof_end() every launch of the MFMA
  * kernels — [0] the per-layer forward kernel k_layer<128,..,PIPE> (128-feature tile, pipelined K loop), [1] the persistent
  * whole-network kernel k_mlp_fused (widths <= 256), [2] the backward-data kernel k_layer<128,..,BWD>, [3] the
- * weight-gradient kernel k_wgrad, [4] the view layer's per-ray-bias instantiation of the forward kernel — is bracketed by
+ * weight-gradient kernel k_wgrad, [4] the view layer's per-ray-bias instantiation of the forward kernel, [5] the chained
+ * wide-network kernel k_net_chain — is bracketed by
  * hipEventRecord on its own stream.  mofa_prof_end() synchronises those
  * events (host blocks) and fills three arrays of length MOFA_PROF_KINDS: summed kernel time, launch count, FLOPs
  * executed (2*M*K*N of the padded shapes).  Used by bench.py only. */
-#define MOFA_PROF_KINDS 5
+#define MOFA_PROF_KINDS 6
 int mofa_prof_begin(void);
 int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops);
 

@@ -45,7 +45,7 @@ __device__ __forceinline__ float relu_np(float v) { return __builtin_elementwise
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
-// Run-time knobs.  Both select between BIT-IDENTICAL forms of the exact-fp32 path (plain / pipelined K loop; persistent /
+// Run-time knobs.  Each selects between BIT-IDENTICAL forms of the exact-fp32 path (plain / pipelined K loop; persistent or chained /
 // per-layer network launch) — there is no reduced-precision mode in this library; measurement arms live in csrc/measure/.
 // The environment is read ONCE (at library load, and again only when the host calls mofa_config_reload()) into an immutable
 // snapshot, so no launch path calls getenv and concurrent host threads see one consistent configuration.
@@ -53,6 +53,7 @@ int check_launch(const char* what);
 struct Config {
     int fused = -1;       // MOFA_FUSED=0/1: persistent whole-network kernel off / on
     int pipe = -1;        // MOFA_PIPE=0: the plain K loops (layer kernel, persistent kernel, weight gradient) instead of the pipelined ones
+    int chain = -1;       // MOFA_CHAIN=0: per-layer launches for the wide networks instead of the chained launch (k_net_chain)
 };
 const Config& config();
 

@@ -90,6 +90,13 @@ __device__ __forceinline__ void glds16(const float* g, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// the same with a cache policy: AUX = 16 is `sc1` (agent scope) — the request is served by the XCD's L2 and never by this CU's vector L1,
+// which other CUs' stores do not refresh: the form for operands another workgroup of the SAME launch has just written (k_net_chain)
+template <int AUX>
+__device__ __forceinline__ void glds16_policy(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
+}
 
 // ---- mask-only tape (fitting: the backward needs (activation > 0), not the activation) -------------------------------------------
 // One bit per activation, addressed through the activation's own float offset `off` inside its panel buffer: the 256 floats of
@@ -166,7 +173,7 @@ __device__ __forceinline__ void mma_panel(const float* __restrict__ Xt, const fl
 // xb / x2b / wb: the tile's first panel in the two activation sources (x2b is only dereferenced when KT > k1p) and in the
 // weight pack; xstep / wstep: floats between consecutive panels; xrow0 / wrow0: this wave's first row in the staged X / W
 // tile; `wave`: index of the wave's 1 KiB slot inside each 4 KiB staging round.
-template <int NI, int NJ, int BM, int BN, class P = ShippedPolicy>
+template <int NI, int NJ, int BM, int BN, class P = ShippedPolicy, int XAUX = 0>
 __device__ __forceinline__ void kloop_pipelined(const float* xb, const float* x2b, const float* wb, long long xstep, long long wstep,
                                                 int k1p, int KT, float* smem, int tid, int wave, int lane, int xrow0, int wrow0,
                                                 f32x16 (&acc)[NI][NJ], typename P::Probe& probe) {
@@ -183,7 +190,7 @@ __device__ __forceinline__ void kloop_pipelined(const float* xb, const float* x2
         float* xs = lds_wave + stage * STAGE;
         float* ws = xs + BM * 16;
 #pragma unroll
-        for (int r = 0; r < XR; ++r) glds16(xb + (r * 1024u + toff), xs + r * 1024);
+        for (int r = 0; r < XR; ++r) glds16_policy<XAUX>(xb + (r * 1024u + toff), xs + r * 1024);
 #pragma unroll
         for (int r = 0; r < WR; ++r) glds16(wb + (r * 1024u + toff), ws + r * 1024);
         ++pq;

@@ -787,11 +787,197 @@ int launch_fused(const FusedArgs& a, hipStream_t st) {
     return check_launch("k_mlp_fused_generic");
 }
 
+
+// ======================================================================================================
+// k_net_chain: the WIDE network (widths > 256: every layer is a grid of 256-point x 128-feature tiles of the layer kernel) as ONE
+// launch.  A per-layer launch ends when its slowest CU has finished its last tile — at 12 tile rounds per launch the fill and the
+// drain cost 2.5 % of every one of the ~26 launches of a sub-batch (profiles/r02_timeline_*.md; a 4x larger netchunk measures 0.949
+// instead of 0.938 for exactly that reason).  Here the tiles of ALL layers form one queue per XCD and the only thing a tile waits
+// for is what it really depends on: the tiles of the previous layers over ITS OWN 256 point rows (layers are row-wise: Linear + bias
+// + ReLU, concatenations of row-aligned tensors).  So a CU that is done with layer l starts layer l + 1 on rows whose inputs are
+// complete while other CUs still finish layer l, and the launch drains once per sub-batch instead of once per layer.
+//
+//   * Queue: workgroups are persistent (two per CU); each pulls tile numbers from the head counter of the XCD it RUNS on
+//     (`s_getreg HW_REG_XCC_ID`, not an assumed blockIdx -> XCD map).  XCD x owns the point-row tiles [x m/8, (x+1) m/8) of every
+//     layer, in layer-major order — a topological order, pulled in increasing order, so a tile only ever waits for tiles that
+//     RUNNING workgroups hold: no deadlock for any residency.  The next tile number is drawn one tile ahead.
+//   * Dependency: one counter per point-row tile, incremented once per finished tile of any layer; tile (layer s, rows m, *) waits
+//     until done[m] has reached the number of tiles the layers before s have over those rows.  The same rule covers the buffers the
+//     plan recycles (a layer overwrites rows only after every reader of the old contents of those rows — the previous layer over the
+//     same rows — is complete).
+//   * Visibility: producer and consumer of a row tile are by construction on the same XCD, whose L2 is their point of coherence:
+//     the producer's plain stores are acknowledged by that L2 (`s_waitcnt vmcnt(0)` in every wave, then a barrier) before one lane
+//     bumps the counter; the consumer polls the counter with relaxed agent-scope loads and requests its activation panels with
+//     `sc1` LDS-DMA loads, which the L2 serves and this CU's vector L1 (never refreshed by other CUs' stores) cannot.  Weights, biases
+//     and the per-ray bias rows were written by earlier launches and use the default policy.
+//   * The tile itself is k_layer<128, .., PIPE>'s: same panels, same K loop, same epilogues — bit-identical to per-layer launches.
+// State (zeroed by a memset node ahead of every launch): 8 heads at a 128-byte stride, a status word, the per-row-tile counters.
+// ======================================================================================================
+constexpr int kMaxChainSteps = 40;
+constexpr int kChainHeadStride = 32;                 // unsigned words between two XCDs' queue heads (one 128-byte line each)
+constexpr int kChainStatus = 8 * kChainHeadStride;   // [0] bit 0: a dependency wait timed out; [1]: tiles finished (all XCDs)
+constexpr int kChainDone = kChainStatus + 32;        // done[m_tiles]
+constexpr unsigned kChainSpinLimit = 1u << 22;       // polls (each >= ~1 us with its s_sleep) before a wait gives up: seconds, never a hang
+
+struct ChainStep {
+    long long x1_off, x2_off, y_off;  // float offsets into the activation arena
+    long long w_off;                  // into the packed weights
+    long long bias_off;               // into `folded` (bias_row_div == 0) or into `view_bias_rows`
+    int k1p, k2p, n_padded, n_tiles;  // 16-wide K panels per source; features; n_padded / 128
+    int bias_row_div, relu;
+    int tiles_before;                 // sum of n_tiles over the earlier steps = what done[m] must have reached
+    int pad_;
+};
+
+struct ChainArgs {
+    float* arena;
+    const float* packed;
+    const float* folded;
+    const float* view_bias_rows;
+    unsigned* state;
+    long long m_padded, bias_rows;
+    int m_tiles, n_steps, tiles_per_m;
+    ChainStep S[kMaxChainSteps];
+};
+static_assert(sizeof(ChainArgs) <= 4096, "kernel arguments are limited to 4 KiB");
+
+// What a workgroup of k_net_chain carries from tile to tile.  It rides into the K loop as the policy's `Probe` (the hook the loop calls
+// after every panel's wait + barrier), because two things belong BEHIND the next tile's first panel rather than between two tiles:
+//   * the completion signal of the tile just finished — the loop's first `s_waitcnt vmcnt(0)` + barrier is the point where every
+//     wave's stores of the PREVIOUS tile are known to be in the L2, so nobody waits for the store acknowledgements at the tile
+//     boundary (2-4 us of a 234 us tile when it was done there);
+//   * the look at the NEXT tile's dependency counter — the queue ticket drawn at the top of this tile has returned by then, and the
+//     counter's value travels while this tile computes; the poll only spins (at the next tile's top) in the rare case it was too early.
+struct ChainPolicy : ShippedPolicy {
+    struct Probe {
+        const ChainArgs& a;
+        unsigned* done;
+        unsigned* status;
+        int m_lo, m_cnt, total, tid;
+        int prev_mt = -1;        // row tile whose completion is still to be signalled
+        bool first = false;      // the current tile's first panel has not been passed yet
+        int s_next = 0;          // (thread 0) step pointer of the next tile
+        int qn = 0;              // (thread 0) next tile number
+        unsigned seen = 0, need = 0;   // (thread 0) the next tile's counter as seen early / what it must reach
+        __device__ __forceinline__ Probe(const ChainArgs& a_, unsigned* done_, unsigned* status_, int m_lo_, int m_cnt_, int total_, int tid_)
+            : a(a_), done(done_), status(status_), m_lo(m_lo_), m_cnt(m_cnt_), total(total_), tid(tid_) {}
+        __device__ __forceinline__ void signal_prev() {       // (after a vmcnt(0) + barrier that covers the previous tile's stores)
+            if (prev_mt >= 0 && tid == 0) {
+                __hip_atomic_fetch_add(done + prev_mt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            prev_mt = -1;
+        }
+        __device__ __forceinline__ void entry() {}
+        __device__ __forceinline__ void kloop_begin() {}
+        __device__ __forceinline__ void first_panel_landed() {}
+        __device__ __forceinline__ void kloop_end() {}
+        __device__ __forceinline__ void stores_issued() {}
+        __device__ __forceinline__ void panel() {
+            if (!first) return;
+            first = false;
+            signal_prev();
+            if (tid == 0 && qn < total) {
+                while (qn >= m_cnt * (a.S[s_next].tiles_before + a.S[s_next].n_tiles)) ++s_next;
+                const int r = qn - m_cnt * a.S[s_next].tiles_before;
+                need = (unsigned)a.S[s_next].tiles_before;
+                seen = __hip_atomic_load(done + m_lo + r / a.S[s_next].n_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+};
+
+__global__ __launch_bounds__(256, 2) void k_net_chain(const ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BM = kRowTile, BN = 128, NI = 2, NJ = 4, STAGE = (BM + BN) * 16;
+    int* const slot = (int*)(smem + 2 * STAGE);       // [0] next tile number, [1] "its inputs are known to be complete": thread 0 -> workgroup
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    const int mpx = (a.m_tiles + 7) >> 3;
+    const int m_lo = (int)xcc * mpx;
+    const int m_cnt = m_lo < a.m_tiles ? (a.m_tiles - m_lo < mpx ? a.m_tiles - m_lo : mpx) : 0;
+    const int total = m_cnt * a.tiles_per_m;
+    unsigned* const head = a.state + xcc * kChainHeadStride;
+    unsigned* const status = a.state + kChainStatus;
+    unsigned* const done = a.state + kChainDone;
+    ChainPolicy::Probe hook(a, done, status, m_lo, m_cnt, total, tid);
+
+    if (tid == 0) slot[0] = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), slot[1] = 0;
+    __syncthreads();
+    int q = slot[0], ready = 0;
+    int s = 0;
+    bool gave_up = false;
+    while (q < total) {
+        while (q >= m_cnt * (a.S[s].tiles_before + a.S[s].n_tiles)) ++s;          // tile numbers only grow: the step pointer only advances
+        const ChainStep& st = a.S[s];
+        const int r = q - m_cnt * st.tiles_before;
+        const int mt = m_lo + r / st.n_tiles, nt = r - (r / st.n_tiles) * st.n_tiles;
+        if (!ready) {
+            // the early look did not find this tile's inputs complete (or there was none: the first tile).  The previous tile's signal
+            // must go out BEFORE waiting — this tile may depend on it — so its stores are waited for here instead of behind the first panel
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            hook.signal_prev();
+            if (tid == 0) {
+                const unsigned need = (unsigned)st.tiles_before;
+                unsigned spins = 0;
+                while (!gave_up && __hip_atomic_load(done + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins == kChainSpinLimit) {      // never a hang: flag it, stop waiting in this workgroup, go on (tests read the flag)
+                        __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gave_up = true;
+                    }
+                }
+            }
+            __syncthreads();                             // the inputs of this tile are complete — for every wave
+        }
+        if (tid == 0) hook.qn = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the ticket after this one
+        hook.first = true;
+
+        const long long m0 = (long long)mt * BM;
+        const int n0 = nt * BN;
+        f32x16 acc[NI][NJ];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        kloop_pipelined<NI, NJ, BM, BN, ChainPolicy, 16>(a.arena + st.x1_off + m0 * 16, st.k2p ? a.arena + st.x2_off + m0 * 16 : nullptr,
+                                                         a.packed + st.w_off + (long long)n0 * 16, a.m_padded * 16, (long long)st.n_padded * 16,
+                                                         st.k1p, st.k1p + st.k2p, smem, tid, wave, lane, wm * (32 * NJ), wn * 64, acc, hook);
+        float* const y = a.arena + st.y_off;
+        const long long mf = m0 + wm * (32 * NJ);
+        const int nf = n0 + wn * 64;
+        if (st.bias_row_div) {                           // the view layer: per-ray bias rows
+            f32x4 bv[NI][4];
+            store_tile<NI, NJ, true>(acc, a.view_bias_rows + st.bias_off, a.bias_rows, st.bias_row_div, st.n_padded, y, a.m_padded, mf, nf, st.relu, lane, bv);
+        } else {
+            float* const win = smem + wave * 1024;       // wave-private window inside stage 0 (free after the loop's last barrier)
+            if (st.relu) store_tile_staged<NI, NJ, true>(acc, a.folded + st.bias_off, y, a.m_padded, mf, nf, lane, win);
+            else store_tile_staged<NI, NJ, false>(acc, a.folded + st.bias_off, y, a.m_padded, mf, nf, lane, win);
+        }
+        hook.prev_mt = mt;                               // signalled behind the next tile's first panel (or below / above when there is a wait)
+        if (tid == 0) slot[0] = hook.qn, slot[1] = (hook.qn >= total || hook.seen >= hook.need) ? 1 : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                 // the windows and stages are free for the next tile's requests
+        q = slot[0], ready = slot[1];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last tile of this workgroup
+    __syncthreads();
+    hook.signal_prev();
+}
+
 // Optional per-launch timing of the dominant kernels with HIP events recorded on the launch stream; used by bench.py for the
 // live roofline figure.  Off by default (no events, no overhead).  The measurement session is explicit state the HOST opens and
 // closes (mofa_prof_begin/end); it is kept per device and guarded by a mutex, so two devices or two host threads in one process
 // do not share or corrupt it.  When no session is open the launch paths only read one relaxed atomic.
-constexpr int kProfKinds = MOFA_PROF_KINDS;   // 0: k_layer<128,..,PIPE> (forward), 1: k_mlp_fused, 2: k_layer<BWD>, 3: k_wgrad, 4: k_layer<..PERRAY> (view layer)
+constexpr int kProfKinds = MOFA_PROF_KINDS;   // 0: k_layer<128,..,PIPE> (forward), 1: k_mlp_fused, 2: k_layer<BWD>, 3: k_wgrad, 4: k_layer<..PERRAY> (view layer), 5: k_net_chain
 struct ProfState {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     std::vector<int> kind;
@@ -1068,7 +1254,8 @@ int mofa_prof_begin(void) {
 
 /* arrays of MOFA_PROF_KINDS: [0] the per-layer forward MFMA kernel k_layer<128,false,false,false,PIPE> (128-feature tile),
  * [1] the persistent network kernel k_mlp_fused, [2] the backward-data kernel k_layer<128,false,BWD,..>, [3] the weight-gradient
- * kernel k_wgrad, [4] the per-ray-bias instantiation k_layer<128,false,false,PERRAY,..> (view layer).
+ * kernel k_wgrad, [4] the per-ray-bias instantiation k_layer<128,false,false,PERRAY,..> (view layer), [5] the chained wide-network kernel
+ * k_net_chain.
  * Session of the CURRENT device. */
 int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops) {
     MOFA_REQUIRE(total_ms && launches && padded_flops, "prof_end: null pointer");
@@ -1122,6 +1309,46 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
     const int rc = launch_fused(a, st);
     prof_close(st, 1, flops);
     return rc;
+}
+
+// internal (used by mofa_net.hip): the MFMA layers of one WIDE network as one chained launch (k_net_chain).  `state`: at least
+// mofa_internal_chain_state_words(m_padded) unsigned words inside the caller's workspace.
+size_t mofa_internal_chain_state_words(long long m_padded) { return (size_t)kChainDone + (size_t)(m_padded / kRowTile) + 32; }
+
+int mofa_internal_chain_forward(float* arena, const float* packed, const float* folded, const float* view_bias_rows, long long bias_rows,
+                                long long m_padded, int n_steps, const long long* x1_off, const long long* x2_off, const long long* y_off,
+                                const long long* w_off, const long long* bias_off, const int* k1p, const int* k2p, const int* n_padded,
+                                const int* bias_row_div, const int* relu, unsigned* state, void* stream) {
+    MOFA_REQUIRE(n_steps > 0 && n_steps <= kMaxChainSteps, "chain_forward: %d layers (max %d)", n_steps, kMaxChainSteps);
+    MOFA_REQUIRE(m_padded > 0 && m_padded % kRowTile == 0 && m_padded / kRowTile < (1 << 24), "chain_forward: m_padded=%lld", m_padded);
+    MOFA_REQUIRE(arena && packed && folded && view_bias_rows && state, "chain_forward: null pointer");
+    ChainArgs a{};
+    a.arena = arena, a.packed = packed, a.folded = folded, a.view_bias_rows = view_bias_rows, a.state = state;
+    a.m_padded = m_padded, a.bias_rows = bias_rows, a.m_tiles = (int)(m_padded / kRowTile), a.n_steps = n_steps;
+    double flops = 0.0;
+    int before = 0;
+    for (int i = 0; i < n_steps; ++i) {
+        const int kt = k1p[i] + k2p[i];
+        MOFA_REQUIRE(n_padded[i] > 0 && n_padded[i] % 128 == 0 && kt >= 4 && (kt & 1) == 0 && k1p[i] > 0,
+                     "chain_forward: layer %d (n_padded=%d, %d K panels) does not fit the pipelined 128-feature tile", i, n_padded[i], kt);
+        a.S[i] = ChainStep{x1_off[i], x2_off[i], y_off[i], w_off[i], bias_off[i], k1p[i], k2p[i], n_padded[i], n_padded[i] / 128,
+                           bias_row_div[i], relu[i], before, 0};
+        before += n_padded[i] / 128;
+        flops += 2.0 * (double)m_padded * (double)n_padded[i] * 16.0 * (double)kt;
+    }
+    a.tiles_per_m = before;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(state, 0, mofa_internal_chain_state_words(m_padded) * sizeof(unsigned), st) != hipSuccess) return check_launch("hipMemsetAsync(chain state)");
+    const int dev = current_device();
+    const long long tiles = (long long)a.m_tiles * before;
+    const int slots = 2 * compute_units(dev);
+    const int grid = tiles < slots ? (int)round_up(tiles, 8) : slots;       // two resident workgroups per CU
+    const size_t lds = 2 * (size_t)(kRowTile + 128) * 16 * sizeof(float) + 64;
+    const bool prof = prof_enabled();
+    if (prof && prof_open(st, 5) != MOFA_OK) return MOFA_EHIP;
+    hipLaunchKernelGGL(k_net_chain, dim3(grid), dim3(256), lds, st, a);
+    if (prof) prof_close(st, 5, flops);
+    return check_launch("k_net_chain");
 }
 
 // internal (used by mofa_net.hip): bits of (y > 0) for a panel buffer of n_floats (a multiple of 256) floats

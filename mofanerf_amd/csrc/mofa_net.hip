@@ -25,6 +25,11 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
                                 const int* k2p, const int* n_padded, const int* bias_row_div, int pe_feats,
                                 unsigned long long* mask_bits, const long long* mask_off, void* stream);
 int mofa_internal_mask_pack(const float* y, long long n_floats, unsigned long long* bits, void* stream);
+size_t mofa_internal_chain_state_words(long long m_padded);
+int mofa_internal_chain_forward(float* arena, const float* packed, const float* folded, const float* view_bias_rows, long long bias_rows,
+                                long long m_padded, int n_steps, const long long* x1_off, const long long* x2_off, const long long* y_off,
+                                const long long* w_off, const long long* bias_off, const int* k1p, const int* k2p, const int* n_padded,
+                                const int* bias_row_div, const int* relu, unsigned* state, void* stream);
 int mofa_internal_head_weight_grad_split(const float* d_raw, int32_t raw_off, int32_t n_out, const float* x, int32_t k_padded,
                                          int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, float* workspace,
                                          void* stream);
@@ -46,7 +51,7 @@ namespace {
 Config read_env() {
     Config c;
     auto tri = [](const char* name) { const char* e = getenv(name); return e ? (e[0] == '1' ? 1 : 0) : -1; };
-    c.fused = tri("MOFA_FUSED"), c.pipe = tri("MOFA_PIPE");
+    c.fused = tri("MOFA_FUSED"), c.pipe = tri("MOFA_PIPE"), c.chain = tri("MOFA_CHAIN");
     return c;
 }
 // two slots + an atomic index: readers never see a half-written snapshot, reload is rare and host-side only
@@ -222,7 +227,7 @@ size_t mofa_net_workspace_floats(MofaNetShape s, int64_t n_points, int64_t n_ray
     if (!shape_ok(s) || n_points <= 0 || n_rays <= 0) return 0;
     const Plan p = make_plan(s);
     const size_t mp = (size_t)round_up(n_points, kRowTile);
-    return 4 * mp * (size_t)p.Wp + (size_t)n_rays * (size_t)p.Hp + 64;
+    return 4 * mp * (size_t)p.Wp + (size_t)n_rays * (size_t)p.Hp + 64 + mofa_internal_chain_state_words((long long)mp);   // (+ k_net_chain's queue state)
 }
 
 int mofa_net_pack(MofaNetShape s, const float* const* weights, float* packed, void* stream) {
@@ -380,6 +385,18 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
         MOFA_TRY(mofa_view_bias(viewdirs, n_rays, s.pe_view_freqs, view_w, l.n_out, l.ld, view_b, vbias, l.n_padded, stream));
         view_bias_rows = vbias;
     }
+    // the chained launch takes an inference forward (no tape of either kind) whose every layer fits the pipelined 128-feature tile
+    // (MOFA_CHAIN=0: per-layer launches — the bit-identical reference form; MOFA_PIPE=0 implies it)
+    auto chain_ok = [&]() {
+        if (tape || mask_tape || config().chain == 0 || config().pipe == 0 || steps.size() > 40) return false;
+        for (const Step& st : steps) {
+            const Layer& l = p.L[st.li];
+            const int kt = l.k_padded[0] / 16 + (st.x2 ? l.k_padded[1] / 16 : 0);
+            if (l.n_padded % 128 != 0 || kt < 4 || (kt & 1)) return false;
+            if (!st.x1 && (l.n_padded < 512 || st.y == t1)) return false;     // layer 0 through k_pe_panels, as below
+        }
+        return true;
+    };
     // ---- dispatch: one persistent launch for widths <= 256 (every layer of a point tile lives in one workgroup), else
     //      one launch per layer.  MOFA_FUSED=0/1 overrides the heuristic (tests / A-B).
     const Config& cfg = config();
@@ -408,6 +425,27 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
         if (mask_tape) {  // the view layer's per-ray-bias epilogue is not the contiguous-store one: its bits come from a pass over its output
             MOFA_TRY(mofa_internal_mask_pack(v, (long long)Mp * p.L[p.view].n_padded, mbits + mword(p.view), stream));
         }
+    } else if (chain_ok()) {
+        // Wide network, inference: ONE chained launch (k_net_chain, mofa_mlp.hip) over the tiles of every layer — the same tiles as the
+        // per-layer launches below (bit-identical), without their ~26 launch boundaries per sub-batch.  Layer 0 reads the encoding
+        // panels k_pe_panels leaves in t1 (layer 1 overwrites them row tile by row tile, after layer 0 is done with those rows).
+        MOFA_TRY(mofa_pe_panels(rays_o, rays_d, z, z_row_stride, pts, M, S, s.pe_point_freqs, Mp, t1, stream));
+        const int n = (int)steps.size();
+        std::vector<long long> x1(n), x2(n), yo(n), wo(n), bo(n);
+        std::vector<int> k1(n), k2(n), np(n), div(n), relu(n, 1);
+        for (int i = 0; i < n; ++i) {
+            const Layer& l = p.L[steps[i].li];
+            const bool view = steps[i].li == p.view;
+            x1[i] = (steps[i].x1 ? steps[i].x1 : t1) - workspace;
+            x2[i] = steps[i].x2 ? steps[i].x2 - workspace : 0;
+            yo[i] = steps[i].y - workspace;
+            wo[i] = (long long)l.packed_off, bo[i] = view ? 0 : (long long)l.folded_off;
+            k1[i] = l.k_padded[0] / 16, k2[i] = steps[i].x2 ? l.k_padded[1] / 16 : 0;
+            np[i] = l.n_padded, div[i] = view ? S : 0;
+        }
+        unsigned* state = (unsigned*)(vbias + (size_t)n_rays * p.Hp + 64);
+        MOFA_TRY(mofa_internal_chain_forward(workspace, packed, folded, view_bias_rows, n_rays, Mp, n, x1.data(), x2.data(), yo.data(), wo.data(),
+                                             bo.data(), k1.data(), k2.data(), np.data(), div.data(), relu.data(), state, stream));
     } else {
         for (const Step& st : steps) {
             const Layer& l = p.L[st.li];

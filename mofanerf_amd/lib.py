@@ -131,7 +131,7 @@ def load() -> C.CDLL:
     return _lib
 
 
-PROF_KINDS = 5     # MOFA_PROF_KINDS: k_layer fwd, k_mlp_fused, k_layer<BWD>, k_wgrad, k_layer fwd with per-ray bias (view layer)
+PROF_KINDS = 6     # MOFA_PROF_KINDS: k_layer fwd, k_mlp_fused, k_layer<BWD>, k_wgrad, k_layer fwd with per-ray bias (view layer), k_net_chain
 
 
 def reload_env() -> None:

@@ -622,6 +622,55 @@ def test_persistent_fused_network_is_bit_identical_to_per_layer_launches(D, W, R
     nan_equal_close(tapes[("1", True)].cpu().numpy(), outs["1"].cpu().numpy(), 2e-5)
 
 
+@pytest.mark.parametrize("D,W,R,S,busy", [(10, 1024, 150, 128, False), (8, 512, 300, 64, True), (10, 1024, 3, 128, False), (8, 768, 77, 64, True),
+                                          (10, 1024, 1536, 128, True)])
+def test_chained_wide_network_is_bit_identical_to_per_layer_launches(D, W, R, S, busy, knob):
+    """Widths > 256 run every MFMA layer of a sub-batch as ONE launch (k_net_chain: the layer kernel's tiles behind per-XCD queues and
+    row-tile dependency counters).  Every word of the output must equal the per-layer launches' (MOFA_CHAIN=0) — also on a re-used
+    workspace (the queue state of the previous launch is still in it), from 1 to 768 row tiles (the benchmark's sub-batch), and with
+    another stream keeping the chip unevenly busy (a hand-off that is only correct on an idle chip shows up there).  The kernel's
+    status words say that no dependency wait timed out and that every tile of every layer ran."""
+    from mofanerf_amd.hipnet import HipNet
+    from mofanerf_amd.model import NeRF
+    rng = np.random.default_rng(D + W + R)
+    net = NeRF(D=D, W=W, input_ch=93, input_ch_views=27, input_ch_textureCodes=256, input_ch_shapeCodes=50, use_viewdirs=True)
+    net.load_state_dict(synth.nerf_state(D, W, 1))
+    h = HipNet(net.to(DEV))
+    o = dev(rng.uniform(-2, 2, (R, 3)).astype(np.float32))
+    d = dev(rng.normal(0, 0.3, (R, 3)).astype(np.float32))
+    z = dev(np.sort(rng.uniform(8, 26, (R, S)).astype(np.float32), -1))
+    vd = torch.nn.functional.normalize(d, dim=-1).contiguous()
+    bm, tex, e = synth.codes(3)
+    folded = h.fold(e.to(DEV), bm.to(DEV), tex.to(DEV)).clone()
+
+    def run():
+        raw = torch.full((R, S, 4), float("nan"), device=DEV)
+        h.forward_rays(o, d, z, S, vd, S, raw, folded)
+        torch.cuda.synchronize()
+        return raw
+
+    knob("MOFA_CHAIN", "0")
+    ref = run()
+    assert torch.isfinite(ref).all()
+    knob("MOFA_CHAIN", "1")
+    Wp, Hp = (W + 63) // 64 * 64, (W // 2 + 63) // 64 * 64
+    mp = (R * S + 255) // 256 * 256
+    state0 = 4 * mp * Wp + R * Hp + 64                       # mofa_net_forward's workspace layout: the chain state follows the per-ray bias rows
+    tiles = (mp // 256) * ((4 + 2 * D) * (Wp // 128) + Hp // 128)
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV)
+    for it in range(3):
+        if busy:                                             # a competitor for the CUs while the chained launch runs
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    a @ a
+        out = run()
+        status = h._ws[0][state0 + 256: state0 + 258].view(torch.int32).tolist()
+        assert status == [0, tiles], (it, status, tiles)
+        assert torch.equal(out, ref), (it, float((out - ref).abs().max()))
+    side.synchronize()
+
+
 @pytest.mark.parametrize("D,W,R,S", [(8, 256, 300, 64), (10, 256, 90, 128), (8, 192, 77, 64), (8, 64, 50, 64), (10, 1024, 40, 128)])
 def test_mask_tape_equals_fp32_tape_across_kernels(D, W, R, S, knob):
     """The mask-only tape (one bit per activation) against the fp32 tape, per-layer launches against the persistent kernels (the
