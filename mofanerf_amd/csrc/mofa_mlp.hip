@@ -798,7 +798,8 @@ int launch_fused(const FusedArgs& a, hipStream_t st) {
 // complete while other CUs still finish layer l, and the launch drains once per sub-batch instead of once per layer.
 //
 //   * Queue: workgroups are persistent (two per CU); each pulls tile numbers from the head counter of the XCD it RUNS on
-//     (`s_getreg HW_REG_XCC_ID`, not an assumed blockIdx -> XCD map).  XCD x owns the point-row tiles [x m/8, (x+1) m/8) of every
+//     (`s_getreg HW_REG_XCC_ID`, not an assumed blockIdx -> XCD map; a one-time census per device checks that all eight XCDs get
+//     workgroups — mofa_internal_chain_supported — else the per-layer launches run).  XCD x owns the point-row tiles [x m/8, (x+1) m/8) of every
 //     layer, in layer-major order — a topological order, pulled in increasing order, so a tile only ever waits for tiles that
 //     RUNNING workgroups hold: no deadlock for any residency.  The next tile number is drawn one tile ahead.
 //   * Dependency: one counter per point-row tile, incremented once per finished tile of any layer; tile (layer s, rows m, *) waits
@@ -840,6 +841,12 @@ struct ChainArgs {
     ChainStep S[kMaxChainSteps];
 };
 static_assert(sizeof(ChainArgs) <= 4096, "kernel arguments are limited to 4 KiB");
+
+__global__ void k_xcc_census(unsigned* counts) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0) atomicAdd(counts + (xcc & 7u), 1u);
+}
 
 // What a workgroup of k_net_chain carries from tile to tile.  It rides into the K loop as the policy's `Probe` (the hook the loop calls
 // after every panel's wait + barrier), because two things belong BEHIND the next tile's first panel rather than between two tiles:
@@ -1309,6 +1316,34 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
     const int rc = launch_fused(a, st);
     prof_close(st, 1, flops);
     return rc;
+}
+
+// internal (used by mofa_net.hip): may this device take the chained launch?  k_net_chain gives every XCD the queue of its own number and
+// relies on all eight having workgroups (the default mode of the part: one device, 8 XCDs, round-robin dispatch).  A device whose
+// workgroups land on fewer XCDs (compute partitions) would leave queues unworked, so the first call per device COUNTS: a 512-workgroup
+// census of HW_REG_XCC_ID (one tiny launch and one stream synchronisation, once per device and process); anything but eight
+// populated XCDs selects the per-layer launches.
+static std::atomic<int> g_chain_census[kMaxDevices];       // 0: not taken, 1: eight XCDs seen, 2: fewer
+
+int mofa_internal_chain_supported(void* stream) {
+    const int dev = current_device();
+    int c = g_chain_census[dev].load(std::memory_order_acquire);
+    if (c) return c == 1;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* counts = nullptr;
+    unsigned host[8] = {};
+    bool ok = hipMalloc((void**)&counts, sizeof(host)) == hipSuccess && hipMemsetAsync(counts, 0, sizeof(host), st) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_xcc_census, dim3(2 * compute_units(dev)), dim3(64), 0, st, counts);
+        ok = hipMemcpyAsync(host, counts, sizeof(host), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    }
+    if (counts) (void)hipFree(counts);
+    (void)hipGetLastError();
+    int populated = 0;
+    for (unsigned v : host) populated += v > 0;
+    c = (ok && populated == 8) ? 1 : 2;
+    g_chain_census[dev].store(c, std::memory_order_release);
+    return c == 1;
 }
 
 // internal (used by mofa_net.hip): the MFMA layers of one WIDE network as one chained launch (k_net_chain).  `state`: at least

@@ -26,6 +26,7 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
                                 unsigned long long* mask_bits, const long long* mask_off, void* stream);
 int mofa_internal_mask_pack(const float* y, long long n_floats, unsigned long long* bits, void* stream);
 size_t mofa_internal_chain_state_words(long long m_padded);
+int mofa_internal_chain_supported(void* stream);
 int mofa_internal_chain_forward(float* arena, const float* packed, const float* folded, const float* view_bias_rows, long long bias_rows,
                                 long long m_padded, int n_steps, const long long* x1_off, const long long* x2_off, const long long* y_off,
                                 const long long* w_off, const long long* bias_off, const int* k1p, const int* k2p, const int* n_padded,
@@ -395,7 +396,7 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
             if (l.n_padded % 128 != 0 || kt < 4 || (kt & 1)) return false;
             if (!st.x1 && (l.n_padded < 512 || st.y == t1)) return false;     // layer 0 through k_pe_panels, as below
         }
-        return true;
+        return mofa_internal_chain_supported(stream) != 0;                     // (a one-time census per device: all eight XCDs get workgroups)
     };
     // ---- dispatch: one persistent launch for widths <= 256 (every layer of a point tile lives in one workgroup), else
     //      one launch per layer.  MOFA_FUSED=0/1 overrides the heuristic (tests / A-B).
