@@ -80,7 +80,7 @@ class NetFn(torch.autograd.Function):
     * ``"recompute"`` (``Renderer.tape_recompute``) — keep only the inputs and re-run the sub-batch's forward in tape mode inside the
       backward: one sub-batch's tape at a time (bounded by netchunk, not by N_rand), for one extra forward pass per step.  The
       re-run must reproduce the forward the loss saw: the weights are checked (``h._key()``); the library's two run-time knobs
-      (MOFA_PIPE / MOFA_FUSED) select between bit-identical forms of the one exact-fp32 arithmetic, so a ``reload_env()`` between
+      (MOFA_PIPE / MOFA_FUSED / MOFA_CHAIN) select between bit-identical forms of the one exact-fp32 arithmetic, so a ``reload_env()`` between
       forward and backward cannot change it (there is no other arithmetic mode in the library).
 
     ``pts`` given (``run_network(inputs, viewdirs, fn)`` under autograd): explicit points instead of ``o + d z``; the backward then

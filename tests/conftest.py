@@ -53,7 +53,7 @@ def nan_equal_close(a, b, atol, rtol=0.0):
 
 @pytest.fixture
 def knob(monkeypatch):
-    """Set one of the library's run-time knobs (MOFA_PIPE / MOFA_FUSED) for one test.  The library reads its knobs ONCE at load time (no getenv on the launch
+    """Set one of the library's run-time knobs (MOFA_PIPE / MOFA_FUSED / MOFA_CHAIN) for one test.  The library reads its knobs ONCE at load time (no getenv on the launch
     paths), so after changing the environment the snapshot is re-read explicitly — and once more when the test ends."""
     from mofanerf_amd import lib
 
