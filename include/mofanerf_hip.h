@@ -35,7 +35,8 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define MOFA_ABI_VERSION 2 /* 2: MofaNetShape carries the encoding / code widths; explicit-point backward; mask tape; no split modes */
+#define MOFA_ABI_VERSION 3 /* 2: MofaNetShape carries the encoding / code widths; explicit-point backward; mask tape; no split modes.
+                             3: MOFA_PROF_KINDS = 6 (mofa_prof_end's arrays grew by the chained kernel's entry); larger mofa_net_workspace_floats */
 #define MOFA_OK 0
 #define MOFA_EINVAL (-1)
 #define MOFA_EHIP (-2)

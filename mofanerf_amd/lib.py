@@ -19,7 +19,7 @@ _fp = C.c_void_p      # device pointers travel as integers
 _i32, _i64, _sz = C.c_int32, C.c_int64, C.c_size_t
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class NetShape(C.Structure):

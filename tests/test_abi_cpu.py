@@ -44,7 +44,7 @@ def test_library_exports_nothing_but_the_declared_abi():
 
 def test_plan_sizes_and_argument_validation():
     L = lib.load()
-    assert L.mofa_abi_version() == 2 == lib.ABI_VERSION
+    assert L.mofa_abi_version() == 3 == lib.ABI_VERSION
     for D, W in ((8, 256), (10, 1024), (8, 64)):
         s = lib.NetShape(D, W)
         assert L.mofa_net_num_layers(s) == 2 * D + 7 == len(schema.nerf_layers(D, W))
