@@ -58,6 +58,7 @@ struct Config {
 const Config& config();
 
 constexpr int kMaxDevices = 64;
+#define MOFA_MAX_CHAIN_STEPS 40    /* MFMA layers one chained launch (k_net_chain) can hold: its step table travels as kernel arguments */
 int current_device();              // hipGetDevice, clamped to [0, kMaxDevices)
 int compute_units(int device);     // multiProcessorCount, cached per device
 

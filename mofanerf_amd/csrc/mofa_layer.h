@@ -1,9 +1,11 @@
 // The fp32-MFMA layer kernel of the MoFaNeRF hot path and its building blocks (gfx950 only), shared by every translation
-// unit that launches it: mofa_mlp.hip (the product: per-layer launches + the persistent whole-network kernel) and
+// unit that launches it: mofa_mlp.hip (the product: per-layer launches, the persistent whole-network kernel of the <= 256-wide nets and the
+// chained launch of the wider ones, whose tiles are this kernel's) and
 // measure/mofa_measure.hip (measurement builds — time stamps, ablations, scheduling arms — built only by tools/).
 //
 // Replaces run_network/batchify/NeRF.forward of the reference (models/render_class.py:69-109, models/model.py:121-137, :202-230):
-// every Linear+bias+ReLU is one launch of k_layer, an LDS-tiled fp32 MFMA (v_mfma_f32_32x32x2_f32 — exact fp32, bitwise an
+// every Linear+bias+ReLU is a grid of k_layer tiles (one launch per layer, or all layers of a sub-batch behind one launch's queues:
+// k_net_chain), an LDS-tiled fp32 MFMA (v_mfma_f32_32x32x2_f32 — exact fp32, bitwise an
 // fmaf chain) GEMM whose operands arrive as ready-made, bank-swizzled LDS images ("panels") by direct global->LDS DMA.
 //
 // Formulation.  For a tile of 256 points (rows m) and BN output features (rows n):

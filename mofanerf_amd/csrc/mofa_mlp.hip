@@ -1,5 +1,6 @@
 // Product translation unit of the network kernels (gfx950): the per-layer launcher of k_layer (mofa_layer.h) with the shipped
-// policy only, the persistent whole-network kernel k_mlp_fused for widths <= 256, the small kernels around them (heads, per-ray
+// policy only, the persistent whole-network kernel k_mlp_fused for widths <= 256, the chained launch k_net_chain of the wider networks (the
+// layer kernel's tiles behind per-XCD queues and row-tile dependency counters), the small kernels around them (heads, per-ray
 // view bias, folded biases, panel packing, positional encoding) and their C ABI.  No measurement arms live here: scheduling
 // experiments, time-stamp builds and ablations are csrc/measure/mofa_measure.hip (built only by tools/build_measure.py into
 // its own library).
@@ -814,7 +815,7 @@ int launch_fused(const FusedArgs& a, hipStream_t st) {
 //   * The tile itself is k_layer<128, .., PIPE>'s: same panels, same K loop, same epilogues — bit-identical to per-layer launches.
 // State (zeroed by a memset node ahead of every launch): 8 heads at a 128-byte stride, a status word, the per-row-tile counters.
 // ======================================================================================================
-constexpr int kMaxChainSteps = 40;
+constexpr int kMaxChainSteps = MOFA_MAX_CHAIN_STEPS;
 constexpr int kChainHeadStride = 32;                 // unsigned words between two XCDs' queue heads (one 128-byte line each)
 constexpr int kChainStatus = 8 * kChainHeadStride;   // [0] bit 0: a dependency wait timed out; [1]: tiles finished (all XCDs)
 constexpr int kChainDone = kChainStatus + 32;        // done[m_tiles]

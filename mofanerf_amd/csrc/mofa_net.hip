@@ -389,7 +389,7 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     // the chained launch takes an inference forward (no tape of either kind) whose every layer fits the pipelined 128-feature tile
     // (MOFA_CHAIN=0: per-layer launches — the bit-identical reference form; MOFA_PIPE=0 implies it)
     auto chain_ok = [&]() {
-        if (tape || mask_tape || config().chain == 0 || config().pipe == 0 || steps.size() > 40) return false;
+        if (tape || mask_tape || config().chain == 0 || config().pipe == 0 || steps.size() > MOFA_MAX_CHAIN_STEPS) return false;
         for (const Step& st : steps) {
             const Layer& l = p.L[st.li];
             const int kt = l.k_padded[0] / 16 + (st.x2 ? l.k_padded[1] / 16 : 0);
@@ -398,8 +398,9 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
         }
         return mofa_internal_chain_supported(stream) != 0;                     // (a one-time census per device: all eight XCDs get workgroups)
     };
-    // ---- dispatch: one persistent launch for widths <= 256 (every layer of a point tile lives in one workgroup), else
-    //      one launch per layer.  MOFA_FUSED=0/1 overrides the heuristic (tests / A-B).
+    // ---- dispatch: one persistent launch for widths <= 256 (every layer of a point tile lives in one workgroup); wider networks: one
+    //      chained launch over the tiles of every layer (inference), else one launch per layer.  MOFA_FUSED=0/1 and MOFA_CHAIN=0 override
+    //      the choice (tests / A-B).
     const Config& cfg = config();
     const bool fused = cfg.fused >= 0 ? cfg.fused == 1 : (p.Wp <= 256 && Mp / kRowTile >= 128);
     if (fused) {
