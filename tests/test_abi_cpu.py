@@ -125,6 +125,18 @@ def test_hipnet_refuses_a_module_the_plan_does_not_describe():
         type(render)(embed_fn=lambda x: x)
 
 
+def test_profiler_kinds_agree_between_header_binding_and_bench():
+    """mofa_prof_end fills arrays of MOFA_PROF_KINDS entries: the header, the ctypes binding and bench.py's kernel table must agree
+    (a shorter array on the Python side would be overrun by the library)."""
+    import re, sys
+    hdr = open(os.path.join(ROOT, "include", "mofanerf_hip.h")).read()
+    n = int(re.search(r"#define MOFA_PROF_KINDS (\d+)", hdr).group(1))
+    sys.path.insert(0, ROOT)
+    import bench
+    assert n == lib.PROF_KINDS == len(bench.KERNELS) == 6
+    assert bench.KERNELS[5][0] == "mofa::k_net_chain" and bench.KERNELS[1][0] == "mofa::k_mlp_fused"
+
+
 def test_product_never_imports_the_oracle():
     """The product package must not reach into oracle/ (nor any CPU fallback): grep the sources."""
     pkg = os.path.join(ROOT, "mofanerf_amd")
@@ -143,12 +155,16 @@ def test_hot_kernels_fit_their_occupancy_without_scratch():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_resources
     rs = {r["kernel"]: r for r in kernel_resources.resources(build.build())}
-    hot = [k for k in rs if k.startswith(("mofa::k_layer<", "mofa::k_mlp_fused", "mofa::k_wgrad<"))]
-    assert len(hot) >= 15, sorted(rs)
+    hot = [k for k in rs if k.startswith(("mofa::k_layer<", "mofa::k_mlp_fused", "mofa::k_wgrad<", "mofa::k_net_chain"))]
+    assert len(hot) >= 16 and "mofa::k_net_chain" in hot, sorted(rs)
     for k in hot:
         r = rs[k]
         assert r["scratch"] == 0 and r["vgpr_spill"] == 0, (k, r)
         assert r["vgpr"] + r["agpr"] <= 256, (k, r)
+    # the chained launch keeps 512 workgroups resident (two per CU): its registers AND its scalar state must leave room for that — an
+    # in-kernel queue-adoption variant that reached 100 SGPRs measured 1.6 % slower (profiles/r04_ab_chain.txt)
+    chain = rs["mofa::k_net_chain"]
+    assert chain["vgpr"] <= 240 and chain["sgpr"] <= 100 and chain["sgpr_spill"] == 0, chain
     dom = rs["mofa::k_layer<128, false, false, false, true, mofa::ShippedPolicy>"]
     assert dom["vgpr"] <= 200 and dom["agpr"] == 0, dom            # 197 since round 2; the refactor into mofa_layer.h + policy did not move it
     for k, r in rs.items():                                        # the ray-side kernels run many rays per CU: keep them light
