@@ -52,8 +52,9 @@ KERNELS = [("mofa::k_layer<128,false,false,false,true,mofa::ShippedPolicy>", "fo
            ("mofa::k_layer<128,false,true,false,true,mofa::ShippedPolicy>", "BWD backward-data", "fp32 MFMA backward-data GEMM + ReLU mask, the same K loop"),
            ("mofa::k_wgrad<128,256>", "weight gradient", "fp32 MFMA weight-gradient GEMM, contraction over points"),
            ("mofa::k_layer<128,false,false,true,true,mofa::ShippedPolicy>", "forward, PERRAY view layer", "the same kernel with the view layer's per-ray bias"),
-           ("mofa::k_net_chain", "forward, chained", "every fp32-MFMA layer of a wide network in one launch: the layer kernel's tiles behind per-XCD queues and "
-                                                     "row-tile dependency counters")]
+           ("mofa::k_net_chain<0>", "forward, chained", "every fp32-MFMA layer of a wide network in one launch: the layer kernel's tiles behind per-XCD queues and "
+                                                        "row-tile dependency counters (<1>: the same, also writing the mask tape)"),
+           ("mofa::k_net_chain<2>", "BWD backward-data, chained", "the backward-data products of a wide network's fitting step in two launches of the same queues")]
 
 
 def pose_spherical(phi_deg, theta_deg, radius):

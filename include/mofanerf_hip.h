@@ -9,7 +9,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer to fp32 unless stated; the caller owns every buffer
  *     (PyTorch's caching allocator in the shipped host layer); nothing here allocates or frees.
- *   - `stream` is a hipStream_t passed as void*; no entry point synchronises the host.
+ *   - `stream` is a hipStream_t passed as void*; no entry point synchronises the host — with ONE exception, mofa_device_init(), the
+ *     explicit per-device initialisation (and mofa_prof_end(), which collects a measurement).
  *   - return 0 on success, MOFA_EINVAL for a bad argument, MOFA_EHIP if a launch failed
  *     (hipGetLastError text via mofa_last_error()).
  *   - kernels are stateless and re-entrant per stream.
@@ -35,8 +36,10 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define MOFA_ABI_VERSION 3 /* 2: MofaNetShape carries the encoding / code widths; explicit-point backward; mask tape; no split modes.
-                             3: MOFA_PROF_KINDS = 6 (mofa_prof_end's arrays grew by the chained kernel's entry); larger mofa_net_workspace_floats */
+#define MOFA_ABI_VERSION 4 /* 2: MofaNetShape carries the encoding / code widths; explicit-point backward; mask tape; no split modes.
+                             3: MOFA_PROF_KINDS = 6 (mofa_prof_end's arrays grew by the chained kernel's entry); larger mofa_net_workspace_floats
+                             4: mofa_device_init(); `verdict` words of mofa_net_forward / mofa_net_backward; MOFA_PROF_KINDS = 7; larger
+                                mofa_net_backward_workspace_floats */
 #define MOFA_OK 0
 #define MOFA_EINVAL (-1)
 #define MOFA_EHIP (-2)
@@ -64,6 +67,23 @@ const char* mofa_last_error(void);   /* thread-local text of the calling thread'
  *     Measurement arms (scheduling experiments, time stamps, ablations) are NOT in this library: csrc/measure/, tools/build_measure.py.
  *   - per-device caches (CU count, a one-time function attribute) and the per-device measurement session below. */
 int mofa_config_reload(void);
+
+/* Per-device initialisation — the ONE entry point that allocates (a 32-byte scratch, freed again) and synchronises `stream`.  Call it
+ * once per device before the first mofa_net_forward (the shipped host layer does, in HipNet.__init__).  It takes the XCD census the
+ * chained launch of the wide networks relies on (k_net_chain: one tile queue per XCD — all eight must receive workgroups) and sets
+ * the persistent kernel's LDS attribute.  xcd_workgroups: NULL, or 8 ints receiving the census (workgroups of a 2-per-CU launch seen
+ * on each XCD).  Without it — or on a device whose census finds fewer than eight XCDs (compute partitions) — the wide networks run as
+ * per-layer launches: bit-identical, slower; mofa_net_forward / mofa_net_backward themselves never allocate or synchronise. */
+int mofa_device_init(void* stream, int32_t* xcd_workgroups);
+
+/* Launch verdicts.  A chained launch (k_net_chain) replaces launch boundaries by an inter-workgroup protocol; if that protocol ever
+ * fails — a dependency wait out of budget, a tile queue nobody worked (CU-masked stream) — the kernel does NOT compute on incomplete
+ * inputs: the launch ends incomplete, a verification kernel behind it overwrites the call's outputs (raw_out; the gradients) with NaN
+ * and raises these words.  `verdict`: NULL, or MOFA_VERDICT_WORDS uint32 on the device, zeroed ONCE by the caller and then sticky:
+ *   [0] bit 0 = a wait timed out, bit 1 = tiles missing (0 = every chained launch so far was complete)
+ *   [1] chained launches verified   [2] [3] [4] the last launch's flags / finished tiles / expected tiles   [5] bad launches.
+ * The host reads them back whenever it likes (asynchronously in the shipped layer) — [0] != 0 is an error, never a result. */
+#define MOFA_VERDICT_WORDS 8
 
 /* ---- network description -------------------------------------------------------------------
  * NeRF(D, W, input_ch, input_ch_views, input_ch_textureCodes, input_ch_shapeCodes, use_viewdirs=True, skips=[4]) of
@@ -121,11 +141,12 @@ int mofa_net_fold(MofaNetShape s, const float* const* weights, const float* cons
  *         backward needs when no weight gradient is asked for (fitting: run_fit.py:305-313 never steps the networks).  The
  *         activations themselves are recycled as in inference: 1/32 of the tape, no recomputation.  Excludes `tape`.
  *   view_bias_rows: NULL (computed here from viewdirs), or caller-provided per-ray bias rows [n_rays, roundup(W/2,64)]
- *         (the autograd path computes them on the host so that gradients reach viewdirs and the 27 view columns) */
+ *         (the autograd path computes them on the host so that gradients reach viewdirs and the 27 view columns)
+ *   verdict: NULL or the caller's sticky launch-verdict words (above). */
 int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, const float* view_w,
                      const float* view_b, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
                      const float* pts, const float* viewdirs, int64_t n_rays, int32_t S, float* workspace,
-                     float* raw_out, float* tape, uint64_t* mask_tape, const float* view_bias_rows, void* stream);
+                     float* raw_out, float* tape, uint64_t* mask_tape, const float* view_bias_rows, uint32_t* verdict, void* stream);
 /* ---- backward (run_fit.py:305-313 photometric fitting, run_train.py:333-357 training) -----------------------
  * Backward of mofa_net_forward given d_raw [n_rays,S,4] and the tape (fp32, or mask-only when d_weights == NULL) of that forward:
  *   d_folded  [mofa_net_folded_floats]: gradient w.r.t. every folded bias (sum over points of the ReLU-masked
@@ -144,7 +165,8 @@ int mofa_net_pack_t(MofaNetShape s, const float* const* weights, float* packed_t
 int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t, const float* tape, const uint64_t* mask_tape,
                       const float* d_raw, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
                       const float* pts, int64_t n_rays, int32_t S, float* workspace, float* d_folded,
-                      float* d_view_bias_rows, float* d_rays_o, float* d_rays_d, float* d_pts, float* const* d_weights, void* stream);
+                      float* d_view_bias_rows, float* d_rays_o, float* d_rays_d, float* d_pts, float* const* d_weights, uint32_t* verdict,
+                      void* stream);
 /* d_weights: NULL (fitting: only codes/pose are optimised), or 2D+7 pointers to [out,in] gradient tensors in state-dict
  * order: the per-point column blocks are OVERWRITTEN with dW = G^T X (fp32 MFMA, contraction over the points, split over
  * M with a deterministic second-stage sum); the per-call-constant columns are left untouched (host autograd owns them). */
@@ -225,11 +247,11 @@ int mofa_positional_encode(const float* x, int64_t n, int32_t n_freqs, float* ou
  * kernels — [0] the per-layer forward kernel k_layer<128,..,PIPE> (128-feature tile, pipelined K loop), [1] the persistent
  * whole-network kernel k_mlp_fused (widths <= 256), [2] the backward-data kernel k_layer<128,..,BWD>, [3] the
  * weight-gradient kernel k_wgrad, [4] the view layer's per-ray-bias instantiation of the forward kernel, [5] the chained
- * wide-network kernel k_net_chain — is bracketed by
+ * wide-network kernel k_net_chain (forward: inference or tape-keeping), [6] its backward-data instantiation — is bracketed by
  * hipEventRecord on its own stream.  mofa_prof_end() synchronises those
  * events (host blocks) and fills three arrays of length MOFA_PROF_KINDS: summed kernel time, launch count, FLOPs
  * executed (2*M*K*N of the padded shapes).  Used by bench.py only. */
-#define MOFA_PROF_KINDS 6
+#define MOFA_PROF_KINDS 7
 int mofa_prof_begin(void);
 int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops);
 

@@ -91,10 +91,12 @@ class NetFn(torch.autograd.Function):
         L = h._L
         raw = torch.empty(R, S, 4, dtype=torch.float32, device=fo.device)
         ws = h.workspace(R * S, R, fo.device)
+        h.check_verdict()
         lib.check(L.mofa_net_forward(h.shape, lib.ptr(h.packed()), lib.ptr(fo), None, None, lib.ptr(ro), lib.ptr(rd),
                                      lib.ptr(zc), z_row_stride, lib.ptr(pts), None, R, S, lib.ptr(ws), lib.ptr(raw), lib.ptr(tape),
-                                     mask.data_ptr() if mask is not None else None, lib.ptr(vb), lib.stream()),
+                                     mask.data_ptr() if mask is not None else None, lib.ptr(vb), h.verdict_ptr(fo.device), lib.stream()),
                   "mofa_net_forward(tape)" if tape is not None else "mofa_net_forward")
+        h.snapshot_verdict()
         return raw
 
     @staticmethod
@@ -172,7 +174,8 @@ class NetFn(torch.autograd.Function):
                                       mask.data_ptr() if mask is not None else None, lib.ptr(d_raw),
                                       lib.ptr(ro), lib.ptr(rd), lib.ptr(zc), ctx.z_row_stride, lib.ptr(pc), R, S, lib.ptr(ws),
                                       lib.ptr(d_folded), lib.ptr(d_vb), lib.ptr(d_o), lib.ptr(d_d), lib.ptr(d_p),
-                                      lib.ptr_array(dws) if dws else None, lib.stream()), "mofa_net_backward")
+                                      lib.ptr_array(dws) if dws else None, h.verdict_ptr(dev), lib.stream()), "mofa_net_backward")
+        h.snapshot_verdict()
         del tape, mask
         return (None, d_o, d_d, None, None, None, d_folded, d_vb, d_p, *dws)
 

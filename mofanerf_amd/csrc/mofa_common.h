@@ -54,11 +54,31 @@ struct Config {
     int fused = -1;       // MOFA_FUSED=0/1: persistent whole-network kernel off / on
     int pipe = -1;        // MOFA_PIPE=0: the plain K loops (layer kernel, persistent kernel, weight gradient) instead of the pipelined ones
     int chain = -1;       // MOFA_CHAIN=0: per-layer launches for the wide networks instead of the chained launch (k_net_chain)
+    unsigned chain_spin = 1u << 22;   // MOFA_CHAIN_SPIN_LIMIT (tests only): polls before a dependency wait of k_net_chain gives up
 };
 const Config& config();
 
 constexpr int kMaxDevices = 64;
 #define MOFA_MAX_CHAIN_STEPS 40    /* MFMA layers one chained launch (k_net_chain) can hold: its step table travels as kernel arguments */
+// One GEMM of a chained launch (k_net_chain, mofa_mlp.hip): a forward layer (Linear + bias + ReLU) or a backward-data product, as the
+// driver (mofa_net.hip) lists them in a topological order.  Plain pointers: the buffers of one launch live in several allocations
+// (workspace, tape, packed weights, folded biases).
+struct ChainStep {
+    const float* x1;            // operand panels [k1p][m_padded][16]
+    const float* x2;            // second source of a skip layer's contraction, or NULL
+    float* y;                   // output panels [n_padded / 16][m_padded][16]
+    const float* w;             // packed weights (forward) / transposed pack (backward), panels [(k1p + k2p)][n_padded][16]
+    const float* aux;           // forward: the bias row (bias_row_div == 0) or the per-ray bias rows; backward: the saved fp32 activation the
+                                // result is masked with, or NULL
+    unsigned long long* bits;   // forward with a mask tape: where (y > 0) goes as bits (NULL: none); backward: the mask bits (NULL: none)
+    int k1p, k2p, n_padded, n_tiles;
+    int bias_row_div;           // forward: 0, or points per bias row (the view layer's per-ray rows)
+    int flags;                  // forward: bit 0 = ReLU; backward: bit 0 = accumulate into y
+    int tiles_before;           // filled by the launcher: tiles of the earlier steps over one row tile
+    int pad_;
+};
+enum ChainMode { kChainForward = 0, kChainForwardMask = 1, kChainBackward = 2 };
+
 int current_device();              // hipGetDevice, clamped to [0, kMaxDevices)
 int compute_units(int device);     // multiProcessorCount, cached per device
 

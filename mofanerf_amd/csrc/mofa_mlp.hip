@@ -366,8 +366,7 @@ struct FusedEpi {
     float* win;                       // wave-private 1024-float window
     float* pass0;                     // wave 0 (when the next layer reads this output first): the two stages' X regions, where output
     float* pass1;                     //   slices 0 / 1 are formed — they ARE the next layer's operand panels 0 / 1; else nullptr
-    unsigned long long* mask_out;     // mask-only tape bits of this layer (MASKW) or nullptr
-};
+};                                    // (no mask-tape output: a forward that keeps mask bits takes k_mlp_fused_generic<true>, launch_fused)
 
 // EPI = true (the ordinary layers): the epilogue runs INSIDE the tail.  After the last panel's first half every wave has read its
 // last fragments, so one barrier frees both stages; the requests for the next layer's panel 1 and bias row go out, and the last 32
@@ -725,7 +724,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
             // layer's operand panels 0 / 1 always come straight from this epilogue: wave 0 forms them in the stages' X regions
             const bool pass = wn == 0;
             const FusedEpi ep{smem + kFsBias + (li & 1) * 256 + wn * 64, const_cast<float*>(a.arena) + l.y_off, a.m_padded, m0, wn * 64, win,
-                              pass ? smem : nullptr, pass ? smem + STAGE : nullptr, nullptr};
+                              pass ? smem : nullptr, pass ? smem + STAGE : nullptr};
             auto pre = [&]() { prefetch(nx, li + 1, false); };
             // ONE instantiation for every ordinary layer (three would meet in register copies of the 128 accumulators): the tail always
             // requests four 1 KiB rounds of the next layer's weight panel 0 — for the 128-row view layer the upper two land in rows the
@@ -772,7 +771,7 @@ int launch_fused(const FusedArgs& a, hipStream_t st) {
     const int grid = half_tiles < 2 * cus ? half_tiles : 2 * cus;      // two resident workgroups per CU
     // (a fitting forward — mask-only tape — takes the generic kernel: its four ballots per KiB of output do not fit the register file
     //  next to the pipelined kernel's fragments without spilling, and it runs 1,024 rays, not frames)
-    if (fused_fast_shape(a) && !a.mask_bits) {
+    if (fused_fast_shape(a) && !a.mask_bits) {                         // (k_mlp_fused writes no mask bits: the condition above is its guard)
         const size_t lds = (size_t)kFsFloats * sizeof(float);          // 66 KiB: above the 64 KiB default limit of dynamic LDS
         if (!g_fused_attr[dev].load(std::memory_order_acquire)) {      // one-time function attribute per device
             if (hipFuncSetAttribute((const void*)k_mlp_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -790,55 +789,51 @@ int launch_fused(const FusedArgs& a, hipStream_t st) {
 
 
 // ======================================================================================================
-// k_net_chain: the WIDE network (widths > 256: every layer is a grid of 256-point x 128-feature tiles of the layer kernel) as ONE
-// launch.  A per-layer launch ends when its slowest CU has finished its last tile — at 12 tile rounds per launch the fill and the
-// drain cost 2.5 % of every one of the ~26 launches of a sub-batch (profiles/r02_timeline_*.md; a 4x larger netchunk measures 0.949
-// instead of 0.938 for exactly that reason).  Here the tiles of ALL layers form one queue per XCD and the only thing a tile waits
-// for is what it really depends on: the tiles of the previous layers over ITS OWN 256 point rows (layers are row-wise: Linear + bias
-// + ReLU, concatenations of row-aligned tensors).  So a CU that is done with layer l starts layer l + 1 on rows whose inputs are
-// complete while other CUs still finish layer l, and the launch drains once per sub-batch instead of once per layer.
+// k_net_chain: the GEMMs of a WIDE network (widths > 256: every layer is a grid of 256-point x 128-feature tiles of the layer kernel)
+// as ONE launch — the forward layers of a sub-batch (inference, or keeping a tape: fp32 or mask bits), or the backward-data products
+// of a fitting step.  A per-layer launch ends when its slowest CU has finished its last tile — at 12 tile rounds per launch the fill
+// and the drain cost 2.5 % of every one of the ~26 launches of a sub-batch (profiles/r02_timeline_*.md; a 4x larger netchunk measures
+// 0.949 instead of 0.938 for exactly that reason).  Here the tiles of ALL steps form one queue per XCD and the only thing a tile waits
+// for is what it really depends on: the tiles of the earlier steps over ITS OWN 256 point rows (every step is row-wise: Linear + bias
+// + ReLU or dX = G W^T with a row-aligned mask, concatenations / accumulations of row-aligned tensors).  So a CU that is done with
+// step l starts step l + 1 on rows whose inputs are complete while other CUs still finish step l, and the launch drains once per
+// sub-batch instead of once per layer.
 //
 //   * Queue: workgroups are persistent (two per CU); each pulls tile numbers from the head counter of the XCD it RUNS on
-//     (`s_getreg HW_REG_XCC_ID`, not an assumed blockIdx -> XCD map; a one-time census per device checks that all eight XCDs get
-//     workgroups — mofa_internal_chain_supported — else the per-layer launches run).  XCD x owns the point-row tiles [x m/8, (x+1) m/8) of every
-//     layer, in layer-major order — a topological order, pulled in increasing order, so a tile only ever waits for tiles that
-//     RUNNING workgroups hold: no deadlock for any residency.  The next tile number is drawn one tile ahead.
-//   * Dependency: one counter per point-row tile, incremented once per finished tile of any layer; tile (layer s, rows m, *) waits
-//     until done[m] has reached the number of tiles the layers before s have over those rows.  The same rule covers the buffers the
-//     plan recycles (a layer overwrites rows only after every reader of the old contents of those rows — the previous layer over the
-//     same rows — is complete).
+//     (`s_getreg HW_REG_XCC_ID`, not an assumed blockIdx -> XCD map; mofa_device_init() takes a census per device that all eight XCDs
+//     get workgroups, else the per-layer launches run).  XCD x owns the point-row tiles [x m/8, (x+1) m/8) of every step, in
+//     step-major order — the driver lists the steps in a topological order, pulled in increasing order, so a tile only ever waits for
+//     tiles that RUNNING workgroups hold: no deadlock for any residency.  The next tile number is drawn one tile ahead.
+//   * Dependency: one counter per point-row tile, incremented once per finished tile of any step; tile (step s, rows m, *) waits
+//     until done[m] has reached the number of tiles the steps before s have over those rows.  Conservative for a step list that is
+//     not a chain (the backward's skip branches), and the same rule covers the buffers the plan recycles or accumulates into (a step
+//     overwrites rows only after every earlier reader / writer of those rows is complete).
 //   * Visibility: producer and consumer of a row tile are by construction on the same XCD, whose L2 is their point of coherence:
 //     the producer's plain stores are acknowledged by that L2 (`s_waitcnt vmcnt(0)` in every wave, then a barrier) before one lane
-//     bumps the counter; the consumer polls the counter with relaxed agent-scope loads and requests its activation panels with
-//     `sc1` LDS-DMA loads, which the L2 serves and this CU's vector L1 (never refreshed by other CUs' stores) cannot.  Weights, biases
-//     and the per-ray bias rows were written by earlier launches and use the default policy.
+//     bumps the counter; the consumer polls the counter with relaxed agent-scope loads and requests its operand panels with
+//     `sc1` LDS-DMA loads, which the L2 serves and this CU's vector L1 (never refreshed by other CUs' stores) cannot; the backward's
+//     accumulate epilogue reads the running sum with agent-scope loads for the same reason.  Weights, biases, masks and the per-ray
+//     bias rows were written by earlier launches and use the default policy.
 //   * The tile itself is k_layer<128, .., PIPE>'s: same panels, same K loop, same epilogues — bit-identical to per-layer launches.
-// State (zeroed by a memset node ahead of every launch): 8 heads at a 128-byte stride, a status word, the per-row-tile counters.
+//   * Failure is LOUD.  A dependency wait that exceeds its poll budget (seconds) — or that sees another
+//     workgroup's time-out flag — sets status bit 0 and the workgroup ABANDONS the launch: it computes nothing further (never a tile
+//     on incomplete inputs), so the launch ends with fewer finished tiles than it has.  An XCD that received no workgroups (a CU-masked
+//     stream, a partition change after the census) leaves its queue unworked with the same result.  k_chain_verify, enqueued behind
+//     every chained launch (after the heads), compares {time-out flag, finished tiles} with what the launch must have produced and on
+//     any difference overwrites the launch's outputs with NaN — the image / the gradients cannot look plausible — and raises the
+//     caller's sticky verdict words, which the host layer reads back asynchronously and turns into MofaError.
+// State (zeroed by a memset node ahead of every launch): 8 heads at a 128-byte stride, two status words, the per-row-tile counters.
 // ======================================================================================================
 constexpr int kMaxChainSteps = MOFA_MAX_CHAIN_STEPS;
 constexpr int kChainHeadStride = 32;                 // unsigned words between two XCDs' queue heads (one 128-byte line each)
 constexpr int kChainStatus = 8 * kChainHeadStride;   // [0] bit 0: a dependency wait timed out; [1]: tiles finished (all XCDs)
 constexpr int kChainDone = kChainStatus + 32;        // done[m_tiles]
-constexpr unsigned kChainSpinLimit = 1u << 22;       // polls (each >= ~1 us with its s_sleep) before a wait gives up: seconds, never a hang
-
-struct ChainStep {
-    long long x1_off, x2_off, y_off;  // float offsets into the activation arena
-    long long w_off;                  // into the packed weights
-    long long bias_off;               // into `folded` (bias_row_div == 0) or into `view_bias_rows`
-    int k1p, k2p, n_padded, n_tiles;  // 16-wide K panels per source; features; n_padded / 128
-    int bias_row_div, relu;
-    int tiles_before;                 // sum of n_tiles over the earlier steps = what done[m] must have reached
-    int pad_;
-};
 
 struct ChainArgs {
-    float* arena;
-    const float* packed;
-    const float* folded;
-    const float* view_bias_rows;
     unsigned* state;
     long long m_padded, bias_rows;
     int m_tiles, n_steps, tiles_per_m;
+    unsigned spin_limit;              // polls (each >= ~1 us with its s_sleep) before a wait gives up: seconds, never a hang
     ChainStep S[kMaxChainSteps];
 };
 static_assert(sizeof(ChainArgs) <= 4096, "kernel arguments are limited to 4 KiB");
@@ -847,6 +842,27 @@ __global__ void k_xcc_census(unsigned* counts) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     if (threadIdx.x == 0) atomicAdd(counts + (xcc & 7u), 1u);
+}
+
+// Behind every chained launch: did every tile of every step run, with no wait abandoned?  If not, the outputs of the launch are
+// overwritten with NaN (up to four buffers) and the sticky verdict words of the caller are raised:
+//   verdict[0] |= 1 (a wait timed out) | 2 (tiles missing);  [1] += 1 (launches verified);  [2], [3], [4] = this launch's flags,
+//   finished tiles, expected tiles;  [5] += 1 per bad launch.
+__global__ __launch_bounds__(256) void k_chain_verify(const unsigned* __restrict__ status, unsigned expect, unsigned* __restrict__ verdict,
+                                                      float* p0, long long n0, float* p1, long long n1, float* p2, long long n2, float* p3, long long n3) {
+    const unsigned flags = status[0], finished = status[1];
+    const bool bad = flags != 0u || finished != expect;
+    if (verdict && blockIdx.x == 0 && threadIdx.x == 0) {
+        verdict[1] += 1u, verdict[2] = flags, verdict[3] = finished, verdict[4] = expect;
+        if (bad) verdict[0] |= (flags ? 1u : 0u) | (finished != expect ? 2u : 0u), verdict[5] += 1u;
+    }
+    if (!bad) return;
+    const float nan = __builtin_nanf("");
+    const long long stride = (long long)gridDim.x * 256, t0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (long long i = t0; i < n0; i += stride) p0[i] = nan;
+    for (long long i = t0; i < n1; i += stride) p1[i] = nan;
+    for (long long i = t0; i < n2; i += stride) p2[i] = nan;
+    for (long long i = t0; i < n3; i += stride) p3[i] = nan;
 }
 
 // What a workgroup of k_net_chain carries from tile to tile.  It rides into the K loop as the policy's `Probe` (the hook the loop calls
@@ -895,10 +911,74 @@ struct ChainPolicy : ShippedPolicy {
     };
 };
 
+// Backward-data epilogue of a chained step whose running sum (ACC) was written by ANOTHER workgroup of the same launch: the same
+// arithmetic as store_tile_staged_bwd, with the old value read at agent scope (served by the XCD's L2, see "Visibility").
+template <int NI, int NJ, int MASK>
+__device__ __forceinline__ void chain_store_bwd_acc(const f32x16 (&acc)[NI][NJ], float* __restrict__ y, const float* __restrict__ mask,
+                                                    long long m_padded, long long m_first, int n_first, int lane, float* win,
+                                                    const unsigned long long* __restrict__ mask_bits) {
+    const int lr = lane & 31, g = lane >> 5, msw = (lr >> 2) & 3;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh) {
+            const long long poff = ((long long)((n_first >> 4) + 2 * i + qh) * m_padded + m_first) * 16;
+#pragma unroll
+            for (int jh = 0; jh < NJ / 2; ++jh) {
+                const long long off = poff + jh * 1024 + lane * 4;
+                f32x4 old[4], act[4];
+                unsigned long long mb[4][4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const float* o = y + off + it * 256;
+                    old[it].x = __hip_atomic_load(o + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    old[it].y = __hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    old[it].z = __hip_atomic_load(o + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    old[it].w = __hip_atomic_load(o + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if constexpr (MASK == 1) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) act[it] = *(const f32x4*)(mask + off + it * 256);
+                }
+                if constexpr (MASK == 2) {
+                    const unsigned long long* w = mask_bits + ((poff + jh * 1024) >> 8) * 4;
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) mb[it][c] = w[it * 4 + c];
+                }
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const int j = 2 * jh + jj, q = 2 * qh + qq;
+                        f32x4 v;
+                        v.x = acc[i][j][4 * q + 0], v.y = acc[i][j][4 * q + 1], v.z = acc[i][j][4 * q + 2], v.w = acc[i][j][4 * q + 3];
+                        *(f32x4*)(win + (32 * jj + lr) * 16 + (((2 * qq + g) ^ msw) << 2)) = v;
+                    }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    f32x4 v = *(const f32x4*)(win + it * 256 + lane * 4);
+                    v.x += old[it].x, v.y += old[it].y, v.z += old[it].z, v.w += old[it].w;
+                    if constexpr (MASK == 1)
+                        v.x = act[it].x > 0.f ? v.x : 0.f, v.y = act[it].y > 0.f ? v.y : 0.f, v.z = act[it].z > 0.f ? v.z : 0.f,
+                        v.w = act[it].w > 0.f ? v.w : 0.f;
+                    if constexpr (MASK == 2)
+                        v.x = ((mb[it][0] >> lane) & 1ull) ? v.x : 0.f, v.y = ((mb[it][1] >> lane) & 1ull) ? v.y : 0.f,
+                        v.z = ((mb[it][2] >> lane) & 1ull) ? v.z : 0.f, v.w = ((mb[it][3] >> lane) & 1ull) ? v.w : 0.f;
+                    *(f32x4*)(y + off + it * 256) = v;
+                }
+            }
+        }
+}
+
+// MODE: kChainForward (inference and fp32-tape forwards: the same epilogues, the outputs simply are tape slots), kChainForwardMask (the
+// contiguous-store epilogue also writes (y > 0) as bits), kChainBackward (backward-data epilogues).
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_net_chain(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BM = kRowTile, BN = 128, NI = 2, NJ = 4, STAGE = (BM + BN) * 16;
-    int* const slot = (int*)(smem + 2 * STAGE);       // [0] next tile number, [1] "its inputs are known to be complete": thread 0 -> workgroup
+    int* const slot = (int*)(smem + 2 * STAGE);       // [0] next tile number, [1] "its inputs are known to be complete", [2] "the wait ended well": thread 0 -> workgroup
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wm = wave >> 1;
@@ -919,7 +999,6 @@ __global__ __launch_bounds__(256, 2) void k_net_chain(const ChainArgs a) {
     __syncthreads();
     int q = slot[0], ready = 0;
     int s = 0;
-    bool gave_up = false;
     while (q < total) {
         while (q >= m_cnt * (a.S[s].tiles_before + a.S[s].n_tiles)) ++s;          // tile numbers only grow: the step pointer only advances
         const ChainStep& st = a.S[s];
@@ -934,15 +1013,22 @@ __global__ __launch_bounds__(256, 2) void k_net_chain(const ChainArgs a) {
             if (tid == 0) {
                 const unsigned need = (unsigned)st.tiles_before;
                 unsigned spins = 0;
-                while (!gave_up && __hip_atomic_load(done + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                int ok = 1;
+                while (__hip_atomic_load(done + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins == kChainSpinLimit) {      // never a hang: flag it, stop waiting in this workgroup, go on (tests read the flag)
+                    ++spins;
+                    // never a hang, never a tile on incomplete inputs: out of budget — or somebody else already is, so the producer this
+                    // tile waits for may never come — flag it and abandon the launch (k_chain_verify turns that into NaN + a verdict)
+                    if (spins >= a.spin_limit || ((spins & 255u) == 0u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                         __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        gave_up = true;
+                        ok = 0;
+                        break;
                     }
                 }
+                slot[2] = ok;
             }
             __syncthreads();                             // the inputs of this tile are complete — for every wave
+            if (!slot[2]) break;
         }
         if (tid == 0) hook.qn = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the ticket after this one
         hook.first = true;
@@ -956,19 +1042,31 @@ __global__ __launch_bounds__(256, 2) void k_net_chain(const ChainArgs a) {
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-        kloop_pipelined<NI, NJ, BM, BN, ChainPolicy, 16>(a.arena + st.x1_off + m0 * 16, st.k2p ? a.arena + st.x2_off + m0 * 16 : nullptr,
-                                                         a.packed + st.w_off + (long long)n0 * 16, a.m_padded * 16, (long long)st.n_padded * 16,
-                                                         st.k1p, st.k1p + st.k2p, smem, tid, wave, lane, wm * (32 * NJ), wn * 64, acc, hook);
-        float* const y = a.arena + st.y_off;
+        kloop_pipelined<NI, NJ, BM, BN, ChainPolicy, 16>(st.x1 + m0 * 16, st.k2p ? st.x2 + m0 * 16 : nullptr, st.w + (long long)n0 * 16,
+                                                         a.m_padded * 16, (long long)st.n_padded * 16, st.k1p, st.k1p + st.k2p, smem, tid, wave,
+                                                         lane, wm * (32 * NJ), wn * 64, acc, hook);
+        float* const y = st.y;
         const long long mf = m0 + wm * (32 * NJ);
         const int nf = n0 + wn * 64;
-        if (st.bias_row_div) {                           // the view layer: per-ray bias rows
+        float* const win = smem + wave * 1024;           // wave-private window inside stage 0 (free after the loop's last barrier)
+        if constexpr (MODE == kChainBackward) {
+            if (st.flags & 1) {                          // += the running sum another step of this launch left there
+                if (st.aux) chain_store_bwd_acc<NI, NJ, 1>(acc, y, st.aux, a.m_padded, mf, nf, lane, win, nullptr);
+                else if (st.bits) chain_store_bwd_acc<NI, NJ, 2>(acc, y, nullptr, a.m_padded, mf, nf, lane, win, st.bits);
+                else chain_store_bwd_acc<NI, NJ, 0>(acc, y, nullptr, a.m_padded, mf, nf, lane, win, nullptr);
+            } else {
+                if (st.aux) store_tile_staged_bwd<NI, NJ, false, 1>(acc, y, st.aux, a.m_padded, mf, nf, lane, win);
+                else if (st.bits) store_tile_staged_bwd<NI, NJ, false, 2>(acc, y, nullptr, a.m_padded, mf, nf, lane, win, st.bits);
+                else store_tile_staged_bwd<NI, NJ, false, 0>(acc, y, nullptr, a.m_padded, mf, nf, lane, win);
+            }
+        } else if (st.bias_row_div) {                    // the view layer: per-ray bias rows (its mask bits, if any, come from a pass over y)
             f32x4 bv[NI][4];
-            store_tile<NI, NJ, true>(acc, a.view_bias_rows + st.bias_off, a.bias_rows, st.bias_row_div, st.n_padded, y, a.m_padded, mf, nf, st.relu, lane, bv);
+            store_tile<NI, NJ, true>(acc, st.aux, a.bias_rows, st.bias_row_div, st.n_padded, y, a.m_padded, mf, nf, st.flags & 1, lane, bv);
+        } else if constexpr (MODE == kChainForwardMask) {
+            store_tile_staged<NI, NJ, true, true>(acc, st.aux, y, a.m_padded, mf, nf, lane, win, st.bits);
         } else {
-            float* const win = smem + wave * 1024;       // wave-private window inside stage 0 (free after the loop's last barrier)
-            if (st.relu) store_tile_staged<NI, NJ, true>(acc, a.folded + st.bias_off, y, a.m_padded, mf, nf, lane, win);
-            else store_tile_staged<NI, NJ, false>(acc, a.folded + st.bias_off, y, a.m_padded, mf, nf, lane, win);
+            if (st.flags & 1) store_tile_staged<NI, NJ, true>(acc, st.aux, y, a.m_padded, mf, nf, lane, win);
+            else store_tile_staged<NI, NJ, false>(acc, st.aux, y, a.m_padded, mf, nf, lane, win);
         }
         hook.prev_mt = mt;                               // signalled behind the next tile's first panel (or below / above when there is a wait)
         if (tid == 0) slot[0] = hook.qn, slot[1] = (hook.qn >= total || hook.seen >= hook.need) ? 1 : 0;
@@ -985,7 +1083,7 @@ __global__ __launch_bounds__(256, 2) void k_net_chain(const ChainArgs a) {
 // live roofline figure.  Off by default (no events, no overhead).  The measurement session is explicit state the HOST opens and
 // closes (mofa_prof_begin/end); it is kept per device and guarded by a mutex, so two devices or two host threads in one process
 // do not share or corrupt it.  When no session is open the launch paths only read one relaxed atomic.
-constexpr int kProfKinds = MOFA_PROF_KINDS;   // 0: k_layer<128,..,PIPE> (forward), 1: k_mlp_fused, 2: k_layer<BWD>, 3: k_wgrad, 4: k_layer<..PERRAY> (view layer), 5: k_net_chain
+constexpr int kProfKinds = MOFA_PROF_KINDS;   // 0: k_layer<128,..,PIPE> (forward), 1: k_mlp_fused, 2: k_layer<BWD>, 3: k_wgrad, 4: k_layer<..PERRAY> (view layer), 5: k_net_chain (forward), 6: k_net_chain<backward>
 struct ProfState {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     std::vector<int> kind;
@@ -1263,7 +1361,7 @@ int mofa_prof_begin(void) {
 /* arrays of MOFA_PROF_KINDS: [0] the per-layer forward MFMA kernel k_layer<128,false,false,false,PIPE> (128-feature tile),
  * [1] the persistent network kernel k_mlp_fused, [2] the backward-data kernel k_layer<128,false,BWD,..>, [3] the weight-gradient
  * kernel k_wgrad, [4] the per-ray-bias instantiation k_layer<128,false,false,PERRAY,..> (view layer), [5] the chained wide-network kernel
- * k_net_chain.
+ * k_net_chain (forward), [6] its backward-data instantiation.
  * Session of the CURRENT device. */
 int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops) {
     MOFA_REQUIRE(total_ms && launches && padded_flops, "prof_end: null pointer");
@@ -1319,72 +1417,124 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
     return rc;
 }
 
-// internal (used by mofa_net.hip): may this device take the chained launch?  k_net_chain gives every XCD the queue of its own number and
-// relies on all eight having workgroups (the default mode of the part: one device, 8 XCDs, round-robin dispatch).  A device whose
-// workgroups land on fewer XCDs (compute partitions) would leave queues unworked, so the first call per device COUNTS: a 512-workgroup
-// census of HW_REG_XCC_ID (one tiny launch and one stream synchronisation, once per device and process); anything but eight
-// populated XCDs selects the per-layer launches.
+// ---- device initialisation: the ONE place of this library that allocates and synchronises ---------------------------------------
+// k_net_chain gives every XCD the queue of its own number and relies on all eight having workgroups (the default mode of the part:
+// one device, 8 XCDs, round-robin dispatch).  A device whose workgroups land on fewer XCDs (compute partitions) would leave queues
+// unworked, so the chained launch is only taken on a device whose CENSUS found eight populated XCDs: a 512-workgroup launch that
+// counts HW_REG_XCC_ID (one tiny allocation, one launch, one stream synchronisation).  It is taken HERE, at an explicit point the
+// host layer calls when it binds a network to a device (HipNet.__init__) — never inside a forward: without it
+// mofa_net_forward / mofa_net_backward use the per-layer launches, which need no census and are bit-identical.
+// The result is keyed on the device of `stream`.  (A stream that later restricts the CUs — hipExtStreamCreateWithCUMask — is not
+// covered by the census; k_chain_verify catches what that does: unworked queues -> NaN outputs + verdict.)
 static std::atomic<int> g_chain_census[kMaxDevices];       // 0: not taken, 1: eight XCDs seen, 2: fewer
 
-int mofa_internal_chain_supported(void* stream) {
-    const int dev = current_device();
-    int c = g_chain_census[dev].load(std::memory_order_acquire);
-    if (c) return c == 1;
-    hipStream_t st = (hipStream_t)stream;
-    unsigned* counts = nullptr;
-    unsigned host[8] = {};
-    bool ok = hipMalloc((void**)&counts, sizeof(host)) == hipSuccess && hipMemsetAsync(counts, 0, sizeof(host), st) == hipSuccess;
-    if (ok) {
-        hipLaunchKernelGGL(k_xcc_census, dim3(2 * compute_units(dev)), dim3(64), 0, st, counts);
-        ok = hipMemcpyAsync(host, counts, sizeof(host), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
-    }
-    if (counts) (void)hipFree(counts);
-    (void)hipGetLastError();
-    int populated = 0;
-    for (unsigned v : host) populated += v > 0;
-    c = (ok && populated == 8) ? 1 : 2;
-    g_chain_census[dev].store(c, std::memory_order_release);
-    return c == 1;
+static int stream_device(hipStream_t st) {
+    hipDevice_t d = 0;
+    if (st && hipStreamGetDevice(st, &d) == hipSuccess && d >= 0) return d < kMaxDevices ? (int)d : kMaxDevices - 1;
+    return current_device();
 }
 
-// internal (used by mofa_net.hip): the MFMA layers of one WIDE network as one chained launch (k_net_chain).  `state`: at least
-// mofa_internal_chain_state_words(m_padded) unsigned words inside the caller's workspace.
+int mofa_device_init(void* stream, int32_t* xcd_workgroups) {
+    hipStream_t st = (hipStream_t)stream;
+    const int dev = stream_device(st);
+    unsigned* counts = nullptr;
+    unsigned host[8] = {};
+    hipError_t e = hipMalloc((void**)&counts, sizeof(host));
+    if (e == hipSuccess) e = hipMemsetAsync(counts, 0, sizeof(host), st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_xcc_census, dim3(2 * compute_units(dev)), dim3(64), 0, st, counts);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, counts, sizeof(host), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (counts) (void)hipFree(counts);
+    if (e != hipSuccess) {
+        set_error("device_init: %s", hipGetErrorString(e));
+        return MOFA_EHIP;
+    }
+    int populated = 0;
+    for (int i = 0; i < 8; ++i) {
+        populated += host[i] > 0;
+        if (xcd_workgroups) xcd_workgroups[i] = (int32_t)host[i];
+    }
+    g_chain_census[dev].store(populated == 8 ? 1 : 2, std::memory_order_release);
+    // the persistent 256-wide kernel's 66 KiB of dynamic LDS needs a function attribute once per device (launch_fused would set it on its
+    // first launch otherwise: not a synchronisation, but it belongs here)
+    if (dev == current_device() && !g_fused_attr[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute((const void*)k_mlp_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kFsFloats * sizeof(float))) != hipSuccess)
+            return check_launch("hipFuncSetAttribute(k_mlp_fused)");
+        g_fused_attr[dev].store(1, std::memory_order_release);
+    }
+    return MOFA_OK;
+}
+
+// internal (used by mofa_net.hip): 1 = this device may take the chained launch, 0 = census found fewer than eight XCDs, -1 = no census yet
+int mofa_internal_chain_capable(void* stream) {
+    const int c = g_chain_census[stream_device((hipStream_t)stream)].load(std::memory_order_acquire);
+    return c == 0 ? -1 : (c == 1 ? 1 : 0);
+}
+
+// internal (used by mofa_net.hip): the steps of one chained launch (k_net_chain).  `state`: at least
+// mofa_internal_chain_state_words(m_padded) unsigned words inside the caller's workspace.  *tiles_out = tiles the launch must finish.
 size_t mofa_internal_chain_state_words(long long m_padded) { return (size_t)kChainDone + (size_t)(m_padded / kRowTile) + 32; }
 
-int mofa_internal_chain_forward(float* arena, const float* packed, const float* folded, const float* view_bias_rows, long long bias_rows,
-                                long long m_padded, int n_steps, const long long* x1_off, const long long* x2_off, const long long* y_off,
-                                const long long* w_off, const long long* bias_off, const int* k1p, const int* k2p, const int* n_padded,
-                                const int* bias_row_div, const int* relu, unsigned* state, void* stream) {
-    MOFA_REQUIRE(n_steps > 0 && n_steps <= kMaxChainSteps, "chain_forward: %d layers (max %d)", n_steps, kMaxChainSteps);
-    MOFA_REQUIRE(m_padded > 0 && m_padded % kRowTile == 0 && m_padded / kRowTile < (1 << 24), "chain_forward: m_padded=%lld", m_padded);
-    MOFA_REQUIRE(arena && packed && folded && view_bias_rows && state, "chain_forward: null pointer");
+int mofa_internal_chain_launch(int mode, const mofa::ChainStep* steps, int n_steps, long long m_padded, long long bias_rows, unsigned* state,
+                               long long* tiles_out, void* stream) {
+    MOFA_REQUIRE(n_steps > 0 && n_steps <= kMaxChainSteps, "chain_launch: %d steps (max %d)", n_steps, kMaxChainSteps);
+    MOFA_REQUIRE(m_padded > 0 && m_padded % kRowTile == 0 && m_padded / kRowTile < (1 << 24), "chain_launch: m_padded=%lld", m_padded);
+    MOFA_REQUIRE(steps && state && mode >= kChainForward && mode <= kChainBackward, "chain_launch: bad arguments");
     ChainArgs a{};
-    a.arena = arena, a.packed = packed, a.folded = folded, a.view_bias_rows = view_bias_rows, a.state = state;
+    a.state = state;
     a.m_padded = m_padded, a.bias_rows = bias_rows, a.m_tiles = (int)(m_padded / kRowTile), a.n_steps = n_steps;
+    a.spin_limit = config().chain_spin;
     double flops = 0.0;
     int before = 0;
     for (int i = 0; i < n_steps; ++i) {
-        const int kt = k1p[i] + k2p[i];
-        MOFA_REQUIRE(n_padded[i] > 0 && n_padded[i] % 128 == 0 && kt >= 4 && (kt & 1) == 0 && k1p[i] > 0,
-                     "chain_forward: layer %d (n_padded=%d, %d K panels) does not fit the pipelined 128-feature tile", i, n_padded[i], kt);
-        a.S[i] = ChainStep{x1_off[i], x2_off[i], y_off[i], w_off[i], bias_off[i], k1p[i], k2p[i], n_padded[i], n_padded[i] / 128,
-                           bias_row_div[i], relu[i], before, 0};
-        before += n_padded[i] / 128;
-        flops += 2.0 * (double)m_padded * (double)n_padded[i] * 16.0 * (double)kt;
+        ChainStep s = steps[i];
+        const int kt = s.k1p + s.k2p;
+        MOFA_REQUIRE(s.x1 && s.y && s.w && (s.k2p == 0 || s.x2), "chain_launch: step %d has a null operand", i);
+        MOFA_REQUIRE(s.n_padded > 0 && s.n_padded % 128 == 0 && kt >= 4 && (kt & 1) == 0 && s.k1p > 0,
+                     "chain_launch: step %d (n_padded=%d, %d K panels) does not fit the pipelined 128-feature tile", i, s.n_padded, kt);
+        MOFA_REQUIRE(mode == kChainBackward || s.aux, "chain_launch: forward step %d has no bias", i);
+        MOFA_REQUIRE(mode != kChainForwardMask || (s.flags & 1), "chain_launch: a mask tape records the ReLU of the layer (step %d has none)", i);
+        MOFA_REQUIRE(mode != kChainForwardMask || s.bits || s.bias_row_div, "chain_launch: step %d has no place for its mask bits", i);
+        MOFA_REQUIRE(mode != kChainBackward || !(s.aux && s.bits), "chain_launch: step %d has both an fp32 mask and mask bits", i);
+        s.n_tiles = s.n_padded / 128, s.tiles_before = before;
+        a.S[i] = s;
+        before += s.n_tiles;
+        flops += 2.0 * (double)m_padded * (double)s.n_padded * 16.0 * (double)kt;
     }
     a.tiles_per_m = before;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(state, 0, mofa_internal_chain_state_words(m_padded) * sizeof(unsigned), st) != hipSuccess) return check_launch("hipMemsetAsync(chain state)");
-    const int dev = current_device();
+    const int dev = stream_device(st);
     const long long tiles = (long long)a.m_tiles * before;
+    if (tiles_out) *tiles_out = tiles;
     const int slots = 2 * compute_units(dev);
     const int grid = tiles < slots ? (int)round_up(tiles, 8) : slots;       // two resident workgroups per CU
     const size_t lds = 2 * (size_t)(kRowTile + 128) * 16 * sizeof(float) + 64;
     const bool prof = prof_enabled();
-    if (prof && prof_open(st, 5) != MOFA_OK) return MOFA_EHIP;
-    hipLaunchKernelGGL(k_net_chain, dim3(grid), dim3(256), lds, st, a);
-    if (prof) prof_close(st, 5, flops);
+    const int pkind = mode == kChainBackward ? 6 : 5;
+    if (prof && prof_open(st, pkind) != MOFA_OK) return MOFA_EHIP;
+    if (mode == kChainForward) hipLaunchKernelGGL(k_net_chain<kChainForward>, dim3(grid), dim3(256), lds, st, a);
+    else if (mode == kChainForwardMask) hipLaunchKernelGGL(k_net_chain<kChainForwardMask>, dim3(grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(k_net_chain<kChainBackward>, dim3(grid), dim3(256), lds, st, a);
+    if (prof) prof_close(st, pkind, flops);
     return check_launch("k_net_chain");
+}
+
+// internal (used by mofa_net.hip): behind a chained launch (and whatever consumed its outputs into p0 / p1 / p2): verify, poison, verdict
+int mofa_internal_chain_verify(const unsigned* state, long long tiles, unsigned* verdict, float* p0, long long n0, float* p1, long long n1,
+                               float* p2, long long n2, float* p3, long long n3, void* stream) {
+    n0 = p0 ? n0 : 0, n1 = p1 ? n1 : 0, n2 = p2 ? n2 : 0, n3 = p3 ? n3 : 0;
+    long long n = n0 > n1 ? n0 : n1;
+    n = n > n2 ? n : n2;
+    n = n > n3 ? n : n3;
+    long long grid = (n + 255) / 256;
+    grid = grid < 1 ? 1 : (grid > 1024 ? 1024 : grid);
+    hipLaunchKernelGGL(k_chain_verify, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, state + kChainStatus, (unsigned)tiles, verdict, p0, n0, p1,
+                       n1, p2, n2, p3, n3);
+    return check_launch("k_chain_verify");
 }
 
 // internal (used by mofa_net.hip): bits of (y > 0) for a panel buffer of n_floats (a multiple of 256) floats

@@ -26,11 +26,11 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
                                 unsigned long long* mask_bits, const long long* mask_off, void* stream);
 int mofa_internal_mask_pack(const float* y, long long n_floats, unsigned long long* bits, void* stream);
 size_t mofa_internal_chain_state_words(long long m_padded);
-int mofa_internal_chain_supported(void* stream);
-int mofa_internal_chain_forward(float* arena, const float* packed, const float* folded, const float* view_bias_rows, long long bias_rows,
-                                long long m_padded, int n_steps, const long long* x1_off, const long long* x2_off, const long long* y_off,
-                                const long long* w_off, const long long* bias_off, const int* k1p, const int* k2p, const int* n_padded,
-                                const int* bias_row_div, const int* relu, unsigned* state, void* stream);
+int mofa_internal_chain_capable(void* stream);
+int mofa_internal_chain_launch(int mode, const mofa::ChainStep* steps, int n_steps, long long m_padded, long long bias_rows, unsigned* state,
+                               long long* tiles_out, void* stream);
+int mofa_internal_chain_verify(const unsigned* state, long long tiles, unsigned* verdict, float* p0, long long n0, float* p1, long long n1,
+                               float* p2, long long n2, float* p3, long long n3, void* stream);
 int mofa_internal_head_weight_grad_split(const float* d_raw, int32_t raw_off, int32_t n_out, const float* x, int32_t k_padded,
                                          int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, float* workspace,
                                          void* stream);
@@ -53,6 +53,10 @@ Config read_env() {
     Config c;
     auto tri = [](const char* name) { const char* e = getenv(name); return e ? (e[0] == '1' ? 1 : 0) : -1; };
     c.fused = tri("MOFA_FUSED"), c.pipe = tri("MOFA_PIPE"), c.chain = tri("MOFA_CHAIN");
+    if (const char* e = getenv("MOFA_CHAIN_SPIN_LIMIT")) {       // tests only: force k_net_chain's dependency waits to give up early
+        const long v = strtol(e, nullptr, 10);
+        if (v > 0) c.chain_spin = (unsigned)v;
+    }
     return c;
 }
 // two slots + an atomic index: readers never see a half-written snapshot, reload is rare and host-side only
@@ -288,8 +292,11 @@ size_t mofa_net_mask_tape_words(MofaNetShape s, int64_t n_points) {
 size_t mofa_net_backward_workspace_floats(MofaNetShape s, int64_t n_points) {
     if (!shape_ok(s) || n_points <= 0) return 0;
     const Plan p = make_plan(s);
-    return (size_t)round_up(n_points, kRowTile) * (4 * (size_t)p.Wp + (size_t)p.pe_k) + 64 +
-           mofa_weight_grad_workspace_floats(n_points, p.Wp, p.Wp) + 64;  // split-M partials of the largest dW block
+    const size_t mp = (size_t)round_up(n_points, kRowTile);
+    return mp * (4 * (size_t)p.Wp + (size_t)p.pe_k) + 64 +
+           mofa_weight_grad_workspace_floats(n_points, p.Wp, p.Wp) + 64 +  // split-M partials of the largest dW block
+           3 * mp * (size_t)p.Wp + 2 * mofa_internal_chain_state_words((long long)mp) + 64;   // the chained fitting backward: three more gradient
+                                                                                              // buffers (the bias-gradient inputs it keeps) + queue state of its two launches
 }
 
 int mofa_net_pack_t(MofaNetShape s, const float* const* weights, float* packed_t, void* stream) {
@@ -315,7 +322,7 @@ int mofa_net_pack_t(MofaNetShape s, const float* const* weights, float* packed_t
 int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, const float* view_w,
                      const float* view_b, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
                      const float* pts, const float* viewdirs, int64_t n_rays, int32_t S, float* workspace,
-                     float* raw_out, float* tape, uint64_t* mask_tape, const float* view_bias_rows, void* stream) {
+                     float* raw_out, float* tape, uint64_t* mask_tape, const float* view_bias_rows, uint32_t* verdict, void* stream) {
     MOFA_REQUIRE(shape_ok(s), "net_forward: unsupported shape " MOFA_SHAPE_FMT, MOFA_SHAPE_ARGS(s));
     MOFA_REQUIRE(packed && folded && workspace && raw_out, "net_forward: null pointer");
     MOFA_REQUIRE(!(tape && mask_tape), "net_forward: give the fp32 tape OR the mask-only tape, not both");
@@ -380,23 +387,26 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     steps.push_back({p.view, rgbc, nullptr, v});
 
     int rc;
+    unsigned* chain_state = nullptr;      // set when the chained launch ran: its status words are verified behind the heads
+    long long chain_tiles = 0;
     if (!view_bias_rows) {
         // per-ray bias b + W[:, :27] @ PE(viewdir) from the ORIGINAL (unpacked) view-layer tensors
         const Layer& l = p.L[p.view];
         MOFA_TRY(mofa_view_bias(viewdirs, n_rays, s.pe_view_freqs, view_w, l.n_out, l.ld, view_b, vbias, l.n_padded, stream));
         view_bias_rows = vbias;
     }
-    // the chained launch takes an inference forward (no tape of either kind) whose every layer fits the pipelined 128-feature tile
+    // the chained launch takes a forward — inference, or keeping either tape — whose every layer fits the pipelined 128-feature tile, on a
+    // device mofa_device_init() found eight populated XCDs on (no census yet: per-layer launches; nothing here allocates or synchronises).
     // (MOFA_CHAIN=0: per-layer launches — the bit-identical reference form; MOFA_PIPE=0 implies it)
     auto chain_ok = [&]() {
-        if (tape || mask_tape || config().chain == 0 || config().pipe == 0 || steps.size() > MOFA_MAX_CHAIN_STEPS) return false;
+        if (config().chain == 0 || config().pipe == 0 || steps.size() > MOFA_MAX_CHAIN_STEPS) return false;
         for (const Step& st : steps) {
             const Layer& l = p.L[st.li];
             const int kt = l.k_padded[0] / 16 + (st.x2 ? l.k_padded[1] / 16 : 0);
             if (l.n_padded % 128 != 0 || kt < 4 || (kt & 1)) return false;
             if (!st.x1 && (l.n_padded < 512 || st.y == t1)) return false;     // layer 0 through k_pe_panels, as below
         }
-        return mofa_internal_chain_supported(stream) != 0;                     // (a one-time census per device: all eight XCDs get workgroups)
+        return mofa_internal_chain_capable(stream) == 1;
     };
     // ---- dispatch: one persistent launch for widths <= 256 (every layer of a point tile lives in one workgroup); wider networks: one
     //      chained launch over the tiles of every layer (inference), else one launch per layer.  MOFA_FUSED=0/1 and MOFA_CHAIN=0 override
@@ -428,26 +438,28 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
             MOFA_TRY(mofa_internal_mask_pack(v, (long long)Mp * p.L[p.view].n_padded, mbits + mword(p.view), stream));
         }
     } else if (chain_ok()) {
-        // Wide network, inference: ONE chained launch (k_net_chain, mofa_mlp.hip) over the tiles of every layer — the same tiles as the
-        // per-layer launches below (bit-identical), without their ~26 launch boundaries per sub-batch.  Layer 0 reads the encoding
-        // panels k_pe_panels leaves in t1 (layer 1 overwrites them row tile by row tile, after layer 0 is done with those rows).
+        // Wide network: ONE chained launch (k_net_chain, mofa_mlp.hip) over the tiles of every layer — the same tiles as the per-layer
+        // launches below (bit-identical), without their ~26 launch boundaries per sub-batch.  Layer 0 reads the encoding panels
+        // k_pe_panels leaves in t1 (without a tape layer 1 overwrites them row tile by row tile, after layer 0 is done with those rows).
+        // With a tape the outputs simply are the tape's slots; with a mask tape the contiguous-store epilogues also write the bits
+        // (the view layer's per-ray-bias epilogue does not: a pass over its output below, as with per-layer launches).
         MOFA_TRY(mofa_pe_panels(rays_o, rays_d, z, z_row_stride, pts, M, S, s.pe_point_freqs, Mp, t1, stream));
-        const int n = (int)steps.size();
-        std::vector<long long> x1(n), x2(n), yo(n), wo(n), bo(n);
-        std::vector<int> k1(n), k2(n), np(n), div(n), relu(n, 1);
-        for (int i = 0; i < n; ++i) {
+        std::vector<ChainStep> cs(steps.size());
+        for (size_t i = 0; i < steps.size(); ++i) {
             const Layer& l = p.L[steps[i].li];
             const bool view = steps[i].li == p.view;
-            x1[i] = (steps[i].x1 ? steps[i].x1 : t1) - workspace;
-            x2[i] = steps[i].x2 ? steps[i].x2 - workspace : 0;
-            yo[i] = steps[i].y - workspace;
-            wo[i] = (long long)l.packed_off, bo[i] = view ? 0 : (long long)l.folded_off;
-            k1[i] = l.k_padded[0] / 16, k2[i] = steps[i].x2 ? l.k_padded[1] / 16 : 0;
-            np[i] = l.n_padded, div[i] = view ? S : 0;
+            ChainStep c{};
+            c.x1 = steps[i].x1 ? steps[i].x1 : t1, c.x2 = steps[i].x2, c.y = steps[i].y;
+            c.w = packed + l.packed_off, c.aux = view ? view_bias_rows : folded + l.folded_off;
+            c.bits = (mask_tape && !view) ? mbits + mword(steps[i].li) : nullptr;
+            c.k1p = l.k_padded[0] / 16, c.k2p = steps[i].x2 ? l.k_padded[1] / 16 : 0;
+            c.n_padded = l.n_padded, c.bias_row_div = view ? S : 0, c.flags = 1;
+            cs[i] = c;
         }
-        unsigned* state = (unsigned*)(vbias + (size_t)n_rays * p.Hp + 64);
-        MOFA_TRY(mofa_internal_chain_forward(workspace, packed, folded, view_bias_rows, n_rays, Mp, n, x1.data(), x2.data(), yo.data(), wo.data(),
-                                             bo.data(), k1.data(), k2.data(), np.data(), div.data(), relu.data(), state, stream));
+        chain_state = (unsigned*)(vbias + (size_t)n_rays * p.Hp + 64);
+        MOFA_TRY(mofa_internal_chain_launch(mask_tape ? kChainForwardMask : kChainForward, cs.data(), (int)cs.size(), Mp, n_rays, chain_state,
+                                            &chain_tiles, stream));
+        if (mask_tape) MOFA_TRY(mofa_internal_mask_pack(v, (long long)Mp * p.L[p.view].n_padded, mbits + mword(p.view), stream));
     } else {
         for (const Step& st : steps) {
             const Layer& l = p.L[st.li];
@@ -482,13 +494,16 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
         const Layer& r = p.L[p.rgb];
         MOFA_TRY(head(v, r.k_padded[0], Mp, packed + r.packed_off, folded + r.folded_off, 3, raw_out, 0, M, stream));
     }
+    // a chained launch that did not finish every tile (a wait abandoned, an unworked queue) must not look like a result: NaN + verdict
+    if (chain_state) MOFA_TRY(mofa_internal_chain_verify(chain_state, chain_tiles, verdict, raw_out, M * 4, nullptr, 0, nullptr, 0, nullptr, 0, stream));
     return MOFA_OK;
 }
 
 int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t, const float* tape, const uint64_t* mask_tape,
                       const float* d_raw, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
                       const float* pts, int64_t n_rays, int32_t S, float* workspace, float* d_folded,
-                      float* d_view_bias_rows, float* d_rays_o, float* d_rays_d, float* d_pts, float* const* d_weights, void* stream) {
+                      float* d_view_bias_rows, float* d_rays_o, float* d_rays_d, float* d_pts, float* const* d_weights, uint32_t* verdict,
+                      void* stream) {
     MOFA_REQUIRE(shape_ok(s), "net_backward: unsupported shape " MOFA_SHAPE_FMT, MOFA_SHAPE_ARGS(s));
     MOFA_REQUIRE(packed && packed_t && d_raw && workspace && d_folded && d_view_bias_rows, "net_backward: null pointer");
     MOFA_REQUIRE((tape != nullptr) != (mask_tape != nullptr), "net_backward: need the fp32 tape OR the mask-only tape");
@@ -505,6 +520,10 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
     float* gX = workspace + 3 * act;   // accumulates d xyz_code
     float* dpe = workspace + 4 * act;  // [Mp, pe_k]
     float* wws = dpe + (size_t)Mp * p.pe_k + 64;  // split-M partial sums of the weight-gradient GEMM
+    float* extra = wws + mofa_weight_grad_workspace_floats(M, p.Wp, p.Wp) + 64;   // three more gradient buffers (chained form only)
+    unsigned* cstate[2];
+    cstate[0] = (unsigned*)(extra + 3 * act);
+    cstate[1] = cstate[0] + mofa_internal_chain_state_words((long long)Mp);
     // (output > 0) of layer li: the saved fp32 activation itself, or its bits in the mask-only tape — never both
     struct Mask {
         const float* act;
@@ -516,6 +535,52 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
         return tape ? Mask{T(li), nullptr} : Mask{nullptr, mask_tape + (size_t)Mp * p.L[li].tape_cols / 64};
     };
     int rc;
+    const int n2 = s.D - 5;
+    // ---- the chained form (fitting: no weight gradients).  The backward-data products of the wide network run as TWO chained launches
+    // (k_net_chain<backward>: view layer + texture stack | shape stack + xyzEncode 3..1) instead of 26 per-layer launches — same tiles,
+    // same epilogues, bit-identical.  What sits between the products in the per-layer form moves around them: the sigma head's
+    // contribution (an elementwise accumulate into d sigmaCodes) separates the two launches, and the five bias-gradient column sums
+    // the fitting needs (the code-conditioned layers) run after the launch that produced their input — which therefore must survive
+    // the launch: those gradients are kept in buffers the chain does not recycle (three more than the per-layer form's four).
+    // Training (weight gradients) keeps the per-layer form: every layer's gradient feeds a weight-gradient GEMM between two products.
+    const bool chain = !d_weights && config().chain != 0 && config().pipe != 0 && p.Wp % 128 == 0 && p.Wp >= 64 && p.Hp % 32 == 0 && p.Hp >= 64 &&
+                       n2 + 7 <= MOFA_MAX_CHAIN_STEPS && n2 + 9 <= MOFA_MAX_CHAIN_STEPS && mofa_internal_chain_capable(stream) == 1;
+    bool chaining = false;                       // products are being recorded (between begin_chain() and flush())
+    std::vector<ChainStep> seg;
+    struct Deferred {
+        int li;
+        const float* g;
+    };
+    std::vector<Deferred> deferred;             // bias gradients whose input the open segment produces
+    std::vector<const float*> kept;             // ... and the buffers they read: not to be overwritten before flush()
+    long long ctiles[2] = {0, 0};
+    int nseg = 0;
+    float *cur = nullptr, *spare = nullptr;
+    auto is_kept = [&](const float* b) {
+        for (const float* k : kept)
+            if (k == b) return true;
+        return false;
+    };
+    // the next buffer a product may overwrite: in the chained form never one a deferred bias gradient still has to read
+    auto fix_spare = [&]() {
+        if (!chaining || (!is_kept(spare) && spare != cur)) return;
+        float* cand[5] = {g0, g1, extra, extra + act, extra + 2 * act};
+        for (float* c : cand)
+            if (!is_kept(c) && c != cur) {
+                spare = c;
+                return;
+            }
+    };
+    auto flush = [&]() -> int {
+        chaining = false;
+        if (seg.empty()) return MOFA_OK;
+        MOFA_REQUIRE(nseg < 2, "net_backward: internal error (more than two chained segments)");
+        MOFA_TRY(mofa_internal_chain_launch(kChainBackward, seg.data(), (int)seg.size(), Mp, 1, cstate[nseg], &ctiles[nseg], stream));
+        ++nseg;
+        for (const Deferred& d : deferred) MOFA_TRY(mofa_bias_grad(d.g, Mp, M, p.L[d.li].n_padded, d_folded + p.L[d.li].folded_off, stream));
+        seg.clear(), deferred.clear(), kept.clear();
+        return MOFA_OK;
+    };
     // dW[li][:, col0[part] : +ncols[part]] = G^T X   (training only: d_weights != NULL; the constant columns are the host's)
     auto wgrad = [&](int li, int part, const float* g, const float* x) -> int {
         if (!d_weights) return MOFA_OK;
@@ -530,11 +595,22 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
     // their slots are zeroed below).
     auto bgrad = [&](int li, const float* g) -> int {
         if (d_weights || p.L[li].fold == kNone) return MOFA_OK;
+        if (chaining) {
+            deferred.push_back({li, g}), kept.push_back(g);
+            return MOFA_OK;
+        }
         return mofa_bias_grad(g, Mp, M, p.L[li].n_padded, d_folded + p.L[li].folded_off, stream);
     };
     // dX = G @ W[:, part]
     auto bdata = [&](int li, int part, const float* g, Mask mask, int accumulate, float* dx) -> int {
         const Layer& l = p.L[li];
+        if (chaining) {
+            ChainStep c{};
+            c.x1 = g, c.y = dx, c.w = packed_t + l.packed_t_off[part], c.aux = mask.act, c.bits = (unsigned long long*)mask.bits;
+            c.k1p = l.n_padded / 16, c.n_padded = l.k_padded[part], c.flags = accumulate ? 1 : 0;
+            seg.push_back(c);
+            return MOFA_OK;
+        }
         if (mask.bits)
             return mofa_layer_backward_data_bits(g, l.n_padded, packed_t + l.packed_t_off[part], mask.bits, accumulate, dx, Mp,
                                                  l.k_padded[part], stream);
@@ -544,7 +620,6 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
         if (mask.bits) return mofa_head_backward_bits(dr, off, n, w, kp, mask.bits, accumulate, dx, Mp, M, stream);
         return mofa_head_backward(dr, off, n, w, kp, mask.act, accumulate, dx, Mp, M, stream);
     };
-    const int n2 = s.D - 5;
     if (!d_weights && hipMemsetAsync(d_folded, 0, p.folded_floats * sizeof(float), (hipStream_t)stream) != hipSuccess)
         return check_launch("hipMemsetAsync(d_folded)");
     // heads' bias gradients
@@ -565,9 +640,10 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
         }
         MOFA_TRY(wgrad(p.view, 0, g0, T(p.uv_skip + n2 - 1)));
     }
+    chaining = chain;                                            // ---- first chained launch: view layer + texture stack
     // view layer -> d rgbCodes, masked by the last uv layer's ReLU
     MOFA_TRY(bdata(p.view, 0, g0, Mk(p.uv_skip + n2 - 1), 0, g1));
-    float *cur = g1, *spare = g0;
+    cur = g1, spare = g0;
     // One conditioned stack, walked backwards.  `cur` = masked gradient at its output.  The gradient w.r.t. the stack's
     // input x has two contributions (the skip concat and linears1.Linear0): the first overwrites gx, the second
     // accumulates and applies `final_mask` (the ReLU of the layer that produced x) if given.
@@ -578,6 +654,7 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
             MOFA_TRY(wgrad(li, 0, cur, T(li - 1)));
             MOFA_TRY(bdata(li, 0, cur, Mk(li - 1), 0, spare));
             std::swap(cur, spare);
+            fix_spare();
         }
         MOFA_TRY(bgrad(skip, cur));
         MOFA_TRY(wgrad(skip, 0, cur, T(skip - 1)));                  // part 0 = the h columns, part 1 = the x columns (make_plan)
@@ -585,11 +662,13 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
         MOFA_TRY(bdata(skip, 1, cur, kNoMask, 0, gx));               // x part of [x | h]
         MOFA_TRY(bdata(skip, 0, cur, Mk(skip - 1), 0, spare));       // h part, masked by linears1's last ReLU
         std::swap(cur, spare);
+        fix_spare();
         for (int li = skip - 1; li > first; --li) {
             MOFA_TRY(bgrad(li, cur));
             MOFA_TRY(wgrad(li, 0, cur, T(li - 1)));
             MOFA_TRY(bdata(li, 0, cur, Mk(li - 1), 0, spare));
             std::swap(cur, spare);
+            fix_spare();
         }
         MOFA_TRY(bgrad(first, cur));
         MOFA_TRY(wgrad(first, 0, cur, xin));
@@ -598,22 +677,27 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
     };
     // uv stack (input sigmaCodes); the sigma head adds the third contribution and applies the bim stack's last ReLU
     MOFA_TRY(stack_bwd(p.uv0, p.uv_skip, T(p.bim_skip + n2 - 1), gS, kNoMask));
+    MOFA_TRY(flush());
     {
         const Layer& a = p.L[p.alpha];
         MOFA_TRY(hbwd(d_raw, 3, 1, packed + a.packed_off, a.k_padded[0], Mk(p.bim_skip + n2 - 1), 1, gS));
     }
+    chaining = chain;                                            // ---- second chained launch: shape stack + xyzEncode Linear3..1
     // bim stack (input xyz_code)
     cur = gS, spare = g0;
     MOFA_TRY(stack_bwd(p.bim0, p.bim_skip, T(p.xyz0 + 3), gX, Mk(p.xyz0 + 3)));
     // xyzEncode Linear3..1, then Linear0 -> gradient w.r.t. the encoding features -> rays
     cur = gX, spare = g0;
+    fix_spare();
     for (int li = p.xyz0 + 3; li > p.xyz0; --li) {
         MOFA_TRY(bgrad(li, cur));
         MOFA_TRY(wgrad(li, 0, cur, T(li - 1)));
         MOFA_TRY(bdata(li, 0, cur, Mk(li - 1), 0, spare));
         std::swap(cur, spare);
         if (spare == gX) spare = g1;
+        fix_spare();
     }
+    MOFA_TRY(flush());                                            // (Linear0's product has a 64-wide output: its own launch)
     MOFA_TRY(bgrad(p.xyz0, cur));
     if (d_weights) {   // layer 0's input is the positional encoding itself: regenerate it as panels, then reuse the buffer
         MOFA_TRY(mofa_pe_panels(rays_o, rays_d, z, z_row_stride, pts, M, S, s.pe_point_freqs, Mp, dpe, stream));
@@ -625,6 +709,11 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
     } else {
         MOFA_TRY(mofa_pe_backward(dpe, Mp, rays_o, rays_d, z, z_row_stride, n_rays, S, s.pe_point_freqs, d_rays_o, d_rays_d, stream));
     }
+    // chained launches that did not finish every tile must not look like gradients: NaN into everything this call returns + verdict
+    for (int i = 0; i < nseg; ++i)
+        MOFA_TRY(mofa_internal_chain_verify(cstate[i], ctiles[i], verdict, d_folded, (long long)p.folded_floats, d_view_bias_rows,
+                                            (long long)n_rays * p.L[p.view].n_padded, pts ? d_pts : d_rays_o, pts ? M * 3 : n_rays * 3,
+                                            pts ? nullptr : d_rays_d, n_rays * 3, stream));
     return MOFA_OK;
 }
 #undef MOFA_TRY

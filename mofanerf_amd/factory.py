@@ -104,6 +104,9 @@ def create_nerf(args):
         name = os.path.basename(ckpt_path)[:-4]
         start = int(name) if name.isdigit() else start
 
+    if dev.type == "cuda":      # bind the networks to the device NOW (plan check, mofa_device_init's census): no first-call work inside render()
+        render.bind(model, model_fine)
+
     render_kwargs_train = {
         "network_query_fn": render.run_network, "perturb": args.perturb, "N_importance": args.N_importance,
         "network_fine": model_fine, "N_samples": args.N_samples, "network_fn": model,

@@ -67,6 +67,13 @@ class HipNet:
                 raise lib.MofaError(f"layer {li} of the module is Linear({l.in_features} -> {l.out_features}) but {self.shape} has "
                                     f"Linear({ni.value} -> {no.value}) there: the module was not built by NeRF(D, W, input_ch, ...) with "
                                     "these widths (tools/create_model_condition.py:16-34); refusing to pack it")
+        # launch verdicts (include/mofanerf_hip.h, MOFA_VERDICT_WORDS): sticky words on the device that the verification kernel behind
+        # every chained launch raises, an asynchronous pinned mirror, and the event that says the mirror is current
+        self._verdict: Optional[torch.Tensor] = None
+        self._verdict_host: Optional[torch.Tensor] = None
+        self._verdict_event: Optional[torch.cuda.Event] = None
+        if torch.cuda.is_available() and next(net.parameters()).is_cuda:
+            lib.device_init(next(net.parameters()).device)       # the XCD census (the library's one synchronising call) — here, not in a forward
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
         self._folded: Optional[torch.Tensor] = None
@@ -79,6 +86,54 @@ class HipNet:
     @property
     def net(self) -> Optional[NeRF]:
         return self._net_strong if self._net_strong is not None else self._net_weak()
+
+    # -- launch verdicts ----------------------------------------------------------------------------
+    def verdict_ptr(self, device) -> int:
+        """Device pointer of this network's sticky verdict words (created zeroed on first use)."""
+        if self._verdict is None or self._verdict.device != device:
+            self._verdict = torch.zeros(lib.VERDICT_WORDS, dtype=torch.int32, device=device)
+            self._verdict_host = torch.zeros(lib.VERDICT_WORDS, dtype=torch.int32).pin_memory()
+            self._verdict_event = None
+        return self._verdict.data_ptr()
+
+    def snapshot_verdict(self) -> None:
+        """Enqueue a copy of the verdict words into the pinned mirror behind the launches issued so far (no host synchronisation)."""
+        if self._verdict is None:
+            return
+        self._verdict_host.copy_(self._verdict, non_blocking=True)
+        if self._verdict_event is None:
+            self._verdict_event = torch.cuda.Event()
+        self._verdict_event.record()
+
+    def check_verdict(self, block: bool = False) -> None:
+        """Raise ``MofaError`` if a chained launch of this network ended incomplete (its outputs were overwritten with NaN by the
+        verification kernel).  ``block=False`` looks only if the last snapshot has already arrived — the form the launch paths use before
+        every call, so a failure surfaces at the next call at the latest without ever stalling the host; ``block=True`` waits for it
+        (end of a frame's consumer: PNG hand-off, bench, tests)."""
+        ev = self._verdict_event
+        if ev is None:
+            return
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        w = self._verdict_host.tolist()
+        if w[0] != 0:
+            self._verdict.zero_()
+            self._verdict_event = None
+            raise lib.MofaError(f"a chained launch (k_net_chain) of {self.shape} did not complete: "
+                                f"{'a dependency wait timed out; ' if w[0] & 1 else ''}{'tiles missing; ' if w[0] & 2 else ''}"
+                                f"last launch finished {w[3]} of {w[4]} tiles, {w[5]} bad of {w[1]} chained launches — its outputs were "
+                                "overwritten with NaN.  (A CU-masked stream or a changed compute partition leaves XCD queues unworked; "
+                                "MOFA_CHAIN=0 selects the per-layer launches.)")
+
+    def chained_launches(self, block: bool = True) -> int:
+        """Number of chained launches verified so far (tests: was the chained form really taken?)."""
+        self.snapshot_verdict()
+        if self._verdict_event is None:
+            return 0
+        self._verdict_event.synchronize()
+        return int(self._verdict_host[1])
 
     def invalidate(self):
         """Forget the packed / transposed copies of the weights (they are rebuilt on the next call).  Needed only
@@ -290,12 +345,15 @@ class HipNet:
         R = viewdirs.shape[0]
         view = self._linears[-3]
         ws = self.workspace(R * S, R, viewdirs.device, slot)
+        self.check_verdict()
         lib.check(self._L.mofa_net_forward(self.shape, lib.ptr(self.packed()),
                                            lib.ptr(folded if folded is not None else self._folded),
                                            lib.ptr(view.weight.detach().contiguous()),
                                            lib.ptr(view.bias.detach().contiguous()), lib.ptr(rays_o), lib.ptr(rays_d),
                                            lib.ptr(z), z_row_stride, None, lib.ptr(viewdirs), R, S, lib.ptr(ws),
-                                           lib.ptr(raw_out), None, None, None, lib.stream()), "mofa_net_forward")
+                                           lib.ptr(raw_out), None, None, None, self.verdict_ptr(viewdirs.device), lib.stream()),
+                  "mofa_net_forward")
+        self.snapshot_verdict()
         return raw_out
 
     def forward_points(self, pts, viewdirs, S: int, raw_out: torch.Tensor, folded: Optional[torch.Tensor] = None):
@@ -303,10 +361,12 @@ class HipNet:
         R = viewdirs.shape[0]
         view = self._linears[-3]
         ws = self.workspace(R * S, R, viewdirs.device)
+        self.check_verdict()
         lib.check(self._L.mofa_net_forward(self.shape, lib.ptr(self.packed()),
                                            lib.ptr(folded if folded is not None else self._folded),
                                            lib.ptr(view.weight.detach().contiguous()),
                                            lib.ptr(view.bias.detach().contiguous()), None, None, None, 0, lib.ptr(pts),
                                            lib.ptr(viewdirs), R, S, lib.ptr(ws), lib.ptr(raw_out), None, None, None,
-                                           lib.stream()), "mofa_net_forward")
+                                           self.verdict_ptr(viewdirs.device), lib.stream()), "mofa_net_forward")
+        self.snapshot_verdict()
         return raw_out

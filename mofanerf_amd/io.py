@@ -38,12 +38,17 @@ class PngSink:
         self._pending = []
 
     @staticmethod
-    def _job(path, host, event):
+    def _job(path, host, event, check=None):
         if event is not None:
             event.synchronize()                          # the D2H copy of THIS frame only
+        if check is not None:
+            check()                                      # the launches behind this frame are done: their verdict has arrived with it
         write_png(path, host.numpy() if torch.is_tensor(host) else host)
 
-    def submit(self, path: str, rgb) -> None:
+    def submit(self, path: str, rgb, check=None) -> None:
+        """``check``: optional callable run on the worker once this frame's copy has landed, before the file is written — the renderer
+        passes its launch-verdict check, so a frame whose chained launch ended incomplete (NaN-poisoned) raises instead of becoming a
+        PNG (the error surfaces at ``close()``)."""
         event = None
         if torch.is_tensor(rgb):
             q = (255 * rgb.detach().clamp(0, 1)).to(torch.uint8)
@@ -56,7 +61,7 @@ class PngSink:
                 host = q
         else:
             host = (255 * np.clip(rgb, 0, 1)).astype(np.uint8)
-        self._pending.append(self._pool.submit(self._job, path, host, event))
+        self._pending.append(self._pool.submit(self._job, path, host, event, check))
 
     def close(self) -> None:
         pending, self._pending = self._pending, []

@@ -19,7 +19,7 @@ _fp = C.c_void_p      # device pointers travel as integers
 _i32, _i64, _sz = C.c_int32, C.c_int64, C.c_size_t
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class NetShape(C.Structure):
@@ -41,6 +41,7 @@ SIGNATURES = {
     "mofa_abi_version": (C.c_int, []),
     "mofa_last_error": (C.c_char_p, []),
     "mofa_config_reload": (C.c_int, []),
+    "mofa_device_init": (C.c_int, [_fp, C.POINTER(_i32)]),
     "mofa_net_num_layers": (C.c_int, [NetShape]),
     "mofa_net_layer_dims": (C.c_int, [NetShape, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "mofa_pe_k_padded": (C.c_int, [_i32]),
@@ -50,14 +51,14 @@ SIGNATURES = {
     "mofa_net_pack": (C.c_int, [NetShape, C.POINTER(_fp), _fp, _fp]),
     "mofa_net_fold": (C.c_int, [NetShape, C.POINTER(_fp), C.POINTER(_fp), _fp, _fp, _fp, _fp, _fp]),
     "mofa_net_forward": (C.c_int, [NetShape, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _fp, _fp, _i64, _i32, _fp, _fp,
-                                   _fp, _fp, _fp, _fp]),
+                                   _fp, _fp, _fp, _fp, _fp]),
     "mofa_net_packed_t_floats": (_sz, [NetShape]),
     "mofa_net_tape_floats": (_sz, [NetShape, _i64]),
     "mofa_net_mask_tape_words": (_sz, [NetShape, _i64]),
     "mofa_net_backward_workspace_floats": (_sz, [NetShape, _i64]),
     "mofa_net_pack_t": (C.c_int, [NetShape, C.POINTER(_fp), _fp, _fp]),
     "mofa_net_backward": (C.c_int, [NetShape, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _fp, _i64, _i32, _fp, _fp, _fp, _fp,
-                                    _fp, _fp, C.POINTER(_fp), _fp]),
+                                    _fp, _fp, C.POINTER(_fp), _fp, _fp]),
     "mofa_weight_grad_workspace_floats": (_sz, [_i64, _i32, _i32]),
     "mofa_weight_grad": (C.c_int, [_fp, _i32, _fp, _i32, _i64, _i64, _i32, _i32, _fp, _i32, _i32, _fp, _fp, _fp]),
     "mofa_head_weight_grad": (C.c_int, [_fp, _i32, _i32, _fp, _i32, _i64, _i64, _i32, _fp, _i32, _fp]),
@@ -131,7 +132,26 @@ def load() -> C.CDLL:
     return _lib
 
 
-PROF_KINDS = 6     # MOFA_PROF_KINDS: k_layer fwd, k_mlp_fused, k_layer<BWD>, k_wgrad, k_layer fwd with per-ray bias (view layer), k_net_chain
+PROF_KINDS = 7     # MOFA_PROF_KINDS: k_layer fwd, k_mlp_fused, k_layer<BWD>, k_wgrad, k_layer fwd with per-ray bias (view layer), k_net_chain fwd, k_net_chain bwd
+VERDICT_WORDS = 8  # MOFA_VERDICT_WORDS
+
+
+_device_census = {}     # device index -> workgroups seen per XCD by mofa_device_init
+
+
+def device_init(device=None):
+    """``mofa_device_init`` for ``device`` (default: the current one), once per device and process: the XCD census the chained launch
+    relies on + the persistent kernel's LDS attribute.  This is the library's ONE synchronising call; it belongs where a network is
+    bound to a device (``HipNet.__init__`` / ``Renderer.bind``), never inside a forward.  Returns the census (8 counts)."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if idx not in _device_census:
+        counts = (_i32 * 8)()
+        with torch.cuda.device(idx):
+            check(load().mofa_device_init(torch.cuda.current_stream(idx).cuda_stream, counts), "mofa_device_init")
+        _device_census[idx] = list(counts)
+    return _device_census[idx]
 
 
 def reload_env() -> None:

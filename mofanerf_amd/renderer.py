@@ -179,6 +179,23 @@ class Renderer(torch.nn.Module):
     def _device(self):
         return next(self.idSpecificMod.parameters()).device
 
+    def bind(self, *nets):
+        """Create the device-side state of ``nets`` (``HipNet``: the plan check against the module, ``mofa_device_init``'s per-device
+        census — the library's one synchronising call) up front, so that the first ``render()`` finds everything in place;
+        ``create_nerf`` calls it.  Networks that were not bound are bound at their first use."""
+        for n in nets:
+            if n is not None:
+                self._hip(n)
+        return self
+
+    def check_launches(self, block: bool = True):
+        """Raise ``MofaError`` if any chained launch issued through this renderer ended incomplete (the kernel abandons a launch rather
+        than compute on incomplete inputs, and a verification kernel then overwrites the outputs with NaN — see
+        ``HipNet.check_verdict``).  The launch paths look without blocking before every call; ``block=True`` waits for the verdict of
+        everything issued so far — for whoever consumes a frame (``render_path`` after its copies, the PNG sink, bench, tests)."""
+        for h in list(self._hipnets.values()):
+            h.check_verdict(block=block)
+
     def _const_row(self, key, builder, device):
         """Small per-call constant rows (sample positions, u) are built once on the host with the same torch CPU
         ops as the reference and cached on the device."""
@@ -202,23 +219,37 @@ class Renderer(torch.nn.Module):
         return self._hip(net).fold(e, row, tex_code.to(row.device))
 
     # ------------------------------------------------------------------------------------------------
-    def run_network(self, inputs, viewdirs, fn=None):
+    def run_network(self, inputs, viewdirs, fn=None, weight_grads=None):
         """``inputs [R,S,3]`` points, ``viewdirs [R,3]`` -> raw ``[R,S,4]`` (render_class.py:69-94; also ``network_query_fn``,
         tools/create_model_condition.py:50).  Under autograd it is differentiable like the reference's: gradients reach
         ``inputs``, ``viewdirs``, the shape / texture / expression codes (through ``self.shapeCodes``, ``self.decoding_texCodes``,
-        ``self.expCodes_Sigma``) and, when ``self._weight_grads`` is set (``render()`` sets it; ``render_fitting()`` sets
-        ``fit_weight_grads``), the network weights — HIP backward (``mofa_net_backward`` with explicit points)."""
+        ``self.expCodes_Sigma``) and the StyleModule — HIP backward (``mofa_net_backward`` with explicit points).  The network WEIGHTS
+        take part when ``weight_grads`` says so: ``True`` / ``False`` explicitly, ``None`` = what the last ``render()`` (on) /
+        ``render_fitting()`` (``fit_weight_grads``) chose — and only those that ``requires_grad``.  The tape-keeping path is taken only
+        if something actually asks for a gradient: a plain call outside ``no_grad`` whose inputs, codes and (participating) weights
+        all have ``requires_grad=False`` runs the inference kernels and keeps nothing."""
         if viewdirs is None:
             raise NotImplementedError(_NO_VIEWDIRS)
         R, S = int(inputs.shape[0]), int(inputs.shape[1])
         h = self._hip(fn)
-        folded = self._fold_codes(fn, self.decoding_texCodes)
+        want_w = (self._weight_grads if weight_grads is None else bool(weight_grads)) and any(l.weight.requires_grad or l.bias.requires_grad
+                                                                                                 for l in h._linears)
+        rg = lambda t: torch.is_tensor(t) and t.requires_grad
+        needs_grad = torch.is_grad_enabled() and (want_w or rg(inputs) or rg(viewdirs) or rg(self.shapeCodes) or rg(self.decoding_texCodes) or
+                                                  rg(self.expCodes_Sigma[self.expType]) or
+                                                  any(q.requires_grad for q in unwrap(self.idSpecificMod).parameters()))
+        keep, self._weight_grads = self._weight_grads, want_w
+        try:
+            with torch.set_grad_enabled(needs_grad):
+                folded = self._fold_codes(fn, self.decoding_texCodes)
+        finally:
+            self._weight_grads = keep
         rays_per = max(1, int(self.netchunk) // S)
-        if torch.is_grad_enabled():
+        if needs_grad:
             h.tape_recompute, h.force_fp32_tape = bool(self.tape_recompute), self.fit_tape == "fp32"
             pts = inputs.reshape(-1, 3).float()
-            vb = view_bias_torch(h, viewdirs.float(), detach_params=not self._weight_grads)
-            wts = [l.weight for l in h._linears] if self._weight_grads else []
+            vb = view_bias_torch(h, viewdirs.float(), detach_params=not want_w)
+            wts = [l.weight for l in h._linears] if want_w else []
             parts = [NetFn.apply(h, None, None, None, 0, S, folded, vb[i:i + rays_per], pts[i * S:(i + rays_per) * S], *wts)
                      for i in range(0, R, rays_per)]
             return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
@@ -542,13 +573,15 @@ class Renderer(torch.nn.Module):
                                                        shapeCodes=shapeCodes[i, :].reshape(1, -1), uvMap=uvMap[i, :],
                                                        expType=expType[i], **render_kwargs)
                 if savedir is not None:
-                    sink.submit(out_file(i), rgb)
+                    sink.submit(out_file(i), rgb, check=lambda: self.check_launches(block=False))
                 frames.append(rgb.detach())
                 disparities.append(disp.detach())
         finally:
             if shared is None:
                 sink.close()
-        return torch.stack(frames, 0).cpu().numpy(), torch.stack(disparities, 0).cpu().numpy()
+        out = torch.stack(frames, 0).cpu().numpy(), torch.stack(disparities, 0).cpu().numpy()
+        self.check_launches(block=True)                     # (the copies above already waited for the device)
+        return out
 
 
 myRenderer = Renderer   # the reference's class name
