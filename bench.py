@@ -259,6 +259,91 @@ def variant_series(arch, steps, dev, L, bm, tex, exp, K, rays, angles, args):
         ARCH = keep
 
 
+def all_rays(L, K, dev, angle, b, n):
+    """Rays of pixels [b, b + n) of the H x W view at `angle` (mofa_get_rays: resident in HBM before any timed region)."""
+    c2w = pose_spherical(angle, 0.0, 16.0)[:3, :4].contiguous().to(dev)
+    o, d, v = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(3))
+    lib.check(L.mofa_get_rays(H, W, float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]), lib.ptr(c2w), b, n,
+                              lib.ptr(o), lib.ptr(d), lib.ptr(v), lib.stream()), "mofa_get_rays")
+    return o, d
+
+
+def make_grad_step(mode, n, render, kw, dev, rank, L, K, bm, tex, exp, timed_comm=lambda fn: fn()):
+    """One step of BASELINE configs[2] (`fit`: run_fit.py:268-313, N_rand rays, forward + backward to codes / light, Adam) or configs[4]
+    (`train`: run_train.py:278-364, N_rand rays per GPU, texture encoder, forward + backward incl. weight gradients, the flat gradient
+    bucket's all-reduce, Adam) on `n` seeded rays of the H x W view — the step function the fit / train modes AND the headline
+    line's `variants.fit1024` / `variants.train4096` time."""
+    n_total = H * W
+    o, d = all_rays(L, K, dev, 15.0 + rank, 0, n_total)
+    idx = torch.from_numpy(np.random.default_rng(rank).choice(n_total, n, replace=False)).to(dev)
+    rays_b = torch.stack([o[idx], d[idx]], 0)
+    target = torch.rand(n, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
+    if mode == "fit":
+        cs = [t.clone().requires_grad_(True) for t in (bm, tex, exp)]
+        light = torch.ones(1, device=dev, requires_grad=True)
+        opts = [torch.optim.Adam(cs, lr=1e-3), torch.optim.Adam([light], lr=1e-3)]
+        return lambda i: msteps.fit_step(render, dict(kw), opts, H, W, K, rays_b, target, cs[0], cs[1], cs[2], light, chunk=n)[0]
+    kwt = dict(kw); kwt["perturb"] = 1.0
+    render.train()
+    params = list(kw["network_fn"].parameters()) + list(kw["network_fine"].parameters()) + list(render.grad_parameter())
+    opt = torch.optim.Adam(params, lr=5e-5)
+    bucket = mdist.GradBucket(params)
+    sync0 = bucket.sync
+    bucket.sync = lambda: timed_comm(sync0)
+    uv = torch.rand(512, 512, 3, device=dev)
+    bm_n = bm.expand(n, -1)
+    return lambda i: msteps.train_step(render, kwt, opt, bucket, H, W, K, rays_b, target, bm_n, uv, 3, chunk=n)
+
+
+def roofline_of(ms, launches, pflops, dt):
+    """The dominant MFMA kernel of a timed region (largest summed HIP-event time) against the fp32 matrix peak."""
+    NK = lib.PROF_KINDS
+    dom = max(range(NK), key=lambda k: ms[k])
+    ach = pflops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+    others = [{"kernel": KERNELS[k][0], "role": KERNELS[k][1], "launches": int(launches[k]), "total_ms": round(ms[k], 2),
+               "tflops": round(pflops[k] / (ms[k] * 1e-3) / 1e12, 2)} for k in range(NK) if k != dom and ms[k] > 0]
+    return dom, {"bound": "mfma", "kernel": f"{KERNELS[dom][0]} ({KERNELS[dom][2]})", "role": KERNELS[dom][1], "achieved": round(ach, 2),
+                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                 "launches": int(launches[dom]), "avg_launch_ms": round(ms[dom] / max(1, launches[dom]), 4),
+                 "algorithmic_gflop_per_launch": round(pflops[dom] / max(1, launches[dom]) / 1e9, 3),
+                 "share_of_timed_region": round(ms[dom] * 1e-3 / dt, 4), "other_mfma_kernels": others}
+
+
+def step_variant(mode, n, steps, warmup, dev, L, K, bm, tex, exp):
+    """BASELINE configs[2] / configs[4] inside the headline's line (VERDICT r4 missing 3): a fresh product of the shipped sizes, `warmup`
+    untimed + `steps` timed steps of `make_grad_step` with the same synchronize bracket and its own HIP-event session, timed AFTER the
+    headline's region.  One GPU: no collective (the N > 1 forms are `--mode fit|train --gpus N`)."""
+    render, kw, _ = build_product(dev, with_tex=(mode == "train"))
+    step = make_grad_step(mode, n, render, kw, dev, 0, L, K, bm, tex, exp)
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    mem0 = torch.cuda.memory_allocated(dev)
+    torch.cuda.reset_peak_memory_stats(dev)
+    lib.check(L.mofa_prof_begin(), "mofa_prof_begin")
+    t0 = time.perf_counter()
+    for i in range(steps):
+        last = step(warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    NK = lib.PROF_KINDS
+    ms, launches, pflops = (ctypes.c_double * NK)(), (ctypes.c_int64 * NK)(), (ctypes.c_double * NK)()
+    lib.check(L.mofa_prof_end(ms, launches, pflops), "mofa_prof_end")
+    peak_extra = torch.cuda.max_memory_allocated(dev) - mem0
+    render.check_launches(block=True)
+    assert bool(torch.isfinite(last).all())
+    _, roof = roofline_of(ms, launches, pflops, dt)
+    work = flops_per_ray(True) * (2 if mode == "fit" else 3)
+    what = {"fit": f"run_fit.py photometric step: {n} rays of a {H}x{W} view, forward + backward to codes / light (mask-only tape), Adam "
+                   "(BASELINE.json configs[2])",
+            "train": f"run_train.py step: {n} rays of a {H}x{W} view, texture encoder, forward + backward incl. weight gradients, flat gradient "
+                     "bucket, Adam (BASELINE.json configs[4], one GPU's share)"}[mode]
+    return {"workload": what + f", coarse {ARCH[1]}x{ARCH[0]} + fine {ARCH[3]}x{ARCH[2]}", "value": round(n * steps / dt, 1), "unit": "rays/s",
+            "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2), "gflop_per_ray_folded": round(work / 1e9, 4),
+            "whole_path_tflops": round(work * n * steps / dt / 1e12, 2), "roofline": roof,
+            "step_peak_extra_memory_gb": round(peak_extra / 2 ** 30, 3)}
+
+
 def self_spawn(n):
     """`python bench.py --gpus N` without a torchrun environment: re-execute under torch.distributed.run (one rank per GPU)."""
     s = socket.socket()
@@ -295,6 +380,10 @@ def main():
     ap.add_argument("--size", type=int, default=512, help="image side (512 = the benchmark; smaller only for functional tests)")
     ap.add_argument("--variant-steps", type=int, default=3, help="frames of the labelled fine-256x8 series after the headline loop (BASELINE.md "
                     "section 2 asks for both series; render mode, N = 1, shipped --arch only; 0 = skip)")
+    ap.add_argument("--fit-steps", type=int, default=10, help="steps of BASELINE configs[2] (run_fit.py step, 1,024 rays) timed after the headline "
+                    "loop into variants.fit1024 (render mode, N = 1, shipped sizes; 0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=4, help="steps of BASELINE configs[4] (run_train.py step, 4,096 rays) timed after the "
+                    "headline loop into variants.train4096 (same conditions; 0 = skip)")
     ap.add_argument("--rays", type=int, default=None, help="fit / train: N_rand per GPU (default 1024 / 4096)")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -325,6 +414,7 @@ def main():
     K = synth.intrinsics(H, W)
     n_total = H * W
     comm_ms = []                                                       # per-step collective time on this rank (N > 1)
+    compute_ev = []                                                    # per-step time of this rank's row block (render, N > 1)
 
     def timed_comm(fn):
         if not mdist.active():
@@ -336,55 +426,32 @@ def main():
         comm_ms.append((e0, e1))
         return out
 
-    def all_rays(angle, b, n):
-        c2w = pose_spherical(angle, 0.0, 16.0)[:3, :4].contiguous().to(dev)
-        o, d, v = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(3))
-        lib.check(L.mofa_get_rays(H, W, float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]), lib.ptr(c2w), b, n,
-                                  lib.ptr(o), lib.ptr(d), lib.ptr(v), lib.stream()), "mofa_get_rays")
-        return o, d
-
     if a.mode == "render":
         b, e = mdist.shard_range(n_total, rank, world, align=W)           # whole image rows per rank
         angles = [0.0, -60.0, 60.0]                                         # run_fit.py's three novel views
-        rays = {ang: torch.stack(all_rays(ang, b, e - b), 0) for ang in angles}   # inputs resident in HBM before timing
+        rays = {ang: torch.stack(all_rays(L, K, dev, ang, b, e - b), 0) for ang in angles}   # inputs resident in HBM before timing
         frame_buf = [None]
         units_per_step, scaling = n_total, "strong"
 
         def step(i):
             r = rays[angles[i % len(angles)]]
+            c0 = torch.cuda.Event(enable_timing=True) if mdist.active() else None
+            if c0 is not None:
+                c0.record()
             with torch.no_grad():                                           # render-only, as run_fit.py's novel-view loop
                 rgb, disp, acc, _ = render.render_fitting(H, W, K, chunk=args.chunk, rays=r, shapeCodes=bm, uvCodes=tex,
                                                           expType=20, expCodes=exp, **kw)
             tile = torch.cat([rgb, disp[:, None], acc[:, None]], -1)        # [rays/N, 5]
+            if c0 is not None:                                              # this rank's own share of the frame, without the exchange
+                c1 = torch.cuda.Event(enable_timing=True)
+                c1.record()
+                compute_ev.append((c0, c1))
             frame_buf[0] = timed_comm(lambda: mdist.all_gather_tiles(tile, n_total, world, rank, align=W, out=frame_buf[0]))
             return frame_buf[0]
     else:
         n = a.rays or (1024 if a.mode == "fit" else 4096)
-        o, d = all_rays(15.0 + rank, 0, n_total)
-        idx = torch.from_numpy(np.random.default_rng(rank).choice(n_total, n, replace=False)).to(dev)
-        rays_b = torch.stack([o[idx], d[idx]], 0)
-        target = torch.rand(n, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
         units_per_step, scaling = n * world, "weak"
-        if a.mode == "fit":
-            cs = [t.clone().requires_grad_(True) for t in (bm, tex, exp)]
-            light = torch.ones(1, device=dev, requires_grad=True)
-            opts = [torch.optim.Adam(cs, lr=1e-3), torch.optim.Adam([light], lr=1e-3)]
-
-            def step(i):
-                return msteps.fit_step(render, dict(kw), opts, H, W, K, rays_b, target, cs[0], cs[1], cs[2], light, chunk=n)[0]
-        else:
-            kwt = dict(kw); kwt["perturb"] = 1.0
-            render.train()
-            params = list(kw["network_fn"].parameters()) + list(kw["network_fine"].parameters()) + list(render.grad_parameter())
-            opt = torch.optim.Adam(params, lr=5e-5)
-            bucket = mdist.GradBucket(params)
-            sync0 = bucket.sync
-            bucket.sync = lambda: timed_comm(sync0)
-            uv = torch.rand(512, 512, 3, device=dev)
-            bm_n = bm.expand(n, -1)
-
-            def step(i):
-                return msteps.train_step(render, kwt, opt, bucket, H, W, K, rays_b, target, bm_n, uv, 3, chunk=n)
+        step = make_grad_step(a.mode, n, render, kw, dev, rank, L, K, bm, tex, exp, timed_comm)
 
     def sync():
         if mdist.active():
@@ -395,6 +462,7 @@ def main():
         step(i)
     sync()
     comm_ms.clear()
+    compute_ev.clear()
     mem0 = torch.cuda.memory_allocated(dev)
     torch.cuda.reset_peak_memory_stats(dev)
     lib.check(L.mofa_prof_begin(), "mofa_prof_begin")
@@ -409,6 +477,13 @@ def main():
     peak_extra = torch.cuda.max_memory_allocated(dev) - mem0           # what one step allocates on top of the resident state
     dt = mdist.barrier_max(dt, dev)
     comm = sum(e0.elapsed_time(e1) for e0, e1 in comm_ms) / max(1, len(comm_ms)) if comm_ms else 0.0
+    render.check_launches(block=True)           # a chained launch that ended incomplete is an error, never a number
+    compute_minmax = None
+    if compute_ev and mdist.active():           # who is the slow rank, and by how much: min / max over ranks of the mean per-step compute time
+        mine = sum(e0.elapsed_time(e1) for e0, e1 in compute_ev) / len(compute_ev)
+        t = torch.tensor([mine, -mine], dtype=torch.float64, device="cpu" if torch.distributed.get_backend() == "gloo" else dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        compute_minmax = (round(-float(t[1]), 3), round(float(t[0]), 3))
     if a.mode == "render":
         assert last.shape == (n_total, 5) and bool(torch.isfinite(last[:, :3]).all())
     else:
@@ -419,10 +494,9 @@ def main():
         # dominant kernel = the MFMA kernel kind with the largest summed time.  Its algorithmic FLOPs are 2*M*K*N of its
         # launches; at the benchmark sizes nothing is padded (K, N multiples of 64, M a multiple of 256), except layer 0's
         # K = 63 -> 64 inside the persistent kernel (0.1 %).
-        dom = max(range(NK), key=lambda k: ms[k])
+        dom, roof = roofline_of(ms, launches, pflops, dt)
         ksym, krole, kdesc = KERNELS[dom]
         kname = f"{ksym} ({kdesc})"
-        achieved = pflops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         traffic, tinfo = None, {}
         # PMC-derived bytes/launch (separate --pmc passes), one record per kernel
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic_chain.json" if dom == 5 else "hbm_traffic.json")
@@ -442,8 +516,6 @@ def main():
             else:
                 tinfo = {"traffic_source": f"null: profiles/{os.path.basename(tpath)} was taken on kernel sources {str(tj.get('csrc_sha256'))[:16]} / "
                                            f"{tj.get('kernel')}, this build is {digest[:16]} / {kname.split(' ')[0]} — re-run tools/gpu_profile_round.sh"}
-        others = [{"kernel": KERNELS[k][0], "role": KERNELS[k][1], "launches": int(launches[k]), "total_ms": round(ms[k], 2),
-                   "tflops": round(pflops[k] / (ms[k] * 1e-3) / 1e12, 2)} for k in range(NK) if k != dom and ms[k] > 0]
         fwd = flops_per_ray(True)
         work = {"render": fwd, "fit": 2 * fwd, "train": 3 * fwd}[a.mode]    # + backward-data (+ weight gradients)
         metric = {"render": "rendered rays/sec (64c+128f samples) at 512^2 novel-view",
@@ -470,13 +542,8 @@ def main():
                        "gflop_per_ray_folded": round(work / 1e9, 4),
                        "gflop_per_ray_nominal": round(work / fwd * flops_per_ray(False) / 1e9, 4)},
             "whole_path_tflops": round(work * units_per_s / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": kname, "role": krole,
-                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "launches": int(launches[dom]), "avg_launch_ms": round(ms[dom] / max(1, launches[dom]), 4),
-                         "algorithmic_gflop_per_launch": round(pflops[dom] / max(1, launches[dom]) / 1e9, 3),
-                         "share_of_timed_region": round(ms[dom] * 1e-3 / dt, 4),
-                         "other_mfma_kernels": others, **tinfo},
+            "roofline": {**{k: v for k, v in roof.items() if k != "other_mfma_kernels"}, "traffic": traffic,
+                         "other_mfma_kernels": roof["other_mfma_kernels"], **tinfo},
         }
         if mdist.active():
             out["rccl_ranks"] = world
@@ -484,11 +551,27 @@ def main():
             out["collective"] = {"what": {"render": "all_gather_into_tensor of the [rays/N,5] fp32 tiles, written straight into the frame",
                                           "fit": "none (replicas)", "train": "all_reduce of the flat fp32 gradient bucket"}[a.mode],
                                  "avg_ms_per_step_rank0": round(comm, 4)}
-        if world == 1 and a.mode == "render" and a.variant_steps > 0 and ARCH == (8, 256, 10, 1024) and (H, W) == (512, 512) and not a.netchunk:
-            out["variants"] = {"fine256x8": variant_series((8, 256, 8, 256), a.variant_steps, dev, L, bm, tex, exp, K, rays, angles, args)}
-        if world == 1 and a.mode == "render" and a.parity_rays > 0:
+            if compute_minmax is not None:
+                out["collective"]["compute_ms_per_step_min_over_ranks"], out["collective"]["compute_ms_per_step_max_over_ranks"] = compute_minmax
+        if a.mode == "render":
+            # what the timed region produced, so that an N > 1 line can be checked against the N = 1 line of the same view: the rows are
+            # rendered by different ranks but chunk invariance is bit-exact, so the gathered frame must hash to the same digest
+            import hashlib
+            out["frame_sha256"] = hashlib.sha256(last.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+            out["frame_view_deg"] = angles[(a.warmup + a.steps - 1) % len(angles)]
+        if a.mode == "render" and a.parity_rays > 0:
+            # ANY world size: the sample is drawn over the whole GATHERED frame — rows other ranks rendered included — re-rendered on this
+            # rank's device (bit-equality with the gathered pixels = the exchange moved the right bytes) and teacher-forced against the oracle
             out["parity"] = parity_sample(render, kw, args, K, last, angles[(a.warmup + a.steps - 1) % len(angles)], bm, tex, exp, dev,
                                           n=a.parity_rays)
+        if world == 1 and a.mode == "render" and ARCH == (8, 256, 10, 1024) and (H, W) == (512, 512) and not a.netchunk:
+            out["variants"] = {}
+            if a.variant_steps > 0:
+                out["variants"]["fine256x8"] = variant_series((8, 256, 8, 256), a.variant_steps, dev, L, bm, tex, exp, K, rays, angles, args)
+            if a.fit_steps > 0:
+                out["variants"]["fit1024"] = step_variant("fit", 1024, a.fit_steps, 3, dev, L, K, bm, tex, exp)
+            if a.train_steps > 0:
+                out["variants"]["train4096"] = step_variant("train", 4096, a.train_steps, 4, dev, L, K, bm, tex, exp)
         if world == 1 and a.cpu_rays > 0:
             out["cpu_baseline"] = cpu_baseline(a.cpu_rays, backward=(a.mode == "fit"), reps=a.cpu_reps,
                                                tile_reps=a.cpu_tile_reps if (H, W) == (512, 512) else 0)

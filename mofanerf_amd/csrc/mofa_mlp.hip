@@ -853,8 +853,9 @@ __global__ __launch_bounds__(256) void k_chain_verify(const unsigned* __restrict
     const unsigned flags = status[0], finished = status[1];
     const bool bad = flags != 0u || finished != expect;
     if (verdict && blockIdx.x == 0 && threadIdx.x == 0) {
-        verdict[1] += 1u, verdict[2] = flags, verdict[3] = finished, verdict[4] = expect;
-        if (bad) verdict[0] |= (flags ? 1u : 0u) | (finished != expect ? 2u : 0u), verdict[5] += 1u;
+        atomicAdd(verdict + 1, 1u);                      // (atomics: two streams may verify launches of one network at the same time)
+        verdict[2] = flags, verdict[3] = finished, verdict[4] = expect;
+        if (bad) atomicOr(verdict, (flags ? 1u : 0u) | (finished != expect ? 2u : 0u)), atomicAdd(verdict + 5, 1u);
     }
     if (!bad) return;
     const float nan = __builtin_nanf("");

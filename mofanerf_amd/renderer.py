@@ -201,7 +201,10 @@ class Renderer(torch.nn.Module):
         ops as the reference and cached on the device."""
         k = (key, str(device))
         if k not in self._cache:
-            self._cache[k] = builder().float().contiguous().to(device)
+            row = builder().float().contiguous()
+            # through pinned memory, asynchronously: a pageable host->device copy synchronises the host, and the first frame of a
+            # process must not (eight ranks would each stall); the stream orders the copy before the kernels that read the row
+            self._cache[k] = row.pin_memory().to(device, non_blocking=True) if torch.device(device).type == "cuda" else row.to(device)
         return self._cache[k]
 
     def _fold_codes(self, net, tex_code):
