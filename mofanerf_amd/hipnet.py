@@ -28,7 +28,7 @@ def _freqs_of(ch: int, what: str) -> int:
 
 
 class HipNet:
-    def __init__(self, net: NeRF, point_freqs: int = 10, weak: bool = False):
+    def __init__(self, net: NeRF, point_freqs: int = 10, weak: bool = False, embedded: bool = False):
         """``point_freqs``: ``multires`` of the point encoding the renderer feeds this network (tools/config_parser.py:53).  The module
         alone only knows ``input_ch = (3 + 6*multires) + input_ch_expCodes`` (tools/create_model_condition.py:25), so the split between
         per-point encoding columns and per-call expression-code columns comes from the renderer's ``embed_fn``; every other width is
@@ -36,37 +36,37 @@ class HipNet:
         (``mofa_net_layer_dims``) — a module the plan does not describe is refused here, never mis-read by a kernel.
 
         ``weak``: keep only a weak reference to the module (the Linear children are still held) — for caches keyed weakly on the
-        module itself (model._EMBEDDED_CACHE): a strong back-reference from the value would keep the key alive for ever."""
+        module itself (model._EMBEDDED_CACHE): a strong back-reference from the value would keep the key alive for ever.
+
+        ``embedded``: the state behind ``NeRF.forward`` on ALREADY-EMBEDDED per-point inputs (``forward_embedded``) only.  There every
+        input column is a per-point column, so neither the encoding / expression split nor ``input_ch_views = 3 + 6 L`` means
+        anything: like the reference's module (models/model.py:85-137) any ``input_ch`` / ``input_ch_views`` is accepted, the Linear
+        shapes are checked against the constructor's own rule, and the folded entry points (which need the C plan) are unavailable."""
         if not isinstance(net, NeRF):
             raise lib.MofaError(f"expected mofanerf_amd.model.NeRF, got {type(net).__name__}")
         self._net_strong = None if weak else net
         self._net_weak = weakref.ref(net)
         self.D, self.W = int(net.D), int(net.W)
-        self.point_freqs = int(point_freqs)
-        self.ch_pe = 3 + 6 * self.point_freqs
-        self.ch_exp = int(net.input_ch) - self.ch_pe
-        if self.ch_exp < 0:
-            raise lib.MofaError(f"NeRF.input_ch = {net.input_ch} is narrower than the point encoding it is fed (multires = {point_freqs} "
-                                f"-> {self.ch_pe} columns); input_ch = (3 + 6*multires) + input_ch_expCodes (tools/create_model_condition.py:25)")
-        self.view_freqs = _freqs_of(int(net.input_ch_views), "NeRF.input_ch_views")
-        self.ch_views = 3 + 6 * self.view_freqs
-        self.ch_shape, self.ch_tex = int(net.input_ch_shapeCodes), int(net.input_ch_textureCodes)
-        self.shape = lib.NetShape(net.D, net.W, self.point_freqs, self.view_freqs, self.ch_exp, self.ch_shape, self.ch_tex)
+        self.embedded = bool(embedded)
         self._L = lib.load()
         self._linears = net.ordered_linears()
-        n_plan = self._L.mofa_net_num_layers(self.shape)
-        if n_plan < 0:
-            raise lib.MofaError(f"unsupported network shape {self.shape}: {self._L.mofa_last_error().decode()}")
-        if n_plan != len(self._linears):
-            raise lib.MofaError(f"layer count mismatch: the module has {len(self._linears)} Linear layers, the plan of {self.shape} has {n_plan}")
-        import ctypes as C
-        no, ni = C.c_int32(), C.c_int32()
-        for li, l in enumerate(self._linears):
-            lib.check(self._L.mofa_net_layer_dims(self.shape, li, C.byref(no), C.byref(ni)), "mofa_net_layer_dims")
-            if (l.out_features, l.in_features) != (no.value, ni.value):
-                raise lib.MofaError(f"layer {li} of the module is Linear({l.in_features} -> {l.out_features}) but {self.shape} has "
-                                    f"Linear({ni.value} -> {no.value}) there: the module was not built by NeRF(D, W, input_ch, ...) with "
-                                    "these widths (tools/create_model_condition.py:16-34); refusing to pack it")
+        self.ch_shape, self.ch_tex = int(net.input_ch_shapeCodes), int(net.input_ch_textureCodes)
+        if self.embedded:
+            D, W = self.D, self.W
+            self.point_freqs, self.view_freqs, self.shape = 0, None, None
+            self.ch_pe, self.ch_exp, self.ch_views = int(net.input_ch), 0, int(net.input_ch_views)
+            want = ([(W, self.ch_pe)] + [(W, W)] * 3 +
+                    [(W, self.ch_shape + W)] + [(W, W)] * 4 + [(W, self.ch_shape + 2 * W)] + [(W, W)] * (D - 6) +
+                    [(W, self.ch_tex + W)] + [(W, W)] * 4 + [(W, self.ch_tex + 2 * W)] + [(W, W)] * (D - 6) +
+                    [(W // 2, self.ch_views + W), (1, W), (3, W // 2)])
+            got = [(l.out_features, l.in_features) for l in self._linears]
+            if D < 6 or got != want:
+                bad = next((i for i, (g, w_) in enumerate(zip(got, want)) if g != w_), min(len(got), len(want)))
+                raise lib.MofaError(f"layer {bad} of the module is not what NeRF(D={D}, W={W}, input_ch={self.ch_pe}, input_ch_views={self.ch_views}, "
+                                    f"input_ch_shapeCodes={self.ch_shape}, input_ch_textureCodes={self.ch_tex}) builds (models/model.py:85-118); "
+                                    "refusing to pack it")
+        else:
+            self._init_plan(net, point_freqs)
         # launch verdicts (include/mofanerf_hip.h, MOFA_VERDICT_WORDS): sticky words on the device that the verification kernel behind
         # every chained launch raises, an asynchronous pinned mirror, and the event that says the mirror is current
         self._verdict: Optional[torch.Tensor] = None
@@ -86,6 +86,35 @@ class HipNet:
     @property
     def net(self) -> Optional[NeRF]:
         return self._net_strong if self._net_strong is not None else self._net_weak()
+
+    def _init_plan(self, net: NeRF, point_freqs: int) -> None:
+        self.point_freqs = int(point_freqs)
+        self.ch_pe = 3 + 6 * self.point_freqs
+        self.ch_exp = int(net.input_ch) - self.ch_pe
+        if self.ch_exp < 0:
+            raise lib.MofaError(f"NeRF.input_ch = {net.input_ch} is narrower than the point encoding it is fed (multires = {point_freqs} "
+                                f"-> {self.ch_pe} columns); input_ch = (3 + 6*multires) + input_ch_expCodes (tools/create_model_condition.py:25)")
+        self.view_freqs = _freqs_of(int(net.input_ch_views), "NeRF.input_ch_views")
+        self.ch_views = 3 + 6 * self.view_freqs
+        self.shape = lib.NetShape(net.D, net.W, self.point_freqs, self.view_freqs, self.ch_exp, self.ch_shape, self.ch_tex)
+        n_plan = self._L.mofa_net_num_layers(self.shape)
+        if n_plan < 0:
+            raise lib.MofaError(f"unsupported network shape {self.shape}: {self._L.mofa_last_error().decode()}")
+        if n_plan != len(self._linears):
+            raise lib.MofaError(f"layer count mismatch: the module has {len(self._linears)} Linear layers, the plan of {self.shape} has {n_plan}")
+        import ctypes as C
+        no, ni = C.c_int32(), C.c_int32()
+        for li, l in enumerate(self._linears):
+            lib.check(self._L.mofa_net_layer_dims(self.shape, li, C.byref(no), C.byref(ni)), "mofa_net_layer_dims")
+            if (l.out_features, l.in_features) != (no.value, ni.value):
+                raise lib.MofaError(f"layer {li} of the module is Linear({l.in_features} -> {l.out_features}) but {self.shape} has "
+                                    f"Linear({ni.value} -> {no.value}) there: the module was not built by NeRF(D, W, input_ch, ...) with "
+                                    "these widths (tools/create_model_condition.py:16-34); refusing to pack it")
+
+    def _need_plan(self, what: str) -> None:
+        if self.shape is None:
+            raise lib.MofaError(f"{what}: this HipNet was built for NeRF.forward on embedded inputs only (embedded=True); the folded "
+                                "renderer path needs HipNet(net, point_freqs=multires)")
 
     # -- launch verdicts ----------------------------------------------------------------------------
     def verdict_ptr(self, device) -> int:
@@ -154,6 +183,7 @@ class HipNet:
 
     def packed(self) -> torch.Tensor:
         """Panel-packed weights; re-packed only when a parameter changed (optimizer step / load_state_dict)."""
+        self._need_plan("packed()")
         key = self._key()
         if self._packed is None or key != self._packed_key:
             ws, _ = self._weights()
@@ -187,6 +217,7 @@ class HipNet:
     def fold(self, exp_code: torch.Tensor, shape_code: torch.Tensor, tex_code: torch.Tensor) -> torch.Tensor:
         """Per-call folded biases from the (already modulated) expression code [ch_exp], shape code [ch_shape] and
         texture code [ch_tex]."""
+        self._need_plan("fold()")
         ws, bs = self._weights()
         n = self._L.mofa_net_folded_floats(self.shape)
         if self._folded is None or self._folded.device != ws[0].device:

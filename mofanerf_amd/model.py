@@ -99,9 +99,9 @@ class NeRF(nn.Module):
             raise lib.MofaError("NeRF.forward needs its parameters and inputs on the GPU (net.cuda()); there is no CPU path")
         h = _EMBEDDED_CACHE.get(self)        # device-side cache kept OUTSIDE the module: deepcopy / pickling of the module stay plain
         if h is None:
-            # point_freqs=0: on embedded inputs EVERY column of input_ch is a per-point column, so where the encoding ends and the
-            # expression code begins is irrelevant here (the layer shapes are the same for any split)
-            h = _EMBEDDED_CACHE[self] = HipNet(self, point_freqs=0, weak=True)      # weak back-reference: the entry dies with the module
+            # embedded=True: on embedded inputs EVERY column of input_ch / input_ch_views is a per-point column — any widths, like the
+            # reference's module; only the Linear shapes are checked
+            h = _EMBEDDED_CACHE[self] = HipNet(self, weak=True, embedded=True)      # weak back-reference: the entry dies with the module
         return h.forward_embedded(input_pts, input_bmCodes, input_views, input_uvCodes)
 
 

@@ -212,3 +212,28 @@ def test_renderer_refuses_code_widths_the_networks_were_not_built_for(golden):
             call(synth.codes(0)[1].to(DEV))                  # the shipped 256-wide texture code into a 128-wide network
     with pytest.raises(lib.MofaError, match="code widths"):
         call(synth.codes(0)[1].to(DEV).requires_grad_(True))
+
+
+@pytest.mark.parametrize("ch_in,ch_views,cs,ct,D,W", [(40, 10, 7, 33, 8, 64), (93, 27, 50, 256, 6, 128), (5, 3, 0, 16, 7, 64)])
+def test_embedded_forward_accepts_any_per_point_widths_like_the_reference_module(ch_in, ch_views, cs, ct, D, W):
+    """``NeRF.forward`` on already-embedded inputs (models/model.py:121-137) takes ANY ``input_ch`` / ``input_ch_views`` in the
+    reference — there they are plain Linear input widths.  The embedded path no longer inherits the renderer path's
+    ``input_ch >= 3 + 6 L`` / ``input_ch_views = 3 + 6 L`` rule; it checks the Linear shapes only and agrees with the oracle's
+    restatement of the module on random weights."""
+    from mofanerf_amd.model import NeRF
+    from oracle import mofa_oracle as orc
+    torch.manual_seed(ch_in + ch_views)
+    net = NeRF(D=D, W=W, input_ch=ch_in, input_ch_views=ch_views, input_ch_textureCodes=ct, input_ch_shapeCodes=cs, use_viewdirs=True).to(DEV)
+    n = 300
+    rng = np.random.default_rng(ch_in)
+    x, bm, v, tex = [T(rng.normal(0, 0.5, (n, c)).astype(np.float32)) for c in (ch_in, cs, ch_views, ct)]
+    with torch.no_grad():
+        raw = net(x.to(DEV), bm.to(DEV), v.to(DEV), tex.to(DEV))
+    st = {k: p.detach().cpu() for k, p in net.state_dict().items()}
+    ref = orc.nerf_forward(st, x, bm, v, tex)
+    nan_equal_close(raw.cpu().numpy(), ref.numpy(), 2e-5, 1e-5)
+    net2 = NeRF(D=D, W=W, input_ch=ch_in, input_ch_views=ch_views, input_ch_textureCodes=ct, input_ch_shapeCodes=cs, use_viewdirs=True).to(DEV)
+    net2.linear_view_xyBMuv[0] = torch.nn.Linear(ch_views + W + 1, W // 2).to(DEV)        # a module the constructor would not build: refused
+    with pytest.raises(lib.MofaError, match="refusing to pack"):
+        with torch.no_grad():
+            net2(x.to(DEV), bm.to(DEV), v.to(DEV), tex.to(DEV))

@@ -21,7 +21,7 @@ n_mfma = 2 * D + 5
 # per layer: its input panels once, its weights once, its output once (the per-layer launches' accounting, summed over the chain)
 act_out = (n_mfma - 1) * M * W * 4 + M * (W // 2) * 4
 act_in = M * 64 * 4 + (n_mfma - 1 + 2) * M * W * 4
-out = {"kernel": "mofa::k_net_chain",
+out = {"kernel": "mofa::k_net_chain<0>",
        "shape": f"fine network {W} x {D} ({n_mfma} MFMA layers) on M = {M} points (768 row tiles): {2 * mac * M / 1e12:.2f} TFLOP per launch",
        "csrc_sha256": build.csrc_digest(),
        "launches_averaged": 4,
