@@ -106,9 +106,47 @@ __device__ __forceinline__ void glds16_policy(const float* g, float* lds_wave_ba
 // exactly what a wavefront holds when lane l carries the 16-byte quad l of the block (the contiguous-store epilogues): word c =
 // ballot(component c > 0), so writing costs four v_cmp and one 32-byte store per KiB of activations, and reading is one 32-byte
 // wave-uniform load per KiB.  32x smaller than the fp32 tape, no recomputation.
+// The words leave through the first lanes WITHOUT a branch and without selects: `if (lane < 4) store` compiles to an exec-mask region
+// with a skip branch, which cuts the basic block — and with it the MFMA / epilogue interleave of the persistent kernel's merged tail —
+// at every KiB, and a select between wave-uniform ballots on a lane-varying condition comes back as branches too.  So: v_writelane puts
+// word c into lane c, and the exec mask is narrowed around the one store inside a single asm statement (saved and restored: correct
+// under any mask).
+template <int LN>
+__device__ __forceinline__ void mask_word_to_lane(int& lo, int& hi, unsigned long long w) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"((int)(unsigned)w), "n"(LN));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"((int)(unsigned)(w >> 32)), "n"(LN));
+}
+template <int LANES>
+__device__ __forceinline__ void mask_store_lanes(unsigned long long* dst, int lo, int hi) {
+    const unsigned long long word = (unsigned long long)(unsigned)lo | ((unsigned long long)(unsigned)hi << 32);
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %3\n\tglobal_store_dwordx2 %1, %2, off\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved)
+                 : "v"(dst), "v"(word), "n"((1 << LANES) - 1)
+                 : "memory", "scc");
+}
+template <int IT>
+__device__ __forceinline__ void mask_ballots(int& lo, int& hi, const f32x4 v) {
+    mask_word_to_lane<4 * IT + 0>(lo, hi, __ballot(v.x > 0.f));
+    mask_word_to_lane<4 * IT + 1>(lo, hi, __ballot(v.y > 0.f));
+    mask_word_to_lane<4 * IT + 2>(lo, hi, __ballot(v.z > 0.f));
+    mask_word_to_lane<4 * IT + 3>(lo, hi, __ballot(v.w > 0.f));
+}
 __device__ __forceinline__ void mask_store_block(unsigned long long* __restrict__ bits, long long off_block_floats, int lane, const f32x4 v) {
-    const unsigned long long b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);
-    if (lane < 4) bits[(off_block_floats >> 8) * 4 + lane] = lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : b3));
+    int lo = 0, hi = 0;
+    mask_ballots<0>(lo, hi, v);
+    mask_store_lanes<4>(bits + (off_block_floats >> 8) * 4 + (lane & 3), lo, hi);
+}
+// FOUR consecutive 1 KiB blocks (what one slice of the contiguous-store epilogues holds: v[it] = the lane's quad of block it): their 16
+// words are consecutive in the tape, so they leave as ONE 128-byte store from lanes 0..15
+__device__ __forceinline__ void mask_store_blocks4(unsigned long long* __restrict__ bits, long long off_first_block_floats, int lane,
+                                                   const f32x4 (&v)[4]) {
+    int lo = 0, hi = 0;
+    mask_ballots<0>(lo, hi, v[0]);
+    mask_ballots<1>(lo, hi, v[1]);
+    mask_ballots<2>(lo, hi, v[2]);
+    mask_ballots<3>(lo, hi, v[3]);
+    mask_store_lanes<16>(bits + (off_first_block_floats >> 8) * 4 + (lane & 15), lo, hi);
 }
 // the four (activation > 0) flags of the quad at float offset `off` (a multiple of 4), for any thread-to-quad mapping
 __device__ __forceinline__ void mask_load_quad(const unsigned long long* __restrict__ bits, long long off, bool (&keep)[4]) {
@@ -372,12 +410,13 @@ __device__ __forceinline__ void store_tile_staged(const f32x16 (&acc)[NI][NJ], c
                         if constexpr (RELU) v.x = relu_np(v.x), v.y = relu_np(v.y), v.z = relu_np(v.z), v.w = relu_np(v.w);
                         *(f32x4*)(win + (32 * jj + lr) * 16 + (((2 * qq + g) ^ msw) << 2)) = v;     // logical chunk 2 qq + g
                     }
+                f32x4 r[4];
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    const f32x4 v = *(const f32x4*)(win + it * 256 + lane * 4);
-                    *(f32x4*)(panel + jh * 1024 + it * 256 + lane * 4) = v;
-                    if constexpr (MASKW) mask_store_block(mask_out, (panel - y) + jh * 1024 + it * 256, lane, v);
+                    r[it] = *(const f32x4*)(win + it * 256 + lane * 4);
+                    *(f32x4*)(panel + jh * 1024 + it * 256 + lane * 4) = r[it];
                 }
+                if constexpr (MASKW) mask_store_blocks4(mask_out, (panel - y) + jh * 1024, lane, r);
             }
         }
 }

@@ -366,14 +366,15 @@ struct FusedEpi {
     float* win;                       // wave-private 1024-float window
     float* pass0;                     // wave 0 (when the next layer reads this output first): the two stages' X regions, where output
     float* pass1;                     //   slices 0 / 1 are formed — they ARE the next layer's operand panels 0 / 1; else nullptr
-};                                    // (no mask-tape output: a forward that keeps mask bits takes k_mlp_fused_generic<true>, launch_fused)
+    unsigned long long* mask_out;     // MASKW: this layer's bits in the mask-only tape
+};
 
 // EPI = true (the ordinary layers): the epilogue runs INSIDE the tail.  After the last panel's first half every wave has read its
 // last fragments, so one barrier frees both stages; the requests for the next layer's panel 1 and bias row go out, and the last 32
 // MFMAs are issued accumulator pair by accumulator pair (each accumulator still sees its k-updates in the same order: bit-identical)
 // with the bias + ReLU + staging + stores of the pair BEFORE in their shadow — a timing-only build without any epilogue says the
 // epilogue is worth 5.3 % of this kernel when it runs by itself after the loop (profiles/r04_ab_fused_epilogue.txt).
-template <int NI, int NJ, int BN, int NWR, int NXR, bool EPI = false, class Pre = int>
+template <int NI, int NJ, int BN, int NWR, int NXR, bool EPI = false, class Pre = int, bool MASKW = false>
 __device__ __forceinline__ void kloop_fused(const float* xb, const float* x2b, const float* wb, long long xstep, long long wstep, int k1p,
                                             int KT, float* smem, int tid, int wave, int lane, int xrow0, int wrow0,
                                             f32x16 (&acc)[NI][NJ], const float* nwb, const float* nxb, const FusedEpi* ep = nullptr,
@@ -549,6 +550,7 @@ __device__ __forceinline__ void kloop_fused(const float* xb, const float* x2b, c
                 for (int it = 0; it < 4; ++it) {
                     *(f32x4*)(panel + it * 256 + ro) = r[it];
                 }
+                if constexpr (MASKW) mask_store_blocks4(ep->mask_out, panel - ep->y, lane, r);
             }
         };
 #pragma unroll
@@ -609,16 +611,18 @@ __device__ __forceinline__ void store_tile_fused(const f32x16 (&acc)[NI][NJ], co
                         v.x = relu_np(v.x), v.y = relu_np(v.y), v.z = relu_np(v.z), v.w = relu_np(v.w);
                         *(f32x4*)(w + 32 * jj * 16 + (qq ? wo1 : wo0)) = v;
                     }
+                f32x4 r[4];
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
-                    const f32x4 v = *(const f32x4*)(w + it * 256 + ro);
-                    *(f32x4*)(panel + jh * 1024 + it * 256 + ro) = v;
-                    if constexpr (MASKW) mask_store_block(mask_out, (panel - y) + jh * 1024 + it * 256, lane, v);
+                    r[it] = *(const f32x4*)(w + it * 256 + ro);
+                    *(f32x4*)(panel + jh * 1024 + it * 256 + ro) = r[it];
                 }
+                if constexpr (MASKW) mask_store_blocks4(mask_out, (panel - y) + jh * 1024, lane, r);
             }
         }
 }
 
+template <bool MASKW>      // MASKW: also leave (y > 0) of every layer as bits (the fitting forward's mask-only tape)
 __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TM = 128, NI = 2, STAGE = kFsStage;
@@ -704,8 +708,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
                 __syncthreads();
             }
             prefetch(a.L[1], 1, true);
-            store_tile_fused<NI, 4, false, false>(acc, a.folded + l.bias_off, const_cast<float*>(a.arena) + l.y_off, a.m_padded, m0, wn * 64, lane, win,
-                                                  wn == 0 ? smem : nullptr, wn == 0 ? smem + STAGE : nullptr, nullptr);
+            store_tile_fused<NI, 4, false, MASKW>(acc, a.folded + l.bias_off, const_cast<float*>(a.arena) + l.y_off, a.m_padded, m0, wn * 64, lane, win,
+                                                  wn == 0 ? smem : nullptr, wn == 0 ? smem + STAGE : nullptr, MASKW ? a.mask_bits + l.mask_off : nullptr);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // layer 1's panels 0 / 1 (and this tile's first stores): once per tile
             __builtin_amdgcn_s_barrier();
         }
@@ -724,12 +728,13 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(const FusedArgs a) {
             // layer's operand panels 0 / 1 always come straight from this epilogue: wave 0 forms them in the stages' X regions
             const bool pass = wn == 0;
             const FusedEpi ep{smem + kFsBias + (li & 1) * 256 + wn * 64, const_cast<float*>(a.arena) + l.y_off, a.m_padded, m0, wn * 64, win,
-                              pass ? smem : nullptr, pass ? smem + STAGE : nullptr};
+                              pass ? smem : nullptr, pass ? smem + STAGE : nullptr, MASKW ? a.mask_bits + l.mask_off : nullptr};
             auto pre = [&]() { prefetch(nx, li + 1, false); };
             // ONE instantiation for every ordinary layer (three would meet in register copies of the 128 accumulators): the tail always
             // requests four 1 KiB rounds of the next layer's weight panel 0 — for the 128-row view layer the upper two land in rows the
             // view layer never reads (they are its panel 1, valid memory)
-            kloop_fused<NI, 4, 256, 4, 0, true>(xb, x2b, wb, a.m_padded * 16, 256 * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc, nwb, nullptr, &ep, pre);
+            kloop_fused<NI, 4, 256, 4, 0, true, decltype(pre), MASKW>(xb, x2b, wb, a.m_padded * 16, 256 * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc, nwb,
+                                                                      nullptr, &ep, pre);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // my LDS writes (the handed-over panels) are done; the stores drain
             __builtin_amdgcn_s_barrier();                                 // behind the next loop's first half panel (its vmcnt(0) + barrier)
         }
@@ -763,22 +768,27 @@ bool fused_fast_shape(const FusedArgs& a) {
     return v.x1_off >= 0 && v.n_padded == 128 && v.k1p == 16 && v.k2p == 0 && v.bias_row_div != 0 && v.x1_off == a.L[a.n_layers - 2].y_off;
 }
 std::atomic<int> g_fused_attr[kMaxDevices];
+int set_fused_attributes(int lds) {
+    if (hipFuncSetAttribute((const void*)k_mlp_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_mlp_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return check_launch("hipFuncSetAttribute(k_mlp_fused)");
+    return MOFA_OK;
+}
 
 int launch_fused(const FusedArgs& a, hipStream_t st) {
     const int dev = current_device();
     const int cus = compute_units(dev);
     const int half_tiles = a.m_tiles * 2;
     const int grid = half_tiles < 2 * cus ? half_tiles : 2 * cus;      // two resident workgroups per CU
-    // (a fitting forward — mask-only tape — takes the generic kernel: its four ballots per KiB of output do not fit the register file
-    //  next to the pipelined kernel's fragments without spilling, and it runs 1,024 rays, not frames)
-    if (fused_fast_shape(a) && !a.mask_bits) {                         // (k_mlp_fused writes no mask bits: the condition above is its guard)
+    if (fused_fast_shape(a)) {
         const size_t lds = (size_t)kFsFloats * sizeof(float);          // 66 KiB: above the 64 KiB default limit of dynamic LDS
         if (!g_fused_attr[dev].load(std::memory_order_acquire)) {      // one-time function attribute per device
-            if (hipFuncSetAttribute((const void*)k_mlp_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return check_launch("hipFuncSetAttribute(k_mlp_fused)");
+            const int rc = set_fused_attributes((int)lds);
+            if (rc != MOFA_OK) return rc;
             g_fused_attr[dev].store(1, std::memory_order_release);
         }
-        hipLaunchKernelGGL(k_mlp_fused, dim3(grid), dim3(256), lds, st, a);
+        if (a.mask_bits) hipLaunchKernelGGL(k_mlp_fused<true>, dim3(grid), dim3(256), lds, st, a);      // the fitting forward: + mask bits
+        else hipLaunchKernelGGL(k_mlp_fused<false>, dim3(grid), dim3(256), lds, st, a);
         return check_launch("k_mlp_fused");
     }
     const size_t lds = 2 * (size_t)(128 + 256) * 16 * sizeof(float);   // 48 KiB
@@ -834,6 +844,8 @@ struct ChainArgs {
     long long m_padded, bias_rows;
     int m_tiles, n_steps, tiles_per_m;
     unsigned spin_limit;              // polls (each >= ~1 us with its s_sleep) before a wait gives up: seconds, never a hang
+    int gang_polls;                   // > 0: re-align the feature tiles that share a row tile's panels (see Probe::first_panel_landed)
+    int pad_;
     ChainStep S[kMaxChainSteps];
 };
 static_assert(sizeof(ChainArgs) <= 4096, "kernel arguments are limited to 4 KiB");
@@ -879,6 +891,9 @@ struct ChainPolicy : ShippedPolicy {
         unsigned* done;
         unsigned* status;
         int m_lo, m_cnt, total, tid;
+        unsigned* arrive = nullptr;   // gang re-alignment (a.gang_polls > 0): tiles STARTED per row tile, all steps
+        int gang_mt = 0;         // the current tile's row tile ...
+        unsigned gang_need = 0;  // ... and what arrive[gang_mt] reaches once every feature tile of this step over those rows has started
         int prev_mt = -1;        // row tile whose completion is still to be signalled
         bool first = false;      // the current tile's first panel has not been passed yet
         int s_next = 0;          // (thread 0) step pointer of the next tile
@@ -895,7 +910,21 @@ struct ChainPolicy : ShippedPolicy {
         }
         __device__ __forceinline__ void entry() {}
         __device__ __forceinline__ void kloop_begin() {}
-        __device__ __forceinline__ void first_panel_landed() {}
+        // Gang re-alignment (a measured option, a.gang_polls > 0).  The n_tiles feature tiles of (step, row tile) read the SAME activation
+        // panels; if they walk them together, seven of eight requests hit the XCD's L2.  Per-layer launches re-align all workgroups every
+        // 2.9 ms; in a 70 ms chained launch the sharers drift apart until the spread times the fetch rate exceeds the 4 MiB L2, and the
+        // panels come from the Infinity Cache again (L2 hit rate 0.54 vs 0.79, fabric traffic 3.2x vs 1.5x algorithmic).  So a tile waits
+        // here — its first two panels are already on their way — until all its siblings have STARTED too, but never long: the wait is a
+        // performance hint, not a dependency (bounded polls, then on regardless: no deadlock for any residency, no effect on results).
+        __device__ __forceinline__ void first_panel_landed() {
+            if (a.gang_polls <= 0) return;
+            if (tid == 0) {
+                int polls = 0;
+                while (__hip_atomic_load(arrive + gang_mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gang_need && ++polls < a.gang_polls)
+                    __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_s_barrier();
+        }
         __device__ __forceinline__ void kloop_end() {}
         __device__ __forceinline__ void stores_issued() {}
         __device__ __forceinline__ void panel() {
@@ -995,6 +1024,7 @@ __global__ __launch_bounds__(256, 2) void k_net_chain(const ChainArgs a) {
     unsigned* const status = a.state + kChainStatus;
     unsigned* const done = a.state + kChainDone;
     ChainPolicy::Probe hook(a, done, status, m_lo, m_cnt, total, tid);
+    hook.arrive = done + ((a.m_tiles + 31) & ~31);
 
     if (tid == 0) slot[0] = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), slot[1] = 0;
     __syncthreads();
@@ -1033,6 +1063,10 @@ __global__ __launch_bounds__(256, 2) void k_net_chain(const ChainArgs a) {
         }
         if (tid == 0) hook.qn = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the ticket after this one
         hook.first = true;
+        if (a.gang_polls > 0) {                          // "this tile has started" (its siblings look for it behind their first panel)
+            if (tid == 0) __hip_atomic_fetch_add(hook.arrive + mt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hook.gang_mt = mt, hook.gang_need = (unsigned)(st.tiles_before + st.n_tiles);
+        }
 
         const long long m0 = (long long)mt * BM;
         const int n0 = nt * BN;
@@ -1462,8 +1496,7 @@ int mofa_device_init(void* stream, int32_t* xcd_workgroups) {
     // the persistent 256-wide kernel's 66 KiB of dynamic LDS needs a function attribute once per device (launch_fused would set it on its
     // first launch otherwise: not a synchronisation, but it belongs here)
     if (dev == current_device() && !g_fused_attr[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)k_mlp_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kFsFloats * sizeof(float))) != hipSuccess)
-            return check_launch("hipFuncSetAttribute(k_mlp_fused)");
+        if (set_fused_attributes((int)((size_t)kFsFloats * sizeof(float))) != MOFA_OK) return MOFA_EHIP;
         g_fused_attr[dev].store(1, std::memory_order_release);
     }
     return MOFA_OK;
@@ -1477,7 +1510,9 @@ int mofa_internal_chain_capable(void* stream) {
 
 // internal (used by mofa_net.hip): the steps of one chained launch (k_net_chain).  `state`: at least
 // mofa_internal_chain_state_words(m_padded) unsigned words inside the caller's workspace.  *tiles_out = tiles the launch must finish.
-size_t mofa_internal_chain_state_words(long long m_padded) { return (size_t)kChainDone + (size_t)(m_padded / kRowTile) + 32; }
+size_t mofa_internal_chain_state_words(long long m_padded) {     // heads, status, done[m_tiles] (padded to 32), arrive[m_tiles]
+    return (size_t)kChainDone + 2 * (((size_t)(m_padded / kRowTile) + 31) & ~(size_t)31) + 32;
+}
 
 int mofa_internal_chain_launch(int mode, const mofa::ChainStep* steps, int n_steps, long long m_padded, long long bias_rows, unsigned* state,
                                long long* tiles_out, void* stream) {
@@ -1488,6 +1523,7 @@ int mofa_internal_chain_launch(int mode, const mofa::ChainStep* steps, int n_ste
     a.state = state;
     a.m_padded = m_padded, a.bias_rows = bias_rows, a.m_tiles = (int)(m_padded / kRowTile), a.n_steps = n_steps;
     a.spin_limit = config().chain_spin;
+    a.gang_polls = config().chain_gang;
     double flops = 0.0;
     int before = 0;
     for (int i = 0; i < n_steps; ++i) {

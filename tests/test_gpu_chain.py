@@ -89,12 +89,13 @@ def test_chained_forward_keeping_either_tape_is_bit_identical_to_per_layer_launc
 
 
 @pytest.mark.parametrize("explicit_points", [False, True])
-@pytest.mark.parametrize("D,W,R,S", [(10, 1024, 40, 128), (8, 512, 33, 64), (10, 1024, 2, 128), (6, 512, 50, 64)])
+@pytest.mark.parametrize("D,W,R,S", [(10, 1024, 40, 128), (8, 512, 33, 64), (10, 1024, 2, 128), (6, 512, 50, 64), (8, 256, 300, 64)])
 def test_chained_fitting_backward_is_bit_identical_to_per_layer_launches(D, W, R, S, explicit_points, knob):
     """The fitting backward (no weight gradients): its backward-data products as TWO chained launches (view layer + texture stack | shape
     stack + xyzEncode 3..1) with the bias-gradient sums deferred behind them — every gradient the call returns must equal the
     per-layer form's bit for bit, from the mask-only tape and from the fp32 tape, on rays and on explicit points (D = 6: the stacks'
-    second halves are one layer, the skip layer's gradient is itself a kept bias-gradient input)."""
+    second halves are one layer, the skip layer's gradient is itself a kept bias-gradient input; width 256: the coarse network's
+    backward chains as well)."""
     h, o, d, z, vd, folded, vb, G = _setup(D, W, R, S)
     pts = (o[:, None, :] + d[:, None, :] * z[:, :, None]).reshape(-1, 3).contiguous()
     runs = {}
@@ -114,7 +115,8 @@ def test_chained_fitting_backward_is_bit_identical_to_per_layer_launches(D, W, R
                 leaves = [og, dg, fo, vbg]
             (raw * G).sum().backward()
             torch.cuda.synchronize()
-            assert h.chained_launches() - before == (3 if chain == "1" else 0)          # 1 forward + 2 backward launches
+            # 1 forward + 2 backward launches (width 256: the forward is the persistent kernel / per-layer launches, only the backward chains)
+            assert h.chained_launches() - before == ((3 if W > 256 else 2) if chain == "1" else 0)
             h.check_verdict(block=True)
             runs[(chain, fp32)] = [raw.detach().clone()] + [t.grad.clone() for t in leaves]
         h.force_fp32_tape = False
@@ -374,6 +376,7 @@ def test_run_network_keeps_nothing_when_nothing_asks_for_a_gradient():
     assert torch.cuda.max_memory_allocated() - m0 < tape_bytes // 2       # no tape of either kind was allocated
     pts_g = pts.clone().requires_grad_(True)
     raw_g = kw["network_query_fn"](pts_g, vd, fine, weight_grads=False)
-    assert raw_g.grad_fn is not None and torch.equal(raw_g.detach(), ref)
+    # (the differentiable path folds the codes and the view encoding in torch — a few ulp from the HIP fold kernels: close, not bit-equal)
+    assert raw_g.grad_fn is not None and float((raw_g.detach() - ref).abs().max()) <= 2e-5 * (1.0 + float(ref.abs().max()))
     raw_g.sum().backward()
     assert torch.isfinite(pts_g.grad).all() and all(p.grad is None for p in fine.parameters())
