@@ -125,12 +125,17 @@ __device__ __forceinline__ void mask_store_lanes(unsigned long long* dst, int lo
                  : "v"(dst), "v"(word), "n"((1 << LANES) - 1)
                  : "memory", "scc");
 }
+// gfx90a+ hazard: a VALU that READS an SGPR needs two wait states after the VALU (here: v_cmp) that WROTE it.  hipcc inserts them for its
+// own instructions but not inside inline asm, so the four ballots are pinned in front of ONE `s_nop 1` (they pass through it as
+// operands) and the eight v_writelane read them behind it.
 template <int IT>
 __device__ __forceinline__ void mask_ballots(int& lo, int& hi, const f32x4 v) {
-    mask_word_to_lane<4 * IT + 0>(lo, hi, __ballot(v.x > 0.f));
-    mask_word_to_lane<4 * IT + 1>(lo, hi, __ballot(v.y > 0.f));
-    mask_word_to_lane<4 * IT + 2>(lo, hi, __ballot(v.z > 0.f));
-    mask_word_to_lane<4 * IT + 3>(lo, hi, __ballot(v.w > 0.f));
+    unsigned long long b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);
+    asm volatile("s_nop 1" : "+s"(b0), "+s"(b1), "+s"(b2), "+s"(b3));
+    mask_word_to_lane<4 * IT + 0>(lo, hi, b0);
+    mask_word_to_lane<4 * IT + 1>(lo, hi, b1);
+    mask_word_to_lane<4 * IT + 2>(lo, hi, b2);
+    mask_word_to_lane<4 * IT + 3>(lo, hi, b3);
 }
 __device__ __forceinline__ void mask_store_block(unsigned long long* __restrict__ bits, long long off_block_floats, int lane, const f32x4 v) {
     int lo = 0, hi = 0;
