@@ -878,6 +878,19 @@ __global__ __launch_bounds__(256) void k_chain_verify(const unsigned* __restrict
     for (long long i = t0; i < n3; i += stride) p3[i] = nan;
 }
 
+// Ticket r (0 <= r < m_cnt * n_tiles) of a step -> (row tile, feature tile).  halves = 0: the n_tiles feature tiles of a row tile are
+// adjacent tickets (they share the row tile's activation panels).  halves = 1 (a measured option, MOFA_CHAIN_NSPLIT=2; the launcher sets
+// it per step when n_tiles is even): the step is walked in two halves of the feature range — all row tiles over the first half of the
+// features, then all over the second — so that the workgroups in flight share HALF of the layer's weights (2 of the 4 MiB at width 1024:
+// it stays resident in the XCD's 4 MiB L2 next to the activation streams) at the price of fetching every activation panel twice.
+__device__ __forceinline__ void chain_tile(int r, int m_cnt, int n_tiles, int halves, int& mt_rel, int& nt) {
+    const int G = n_tiles >> halves, per = m_cnt * G;
+    const int grp = r >= per ? 1 : 0;          // (halves = 0: per = m_cnt * n_tiles > r, always group 0)
+    const int rr = r - grp * per;
+    mt_rel = rr / G;
+    nt = grp * G + (rr - mt_rel * G);
+}
+
 // What a workgroup of k_net_chain carries from tile to tile.  It rides into the K loop as the policy's `Probe` (the hook the loop calls
 // after every panel's wait + barrier), because two things belong BEHIND the next tile's first panel rather than between two tiles:
 //   * the completion signal of the tile just finished — the loop's first `s_waitcnt vmcnt(0)` + barrier is the point where every
@@ -935,7 +948,9 @@ struct ChainPolicy : ShippedPolicy {
                 while (qn >= m_cnt * (a.S[s_next].tiles_before + a.S[s_next].n_tiles)) ++s_next;
                 const int r = qn - m_cnt * a.S[s_next].tiles_before;
                 need = (unsigned)a.S[s_next].tiles_before;
-                seen = __hip_atomic_load(done + m_lo + r / a.S[s_next].n_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int mr, nr;
+                chain_tile(r, m_cnt, a.S[s_next].n_tiles, (a.S[s_next].flags >> 1) & 1, mr, nr);
+                seen = __hip_atomic_load(done + m_lo + mr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     };
@@ -1034,7 +1049,9 @@ __global__ __launch_bounds__(256, 2) void k_net_chain(const ChainArgs a) {
         while (q >= m_cnt * (a.S[s].tiles_before + a.S[s].n_tiles)) ++s;          // tile numbers only grow: the step pointer only advances
         const ChainStep& st = a.S[s];
         const int r = q - m_cnt * st.tiles_before;
-        const int mt = m_lo + r / st.n_tiles, nt = r - (r / st.n_tiles) * st.n_tiles;
+        int mt, nt;
+        chain_tile(r, m_cnt, st.n_tiles, (st.flags >> 1) & 1, mt, nt);
+        mt += m_lo;
         if (!ready) {
             // the early look did not find this tile's inputs complete (or there was none: the first tile).  The previous tile's signal
             // must go out BEFORE waiting — this tile may depend on it — so its stores are waited for here instead of behind the first panel
@@ -1537,6 +1554,7 @@ int mofa_internal_chain_launch(int mode, const mofa::ChainStep* steps, int n_ste
         MOFA_REQUIRE(mode != kChainForwardMask || s.bits || s.bias_row_div, "chain_launch: step %d has no place for its mask bits", i);
         MOFA_REQUIRE(mode != kChainBackward || !(s.aux && s.bits), "chain_launch: step %d has both an fp32 mask and mask bits", i);
         s.n_tiles = s.n_padded / 128, s.tiles_before = before;
+        s.flags = (s.flags & 1) | ((config().chain_nsplit == 2 && s.n_tiles % 2 == 0) ? 2 : 0);      // bit 1: queue order in feature halves
         a.S[i] = s;
         before += s.n_tiles;
         flops += 2.0 * (double)m_padded * (double)s.n_padded * 16.0 * (double)kt;
