@@ -55,8 +55,6 @@ struct Config {
     int pipe = -1;        // MOFA_PIPE=0: the plain K loops (layer kernel, persistent kernel, weight gradient) instead of the pipelined ones
     int chain = -1;       // MOFA_CHAIN=0: per-layer launches for the wide networks instead of the chained launch (k_net_chain)
     unsigned chain_spin = 1u << 22;   // MOFA_CHAIN_SPIN_LIMIT (tests only): polls before a dependency wait of k_net_chain gives up
-    int chain_gang = 0;               // MOFA_CHAIN_GANG=n: k_net_chain re-aligns the feature tiles sharing a row tile (at most n polls; 0 = off)
-    int chain_nsplit = 1;             // MOFA_CHAIN_NSPLIT=2: k_net_chain's queue walks a layer's feature range in two halves (1 = whole: shipped)
 };
 const Config& config();
 
@@ -75,7 +73,7 @@ struct ChainStep {
     unsigned long long* bits;   // forward with a mask tape: where (y > 0) goes as bits (NULL: none); backward: the mask bits (NULL: none)
     int k1p, k2p, n_padded, n_tiles;
     int bias_row_div;           // forward: 0, or points per bias row (the view layer's per-ray rows)
-    int flags;                  // forward: bit 0 = ReLU; backward: bit 0 = accumulate into y; bit 1 (set by the launcher): queue order in feature halves
+    int flags;                  // forward: bit 0 = ReLU; backward: bit 0 = accumulate into y
     int tiles_before;           // filled by the launcher: tiles of the earlier steps over one row tile
     int pad_;
 };

@@ -844,8 +844,6 @@ struct ChainArgs {
     long long m_padded, bias_rows;
     int m_tiles, n_steps, tiles_per_m;
     unsigned spin_limit;              // polls (each >= ~1 us with its s_sleep) before a wait gives up: seconds, never a hang
-    int gang_polls;                   // > 0: re-align the feature tiles that share a row tile's panels (see Probe::first_panel_landed)
-    int pad_;
     ChainStep S[kMaxChainSteps];
 };
 static_assert(sizeof(ChainArgs) <= 4096, "kernel arguments are limited to 4 KiB");
@@ -878,19 +876,6 @@ __global__ __launch_bounds__(256) void k_chain_verify(const unsigned* __restrict
     for (long long i = t0; i < n3; i += stride) p3[i] = nan;
 }
 
-// Ticket r (0 <= r < m_cnt * n_tiles) of a step -> (row tile, feature tile).  halves = 0: the n_tiles feature tiles of a row tile are
-// adjacent tickets (they share the row tile's activation panels).  halves = 1 (a measured option, MOFA_CHAIN_NSPLIT=2; the launcher sets
-// it per step when n_tiles is even): the step is walked in two halves of the feature range — all row tiles over the first half of the
-// features, then all over the second — so that the workgroups in flight share HALF of the layer's weights (2 of the 4 MiB at width 1024:
-// it stays resident in the XCD's 4 MiB L2 next to the activation streams) at the price of fetching every activation panel twice.
-__device__ __forceinline__ void chain_tile(int r, int m_cnt, int n_tiles, int halves, int& mt_rel, int& nt) {
-    const int G = n_tiles >> halves, per = m_cnt * G;
-    const int grp = r >= per ? 1 : 0;          // (halves = 0: per = m_cnt * n_tiles > r, always group 0)
-    const int rr = r - grp * per;
-    mt_rel = rr / G;
-    nt = grp * G + (rr - mt_rel * G);
-}
-
 // What a workgroup of k_net_chain carries from tile to tile.  It rides into the K loop as the policy's `Probe` (the hook the loop calls
 // after every panel's wait + barrier), because two things belong BEHIND the next tile's first panel rather than between two tiles:
 //   * the completion signal of the tile just finished — the loop's first `s_waitcnt vmcnt(0)` + barrier is the point where every
@@ -904,9 +889,6 @@ struct ChainPolicy : ShippedPolicy {
         unsigned* done;
         unsigned* status;
         int m_lo, m_cnt, total, tid;
-        unsigned* arrive = nullptr;   // gang re-alignment (a.gang_polls > 0): tiles STARTED per row tile, all steps
-        int gang_mt = 0;         // the current tile's row tile ...
-        unsigned gang_need = 0;  // ... and what arrive[gang_mt] reaches once every feature tile of this step over those rows has started
         int prev_mt = -1;        // row tile whose completion is still to be signalled
         bool first = false;      // the current tile's first panel has not been passed yet
         int s_next = 0;          // (thread 0) step pointer of the next tile
@@ -923,21 +905,7 @@ struct ChainPolicy : ShippedPolicy {
         }
         __device__ __forceinline__ void entry() {}
         __device__ __forceinline__ void kloop_begin() {}
-        // Gang re-alignment (a measured option, a.gang_polls > 0).  The n_tiles feature tiles of (step, row tile) read the SAME activation
-        // panels; if they walk them together, seven of eight requests hit the XCD's L2.  Per-layer launches re-align all workgroups every
-        // 2.9 ms; in a 70 ms chained launch the sharers drift apart until the spread times the fetch rate exceeds the 4 MiB L2, and the
-        // panels come from the Infinity Cache again (L2 hit rate 0.54 vs 0.79, fabric traffic 3.2x vs 1.5x algorithmic).  So a tile waits
-        // here — its first two panels are already on their way — until all its siblings have STARTED too, but never long: the wait is a
-        // performance hint, not a dependency (bounded polls, then on regardless: no deadlock for any residency, no effect on results).
-        __device__ __forceinline__ void first_panel_landed() {
-            if (a.gang_polls <= 0) return;
-            if (tid == 0) {
-                int polls = 0;
-                while (__hip_atomic_load(arrive + gang_mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gang_need && ++polls < a.gang_polls)
-                    __builtin_amdgcn_s_sleep(2);
-            }
-            __builtin_amdgcn_s_barrier();
-        }
+        __device__ __forceinline__ void first_panel_landed() {}
         __device__ __forceinline__ void kloop_end() {}
         __device__ __forceinline__ void stores_issued() {}
         __device__ __forceinline__ void panel() {
@@ -948,9 +916,7 @@ struct ChainPolicy : ShippedPolicy {
                 while (qn >= m_cnt * (a.S[s_next].tiles_before + a.S[s_next].n_tiles)) ++s_next;
                 const int r = qn - m_cnt * a.S[s_next].tiles_before;
                 need = (unsigned)a.S[s_next].tiles_before;
-                int mr, nr;
-                chain_tile(r, m_cnt, a.S[s_next].n_tiles, (a.S[s_next].flags >> 1) & 1, mr, nr);
-                seen = __hip_atomic_load(done + m_lo + mr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                seen = __hip_atomic_load(done + m_lo + r / a.S[s_next].n_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     };
@@ -1039,7 +1005,6 @@ __global__ __launch_bounds__(256, 2) void k_net_chain(const ChainArgs a) {
     unsigned* const status = a.state + kChainStatus;
     unsigned* const done = a.state + kChainDone;
     ChainPolicy::Probe hook(a, done, status, m_lo, m_cnt, total, tid);
-    hook.arrive = done + ((a.m_tiles + 31) & ~31);
 
     if (tid == 0) slot[0] = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), slot[1] = 0;
     __syncthreads();
@@ -1049,9 +1014,7 @@ __global__ __launch_bounds__(256, 2) void k_net_chain(const ChainArgs a) {
         while (q >= m_cnt * (a.S[s].tiles_before + a.S[s].n_tiles)) ++s;          // tile numbers only grow: the step pointer only advances
         const ChainStep& st = a.S[s];
         const int r = q - m_cnt * st.tiles_before;
-        int mt, nt;
-        chain_tile(r, m_cnt, st.n_tiles, (st.flags >> 1) & 1, mt, nt);
-        mt += m_lo;
+        const int mt = m_lo + r / st.n_tiles, nt = r - (r / st.n_tiles) * st.n_tiles;
         if (!ready) {
             // the early look did not find this tile's inputs complete (or there was none: the first tile).  The previous tile's signal
             // must go out BEFORE waiting — this tile may depend on it — so its stores are waited for here instead of behind the first panel
@@ -1080,10 +1043,6 @@ __global__ __launch_bounds__(256, 2) void k_net_chain(const ChainArgs a) {
         }
         if (tid == 0) hook.qn = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the ticket after this one
         hook.first = true;
-        if (a.gang_polls > 0) {                          // "this tile has started" (its siblings look for it behind their first panel)
-            if (tid == 0) __hip_atomic_fetch_add(hook.arrive + mt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            hook.gang_mt = mt, hook.gang_need = (unsigned)(st.tiles_before + st.n_tiles);
-        }
 
         const long long m0 = (long long)mt * BM;
         const int n0 = nt * BN;
@@ -1527,9 +1486,7 @@ int mofa_internal_chain_capable(void* stream) {
 
 // internal (used by mofa_net.hip): the steps of one chained launch (k_net_chain).  `state`: at least
 // mofa_internal_chain_state_words(m_padded) unsigned words inside the caller's workspace.  *tiles_out = tiles the launch must finish.
-size_t mofa_internal_chain_state_words(long long m_padded) {     // heads, status, done[m_tiles] (padded to 32), arrive[m_tiles]
-    return (size_t)kChainDone + 2 * (((size_t)(m_padded / kRowTile) + 31) & ~(size_t)31) + 32;
-}
+size_t mofa_internal_chain_state_words(long long m_padded) { return (size_t)kChainDone + (size_t)(m_padded / kRowTile) + 32; }
 
 int mofa_internal_chain_launch(int mode, const mofa::ChainStep* steps, int n_steps, long long m_padded, long long bias_rows, unsigned* state,
                                long long* tiles_out, void* stream) {
@@ -1540,7 +1497,6 @@ int mofa_internal_chain_launch(int mode, const mofa::ChainStep* steps, int n_ste
     a.state = state;
     a.m_padded = m_padded, a.bias_rows = bias_rows, a.m_tiles = (int)(m_padded / kRowTile), a.n_steps = n_steps;
     a.spin_limit = config().chain_spin;
-    a.gang_polls = config().chain_gang;
     double flops = 0.0;
     int before = 0;
     for (int i = 0; i < n_steps; ++i) {
@@ -1554,7 +1510,6 @@ int mofa_internal_chain_launch(int mode, const mofa::ChainStep* steps, int n_ste
         MOFA_REQUIRE(mode != kChainForwardMask || s.bits || s.bias_row_div, "chain_launch: step %d has no place for its mask bits", i);
         MOFA_REQUIRE(mode != kChainBackward || !(s.aux && s.bits), "chain_launch: step %d has both an fp32 mask and mask bits", i);
         s.n_tiles = s.n_padded / 128, s.tiles_before = before;
-        s.flags = (s.flags & 1) | ((config().chain_nsplit == 2 && s.n_tiles % 2 == 0) ? 2 : 0);      // bit 1: queue order in feature halves
         a.S[i] = s;
         before += s.n_tiles;
         flops += 2.0 * (double)m_padded * (double)s.n_padded * 16.0 * (double)kt;

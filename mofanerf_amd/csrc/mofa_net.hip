@@ -57,14 +57,6 @@ Config read_env() {
         const long v = strtol(e, nullptr, 10);
         if (v > 0) c.chain_spin = (unsigned)v;
     }
-    if (const char* e = getenv("MOFA_CHAIN_NSPLIT")) {           // a measured option of k_net_chain's queue order (bit-identical either way)
-        const long v = strtol(e, nullptr, 10);
-        c.chain_nsplit = v == 2 ? 2 : 1;
-    }
-    if (const char* e = getenv("MOFA_CHAIN_GANG")) {             // a measured option of k_net_chain (bit-identical either way)
-        const long v = strtol(e, nullptr, 10);
-        c.chain_gang = v > 0 ? (int)(v < 4096 ? v : 4096) : 0;
-    }
     return c;
 }
 // two slots + an atomic index: readers never see a half-written snapshot, reload is rare and host-side only

@@ -53,9 +53,8 @@ def test_plan_sizes_and_argument_validation():
         want = Wp * 64 + n_plain * Wp * Wp + 2 * Wp * Wp + 2 * Wp * 2 * Wp + Hp * Wp + Wp + 3 * Hp
         assert want <= L.mofa_net_packed_floats(s) <= want + 64 * (2 * D + 7)
         assert L.mofa_net_folded_floats(s) == (2 * D + 4) * Wp + 8
-        # four activation buffers, the per-ray bias rows, and k_net_chain's queue state (8 heads x 32 words, 32 status words, two counters per
-        # row tile — finished / started — each array padded to 32 words, 32 spare)
-        assert L.mofa_net_workspace_floats(s, 1000, 10) == 4 * 1024 * Wp + 10 * Hp + 64 + (8 * 32 + 32 + 2 * 32 + 32)
+        # four activation buffers, the per-ray bias rows, and k_net_chain's queue state (8 heads x 32 words, 32 status words, a counter per row tile, 32 spare)
+        assert L.mofa_net_workspace_floats(s, 1000, 10) == 4 * 1024 * Wp + 10 * Hp + 64 + (8 * 32 + 32 + 1024 // 256 + 32)
         assert L.mofa_net_mask_tape_words(s, 1000) * 64 == L.mofa_net_tape_floats(s, 1000)      # one bit per tape float
     assert L.mofa_net_num_layers(lib.NetShape(3, 256)) == -1
     assert L.mofa_net_num_layers(lib.NetShape(8, 256, pe_point_freqs=17)) == -1
