@@ -21,7 +21,7 @@ bash tools/gpu_profile_chain.sh $tag > /dev/null 2>&1
 python tools/make_traffic_chain_json.py gpurun_out/$tag gpurun_out/$tag/hbm_traffic_chain.json > /dev/null 2> gpurun_out/$tag/hbm_traffic_chain.err
 python tools/kernel_resources.py mofanerf_amd/libmofanerf_hip.so gpurun_out/$tag/kernel_resources.md > /dev/null
 quick="--steps 3 --warmup 1 --cpu-rays 0 --variant-steps 0 --fit-steps 0 --train-steps 0 --parity-rays 0"
-for c in 1 0 1 0; do
+[ "${SKIP_CLOCKS:-0}" = 1 ] || for c in 1 0 1 0; do
   MOFA_CHAIN=$c bash tools/clock_probe.sh gpurun_out/$tag/clocks_chain${c}_$RANDOM.txt python bench.py $quick > gpurun_out/$tag/bench_clock_chain${c}_$RANDOM.json 2> /dev/null
 done
 ls -la gpurun_out/$tag | head -40
