@@ -1452,9 +1452,9 @@ int mofa_device_init(void* stream, int32_t* xcd_workgroups) {
     unsigned host[8] = {};
     hipError_t e = hipMalloc((void**)&counts, sizeof(host));
     if (e == hipSuccess) e = hipMemsetAsync(counts, 0, sizeof(host), st);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_xcc_census, dim3(2 * compute_units(dev)), dim3(64), 0, st, counts);
-        e = hipGetLastError();
+    if (e == hipSuccess) {      // (hipLaunchKernel reports THIS launch's status; an earlier call's pending error is not consumed here)
+        void* args[] = {(void*)&counts};
+        e = hipLaunchKernel((const void*)k_xcc_census, dim3(2 * compute_units(dev)), dim3(64), args, 0, st);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(host, counts, sizeof(host), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);

@@ -295,7 +295,7 @@ size_t mofa_net_backward_workspace_floats(MofaNetShape s, int64_t n_points) {
     const size_t mp = (size_t)round_up(n_points, kRowTile);
     return mp * (4 * (size_t)p.Wp + (size_t)p.pe_k) + 64 +
            mofa_weight_grad_workspace_floats(n_points, p.Wp, p.Wp) + 64 +  // split-M partials of the largest dW block
-           3 * mp * (size_t)p.Wp + 2 * mofa_internal_chain_state_words((long long)mp) + 64;   // the chained fitting backward: three more gradient
+           3 * mp * (size_t)p.Wp + 2 * (size_t)round_up((int64_t)mofa_internal_chain_state_words((long long)mp), 32) + 64;   // the chained fitting backward: three more gradient
                                                                                               // buffers (the bias-gradient inputs it keeps) + queue state of its two launches
 }
 
@@ -521,9 +521,9 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
     float* dpe = workspace + 4 * act;  // [Mp, pe_k]
     float* wws = dpe + (size_t)Mp * p.pe_k + 64;  // split-M partial sums of the weight-gradient GEMM
     float* extra = wws + mofa_weight_grad_workspace_floats(M, p.Wp, p.Wp) + 64;   // three more gradient buffers (chained form only)
-    unsigned* cstate[2];
-    cstate[0] = (unsigned*)(extra + 3 * act);
-    cstate[1] = cstate[0] + mofa_internal_chain_state_words((long long)Mp);
+    unsigned* cstate[2];        // queue state of the two chained launches, each on a 128-byte boundary of the workspace (the queue heads own a line each)
+    cstate[0] = (unsigned*)(workspace + round_up((extra + 3 * act) - workspace, 32));
+    cstate[1] = cstate[0] + round_up((int64_t)mofa_internal_chain_state_words((long long)Mp), 32);
     // (output > 0) of layer li: the saved fp32 activation itself, or its bits in the mask-only tape — never both
     struct Mask {
         const float* act;
