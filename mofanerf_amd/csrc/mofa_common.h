@@ -55,6 +55,7 @@ struct Config {
     int pipe = -1;        // MOFA_PIPE=0: the plain K loops (layer kernel, persistent kernel, weight gradient) instead of the pipelined ones
     int chain = -1;       // MOFA_CHAIN=0: per-layer launches for the wide networks instead of the chained launch (k_net_chain)
     unsigned chain_spin = 1u << 22;   // MOFA_CHAIN_SPIN_LIMIT (tests only): polls before a dependency wait of k_net_chain gives up
+    int chain_skip_xcd = -1;          // MOFA_CHAIN_TEST_SKIP_XCD (tests only): k_net_chain's workgroups on this XCD leave at once (an unworked queue)
 };
 const Config& config();
 

@@ -844,6 +844,8 @@ struct ChainArgs {
     long long m_padded, bias_rows;
     int m_tiles, n_steps, tiles_per_m;
     unsigned spin_limit;              // polls (each >= ~1 us with its s_sleep) before a wait gives up: seconds, never a hang
+    int skip_xcd;                     // tests only (MOFA_CHAIN_TEST_SKIP_XCD): workgroups on this XCD leave at once — what a CU-masked stream
+                                      // that starves an XCD looks like; -1 = none
     ChainStep S[kMaxChainSteps];
 };
 static_assert(sizeof(ChainArgs) <= 4096, "kernel arguments are limited to 4 KiB");
@@ -997,6 +999,7 @@ __global__ __launch_bounds__(256, 2) void k_net_chain(const ChainArgs a) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7u;
+    if ((int)xcc == a.skip_xcd) return;
     const int mpx = (a.m_tiles + 7) >> 3;
     const int m_lo = (int)xcc * mpx;
     const int m_cnt = m_lo < a.m_tiles ? (a.m_tiles - m_lo < mpx ? a.m_tiles - m_lo : mpx) : 0;
@@ -1497,6 +1500,7 @@ int mofa_internal_chain_launch(int mode, const mofa::ChainStep* steps, int n_ste
     a.state = state;
     a.m_padded = m_padded, a.bias_rows = bias_rows, a.m_tiles = (int)(m_padded / kRowTile), a.n_steps = n_steps;
     a.spin_limit = config().chain_spin;
+    a.skip_xcd = config().chain_skip_xcd;
     double flops = 0.0;
     int before = 0;
     for (int i = 0; i < n_steps; ++i) {

@@ -57,6 +57,10 @@ Config read_env() {
         const long v = strtol(e, nullptr, 10);
         if (v > 0) c.chain_spin = (unsigned)v;
     }
+    if (const char* e = getenv("MOFA_CHAIN_TEST_SKIP_XCD")) {    // tests only: leave one XCD's tile queue unworked
+        const long v = strtol(e, nullptr, 10);
+        c.chain_skip_xcd = (e[0] && v >= 0 && v < 8) ? (int)v : -1;
+    }
     return c;
 }
 // two slots + an atomic index: readers never see a half-written snapshot, reload is rare and host-side only

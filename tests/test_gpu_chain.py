@@ -191,6 +191,42 @@ def test_a_dependency_wait_out_of_budget_is_loud_not_wrong(knob):
     assert torch.equal(again, ref)
 
 
+@pytest.mark.parametrize("xcd", [0, 5])
+def test_an_unworked_xcd_queue_is_loud_not_wrong(xcd, knob):
+    """ADVICE r4 medium, made deterministic: an XCD that receives no workgroups (a CU-masked stream, a partition change after the census)
+    leaves its row tiles unwritten while every other XCD finishes normally — nobody waits across XCDs, so nothing times out.  With the
+    workgroups of one XCD sent home at once (MOFA_CHAIN_TEST_SKIP_XCD) the launch must END, raw must be NaN (not the stale workspace
+    contents the heads would otherwise read) and the verdict must say "tiles missing" without a time-out; the fitting backward too."""
+    h, o, d, z, vd, folded, vb, G = _setup(10, 1024, 40, 128)
+    R, S = 40, 128
+    ref = torch.zeros(R, S, 4, device=DEV)
+    h.forward_rays(o, d, z, S, vd, S, ref, folded)
+    torch.cuda.synchronize()
+    h.check_verdict(block=True)
+    knob("MOFA_CHAIN_TEST_SKIP_XCD", str(xcd))
+    out = torch.zeros(R, S, 4, device=DEV)
+    h.forward_rays(o, d, z, S, vd, S, out, folded)
+    torch.cuda.synchronize()
+    assert torch.isnan(out).all()
+    with pytest.raises(lib.MofaError, match="tiles missing") as ei:
+        h.check_verdict(block=True)
+    assert "timed out" not in str(ei.value)
+    og, dg = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    fo, vbg = folded.clone().requires_grad_(True), vb.clone().requires_grad_(True)
+    raw = NetFn.apply(h, og, dg, z, S, S, fo, vbg, None)
+    (torch.nan_to_num(raw) * G).sum().backward()
+    torch.cuda.synchronize()
+    assert all(torch.isnan(t.grad).all() for t in (og, dg, fo, vbg))
+    with pytest.raises(lib.MofaError, match="tiles missing"):
+        h.check_verdict(block=True)
+    knob("MOFA_CHAIN_TEST_SKIP_XCD", "-1")
+    again = torch.zeros(R, S, 4, device=DEV)
+    h.forward_rays(o, d, z, S, vd, S, again, folded)
+    torch.cuda.synchronize()
+    h.check_verdict(block=True)
+    assert torch.equal(again, ref)
+
+
 def test_renderer_surfaces_an_incomplete_launch(knob, tmp_path):
     """End to end: a frame whose chained launch ended incomplete is NaN, `check_launches()` raises, and `render_path` refuses to
     turn it into a PNG."""
