@@ -171,3 +171,44 @@ def test_hot_kernels_fit_their_occupancy_without_scratch():
     for k, r in rs.items():                                        # the ray-side kernels run many rays per CU: keep them light
         if k.startswith(("mofa::k_composite", "mofa::k_sample_pdf_merge", "mofa::k_get_rays")):
             assert r["vgpr"] <= 128 and r["scratch"] == 0, (k, r)
+
+
+def test_inline_asm_writelanes_keep_the_valu_sgpr_wait_states(tmp_path):
+    """ISA-level guard for a hazard hipcc does not cover inside inline asm (round 5: 26 GPU tests failed on it).  On gfx90a+ a VALU that
+    READS an SGPR needs two wait states after the VALU that WROTE it; the mask-tape writers move `v_cmp` ballots into lanes with
+    `v_writelane_b32` from inline asm (mofa_layer.h, mask_ballots), so the wait states are ours to provide (`s_nop 1` with the ballots as
+    operands).  Compile the product's network TU to assembly (no GPU needed) and check every v_writelane that takes an SGPR: none of the two
+    instruction slots before it may be a v_cmp writing that SGPR."""
+    import re
+    import subprocess
+    asm = tmp_path / "mlp.s"
+    subprocess.run([build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fvisibility=hidden", "-S", "--cuda-device-only",
+                    "-o", str(asm), os.path.join(build.CSRC, "mofa_mlp.hip")], check=True, capture_output=True)
+    lines = [l.strip() for l in asm.read_text().split("\n")]
+    lines = [l for l in lines if l and not l.startswith((";", ".")) and not l.endswith(":")]
+
+    def covers(dst, src):          # does the v_cmp destination `dst` ("vcc", "s[10:11]") contain the 32-bit register `src` ("vcc_lo", "s11")?
+        if dst.startswith("vcc"):
+            return src.startswith("vcc")
+        m = re.match(r"s\[(\d+):(\d+)\]", dst)
+        return bool(m) and src.startswith("s") and src[1:].isdigit() and int(m.group(1)) <= int(src[1:]) <= int(m.group(2))
+
+    total = hazards = 0
+    for i, l in enumerate(lines):
+        m = re.match(r"v_writelane_b32 v\d+, (s\d+|vcc_lo|vcc_hi), \d+", l)
+        if not m:
+            continue
+        total += 1
+        ws, j = 0, i - 1
+        while j >= 0 and ws < 2:
+            p = lines[j]
+            if p.startswith("s_nop"):
+                ws += int(p.split()[1]) + 1
+            else:
+                if p.startswith("v_cmp") and covers(p.split()[1].rstrip(","), m.group(1)):
+                    hazards += 1
+                    break
+                ws += 1
+            j -= 1
+    assert total >= 64, total            # the mask writers are there (16 ballots x 2 halves per 4 KiB slice, several instantiations)
+    assert hazards == 0, hazards
