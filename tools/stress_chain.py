@@ -11,6 +11,7 @@ Arms (shipped fine network 1024 x 10 unless stated):
   * forward writing the mask tape + the fitting backward's two chained launches (a 1,024-ray fitting step's fine pass), gradients
     compared with the per-layer form's
   * forward keeping the fp32 tape (training forward)
+  * the coarse 256 x 8 network's fitting pass: the pipelined persistent kernel writing the mask tape (k_mlp_fused<true>) + its chained backward
 
     python tools/stress_chain.py [scale]        # scale 1.0 = >= 5,000 chained launches (about 5 minutes of GPU)
 Exit code 1 on any mismatch or verdict.
@@ -103,7 +104,7 @@ def forward_arm(name, R, S, n, busy=False, two_streams=False, D=10, W=1024):
     report(name, done, mism, t0)
 
 
-def fit_arm(name, R, S, n, fp32_tape=False, D=10, W=1024):
+def fit_arm(name, R, S, n, fp32_tape=False, D=10, W=1024, per_step=3):
     h, o, d, z, vd, folded, vb, G = setup(D, W, R, S)
     h.force_fp32_tape = fp32_tape
 
@@ -126,7 +127,7 @@ def fit_arm(name, R, S, n, fp32_tape=False, D=10, W=1024):
     torch.cuda.synchronize()
     h.check_verdict(block=True)
     launches = h.chained_launches() - before
-    assert launches == 3 * n, f"{launches} chained launches for {n} steps (expected 1 forward + 2 backward each)"
+    assert launches == per_step * n, f"{launches} chained launches for {n} steps (expected {per_step} each: forward + 2 backward; width 256: the backward only)"
     report(name, launches, mism, t0)
 
 
@@ -173,6 +174,8 @@ forward_arm("forward, 3 row tiles, competing stream", 6, 128, n_of(500), busy=Tr
 forward_arm("forward, width 512 x 8, 300 row tiles, competing stream", 1200, 64, n_of(300), busy=True, D=8, W=512)
 fit_arm("fitting step fine pass (1024 rays x 128): forward + mask tape, 2 backward launches", 1024, 128, n_of(250))
 fit_arm("fitting step, fp32 tape (256 rays x 128)", 256, 128, n_of(60), fp32_tape=True)
+fit_arm("coarse network 256 x 8 fitting pass (1024 rays x 64): k_mlp_fused<true> writes the mask tape, 2 chained backward launches", 1024, 64, n_of(200),
+        D=8, W=256, per_step=2)
 tape_forward_arm("training forward keeping the fp32 tape (512 rays x 128)", 512, 128, n_of(120))
 print(f"TOTAL: {total_chained} chained launches, {bad} mismatching, every verdict clean", flush=True)
 sys.exit(1 if bad else 0)
