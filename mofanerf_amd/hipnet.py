@@ -119,6 +119,9 @@ class HipNet:
     # -- launch verdicts ----------------------------------------------------------------------------
     def verdict_ptr(self, device) -> int:
         """Device pointer of this network's sticky verdict words (created zeroed on first use)."""
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:       # "cuda" = the current device: compare like with like
+            device = torch.device("cuda", torch.cuda.current_device())
         if self._verdict is None or self._verdict.device != device:
             self._verdict = torch.zeros(lib.VERDICT_WORDS, dtype=torch.int32, device=device)
             self._verdict_host = torch.zeros(lib.VERDICT_WORDS, dtype=torch.int32).pin_memory()
