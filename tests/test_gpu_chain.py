@@ -27,6 +27,18 @@ DEV = "cuda"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(autouse=True)
+def _shipped_launch_forms(monkeypatch):
+    """These tests are ABOUT the chained launch: whatever MOFA_* knob the surrounding run exports (the suite is also run under
+    MOFA_PIPE=0 / MOFA_CHAIN=0 / MOFA_FUSED=0), they start from the shipped forms and set what they vary themselves."""
+    for k in ("MOFA_PIPE", "MOFA_CHAIN", "MOFA_FUSED", "MOFA_CHAIN_SPIN_LIMIT", "MOFA_CHAIN_TEST_SKIP_XCD"):
+        monkeypatch.delenv(k, raising=False)
+    lib.reload_env()
+    yield
+    monkeypatch.undo()
+    lib.reload_env()
+
+
 def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 

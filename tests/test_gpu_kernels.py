@@ -649,6 +649,7 @@ def test_chained_wide_network_is_bit_identical_to_per_layer_launches(D, W, R, S,
         torch.cuda.synchronize()
         return raw
 
+    knob("MOFA_PIPE", "1")                                   # (the chained launch is built on the pipelined K loop: MOFA_PIPE=0 in the environment would select per-layer launches)
     knob("MOFA_CHAIN", "0")
     ref = run()
     assert torch.isfinite(ref).all()
