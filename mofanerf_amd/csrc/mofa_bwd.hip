@@ -111,6 +111,63 @@ __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ g, lo
     }
 }
 
+// The same sum split over the rows (fitting's five bias gradients, mofa_net_backward): 64 workgroups — one per panel of a 1024-wide
+// layer — are a quarter of the chip, and the column sum of a 0.5 GB gradient buffer is HBM-bound work (175 us = 3 TB/s in that form).
+// Here blockIdx.y walks `splits` row ranges (multiples of 1024 rows, so the per-lane swizzle argument above still holds), each writing
+// a partial row; k_colsum_combine adds the partials in index order: deterministic, independent of the device.
+__global__ __launch_bounds__(1024) void k_colsum_split(const float* __restrict__ g, long long m_padded, long long n_points, long long rows_per_split,
+                                                       int n_padded, float* __restrict__ partial) {
+    __shared__ f32x4 red[1024];
+    const int panel = blockIdx.x, tid = threadIdx.x;
+    const int chunk = tid & 3, r0 = tid >> 2;
+    const long long lo = (long long)blockIdx.y * rows_per_split;
+    long long hi = lo + rows_per_split;
+    if (hi > n_points) hi = n_points;
+    const float* base = g + (long long)panel * m_padded * 16 + chunk * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    long long m = lo + r0;
+    for (; m + 3 * 256 < hi; m += 4 * 256) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(base + (m + u * 256) * 16);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc.x += v[u].x, acc.y += v[u].y, acc.z += v[u].z, acc.w += v[u].w;
+    }
+    for (; m < hi; m += 256) {
+        const f32x4 v = *(const f32x4*)(base + m * 16);
+        acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < 256) {
+        f32x4 t = red[tid];
+#pragma unroll
+        for (int u = 1; u < 4; ++u) {
+            const f32x4 v = red[tid + 256 * u];
+            t.x += v.x, t.y += v.y, t.z += v.z, t.w += v.w;
+        }
+        red[tid] = t;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const int want = tid >> 2, comp = tid & 3;
+        float t = 0.f;
+        for (int i = 0; i < 256; ++i) {
+            const int lg = (i & 3) ^ ((i >> 4) & 3);
+            if (lg == want) t += red[i][comp];
+        }
+        partial[(long long)blockIdx.y * n_padded + panel * 16 + tid] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_colsum_combine(const float* __restrict__ partial, int splits, int n_padded, float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_padded) return;
+    float t = 0.f;
+    for (int s = 0; s < splits; ++s) t += partial[(long long)s * n_padded + n];
+    out[n] = t;
+}
+
 __global__ __launch_bounds__(256) void k_colsum_rays(const float* __restrict__ g, long long m_padded, long long n_rays,
                                                      int S, int n_padded, float* __restrict__ out) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -513,6 +570,24 @@ int mofa_bias_grad(const float* g, int64_t m_padded, int64_t n_points, int32_t n
     hipLaunchKernelGGL(k_colsum, dim3(n_padded / 16), dim3(1024), 0, (hipStream_t)stream, g, (long long)m_padded,
                        (long long)n_points, out);
     return check_launch("k_colsum");
+}
+
+// internal (mofa_net_backward, fitting): the same column sums over `splits` row ranges + a fixed-order combine; `workspace`: at least
+// 8 * n_padded floats.  The number of ranges depends on the SHAPE only (never on the device), so results are reproducible everywhere.
+int mofa_internal_bias_grad_split(const float* g, long long m_padded, long long n_points, int n_padded, float* out, float* workspace,
+                                  void* stream) {
+    MOFA_REQUIRE(g && out && workspace && n_padded % 16 == 0 && n_points > 0 && n_points <= m_padded, "bias_grad_split: bad arguments");
+    const int panels = n_padded / 16;
+    int splits = panels >= 256 ? 1 : 256 / panels;                 // ~ one workgroup per CU of a 256-CU part
+    if (splits > 8) splits = 8;
+    long long rows = (n_points + splits - 1) / splits;
+    rows = (rows + 1023) / 1024 * 1024;                            // whole 1024-row strides per range
+    splits = (int)((n_points + rows - 1) / rows);
+    hipLaunchKernelGGL(k_colsum_split, dim3(panels, splits), dim3(1024), 0, (hipStream_t)stream, g, m_padded, n_points, rows, n_padded, workspace);
+    int rc = check_launch("k_colsum_split");
+    if (rc != MOFA_OK) return rc;
+    hipLaunchKernelGGL(k_colsum_combine, dim3((n_padded + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, splits, n_padded, out);
+    return check_launch("k_colsum_combine");
 }
 
 int mofa_bias_grad_rays(const float* g, int64_t m_padded, int64_t n_rays, int32_t S, int32_t n_padded, float* out,

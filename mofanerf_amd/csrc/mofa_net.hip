@@ -31,6 +31,7 @@ int mofa_internal_chain_launch(int mode, const mofa::ChainStep* steps, int n_ste
                                long long* tiles_out, void* stream);
 int mofa_internal_chain_verify(const unsigned* state, long long tiles, unsigned* verdict, float* p0, long long n0, float* p1, long long n1,
                                float* p2, long long n2, float* p3, long long n3, void* stream);
+int mofa_internal_bias_grad_split(const float* g, long long m_padded, long long n_points, int n_padded, float* out, float* workspace, void* stream);
 int mofa_internal_head_weight_grad_split(const float* d_raw, int32_t raw_off, int32_t n_out, const float* x, int32_t k_padded,
                                          int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, float* workspace,
                                          void* stream);
@@ -581,7 +582,8 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
         MOFA_REQUIRE(nseg < 2, "net_backward: internal error (more than two chained segments)");
         MOFA_TRY(mofa_internal_chain_launch(kChainBackward, seg.data(), (int)seg.size(), Mp, 1, cstate[nseg], &ctiles[nseg], stream));
         ++nseg;
-        for (const Deferred& d : deferred) MOFA_TRY(mofa_bias_grad(d.g, Mp, M, p.L[d.li].n_padded, d_folded + p.L[d.li].folded_off, stream));
+        for (const Deferred& d : deferred)
+            MOFA_TRY(mofa_internal_bias_grad_split(d.g, Mp, M, p.L[d.li].n_padded, d_folded + p.L[d.li].folded_off, wws, stream));
         seg.clear(), deferred.clear(), kept.clear();
         return MOFA_OK;
     };
@@ -603,7 +605,8 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
             deferred.push_back({li, g}), kept.push_back(g);
             return MOFA_OK;
         }
-        return mofa_bias_grad(g, Mp, M, p.L[li].n_padded, d_folded + p.L[li].folded_off, stream);
+        // (row-split form: 64 workgroups — one per panel — are a quarter of the chip; the weight-gradient partials' region is free in fitting)
+        return mofa_internal_bias_grad_split(g, Mp, M, p.L[li].n_padded, d_folded + p.L[li].folded_off, wws, stream);
     };
     // dX = G @ W[:, part]
     auto bdata = [&](int li, int part, const float* g, Mask mask, int accumulate, float* dx) -> int {
