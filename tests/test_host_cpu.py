@@ -235,3 +235,21 @@ def test_embedded_forward_cache_does_not_keep_modules_alive():
     strong = HipNet(NeRF(D=8, W=64, input_ch=93, input_ch_views=27, input_ch_textureCodes=256, input_ch_shapeCodes=50, use_viewdirs=True))
     gc.collect()
     assert strong.net is not None                     # the renderer's own HipNets keep their module (default: strong)
+
+
+def test_bench_roofline_of_picks_the_kernel_with_the_largest_summed_time():
+    """bench.py's `roofline` object (ours and the variants'): dominant kernel = largest summed HIP-event time; achieved = its algorithmic
+    FLOPs / that time; frac against the fp32 matrix peak; everything else listed under `other_mfma_kernels`."""
+    import ctypes
+    import bench
+    from mofanerf_amd import lib
+    NK = lib.PROF_KINDS
+    ms, launches, pflops = (ctypes.c_double * NK)(), (ctypes.c_int64 * NK)(), (ctypes.c_double * NK)()
+    ms[5], launches[5], pflops[5] = 705.0, 10, 10 * 10.52e12            # ten chained launches of 10.52 TFLOP in 70.5 ms each
+    ms[1], launches[1], pflops[1] = 40.0, 10, 10 * 0.5604e12            # the coarse network's persistent kernel
+    dom, r = bench.roofline_of(ms, launches, pflops, dt=0.75)
+    assert dom == 5 and r["kernel"].startswith("mofa::k_net_chain<0>") and r["bound"] == "mfma" and r["unit"] == "TFLOP/s"
+    assert abs(r["achieved"] - 149.22) < 0.01 and abs(r["frac"] - 149.22 / 157.3) < 1e-4 and r["peak"] == 157.3
+    assert r["launches"] == 10 and abs(r["avg_launch_ms"] - 70.5) < 1e-9 and abs(r["algorithmic_gflop_per_launch"] - 10520.0) < 1e-6
+    assert abs(r["share_of_timed_region"] - 0.94) < 1e-9
+    assert [o["kernel"] for o in r["other_mfma_kernels"]] == ["mofa::k_mlp_fused"] and abs(r["other_mfma_kernels"][0]["tflops"] - 140.1) < 0.01
