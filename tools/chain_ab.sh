@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of k_net_chain options, one arm per "NAME=VALUE" environment assignment (e.g. MOFA_CHAIN_NSPLIT=2, MOFA_CHAIN_GANG=16, MOFA_CHAIN=0):
+# A/B of launch-form options, one arm per "NAME=VALUE" environment assignment (e.g. MOFA_CHAIN=0; the round-5 arms MOFA_CHAIN_GANG=n and
+# MOFA_CHAIN_NSPLIT=2 existed only in the commits named in profiles/r05_ab_chain_gang.txt):
 # frame rate + live roofline, socket power / clock, and three PMC passes (fabric fetch bytes, L2 hit rate, matrix-pipe busy).
 #   bash tools/chain_ab.sh <tag> ARM [ARM...]        # an arm "X=1" runs with X=1 exported; "base" runs with nothing set
 set -u
