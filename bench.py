@@ -20,9 +20,10 @@ GPU, RCCL), so `python bench.py --gpus 8` alone produces the line; launched unde
   train   BASELINE configs[4]: run_train.py's step, N_rand = 4096 rays per GPU, texture encoder, forward + backward incl.
           weight gradients, ONE RCCL all-reduce of the flat gradient bucket, Adam; scaling "weak".
 
-Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel of the mode (render/fit: the BN=128 fp32-MFMA layer kernel;
-train: whichever of forward / backward-data / weight-gradient kernels has the largest summed time): algorithmic FLOPs of its
-launches / their summed duration measured with HIP events on the launch stream, against the fp32 MFMA peak of 157.3 TFLOP/s.
+Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel of the mode (the MFMA kernel kind with the largest summed time):
+algorithmic FLOPs of its launches / their summed duration measured with HIP events on the launch stream, against the fp32 MFMA
+peak of 157.3 TFLOP/s.  `roofline_hbm` is SURVEY section 8d's second roofline: the HBM-bound compositing / resampling kernels of the
+same timed region, algorithmic bytes / HIP-event time against the 8 TB/s HBM peak.
 `cpu_baseline` times the CPU oracle on a bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
@@ -43,18 +44,31 @@ sys.path.insert(0, ROOT)
 from mofanerf_amd import dist as mdist, factory, lib, schema, steps as msteps, synth  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0              # same guide, "HBM3E (288 GB, 8 TB/s peak)" (~6.3 TB/s achievable by a streaming kernel)
 H = W = 512
 ARCH = (8, 256, 10, 1024)
 N_SAMPLES, N_IMPORTANCE = 64, 64
-# (symbol, role, description) per profiler kind of libmofanerf_hip.so; k_layer's template = <BN, L0, BWD, PERRAY, PIPE, policy>
+# (symbol, role, description) per profiler kind of libmofanerf_hip.so (include/mofanerf_hip.h, MOFA_PROF_KINDS); k_layer's template =
+# <BN, L0, BWD, PERRAY, PIPE, policy>.  Kinds 0-7 are the fp32-MFMA kernels (work = FLOPs), 8-10 the HBM-bound ray kernels (work = rays).
 KERNELS = [("mofa::k_layer<128,false,false,false,true,mofa::ShippedPolicy>", "forward", "fp32 MFMA Linear+bias+ReLU, software-pipelined K loop"),
            ("mofa::k_mlp_fused", "forward, persistent", "persistent fp32-MFMA network kernel, 256-wide layers pipelined across layer boundaries"),
            ("mofa::k_layer<128,false,true,false,true,mofa::ShippedPolicy>", "BWD backward-data", "fp32 MFMA backward-data GEMM + ReLU mask, the same K loop"),
            ("mofa::k_wgrad<128,256>", "weight gradient", "fp32 MFMA weight-gradient GEMM, contraction over points"),
            ("mofa::k_layer<128,false,false,true,true,mofa::ShippedPolicy>", "forward, PERRAY view layer", "the same kernel with the view layer's per-ray bias"),
            ("mofa::k_net_chain<0>", "forward, chained", "every fp32-MFMA layer of a wide network in one launch: the layer kernel's tiles behind per-XCD queues and "
-                                                        "row-tile dependency counters (<1>: the same, also writing the mask tape)"),
-           ("mofa::k_net_chain<2>", "BWD backward-data, chained", "the backward-data products of a wide network's fitting step in two launches of the same queues")]
+                                                        "row-tile dependency counters (inference, or keeping the fp32 tape)"),
+           ("mofa::k_net_chain<2>", "BWD backward-data, chained", "the backward-data products of a wide network's fitting step in two launches of the same queues"),
+           ("mofa::k_net_chain<1>", "forward + mask tape, chained", "the chained forward whose contiguous-store epilogue also writes (y > 0) as one bit per activation "
+                                                                    "(the fitting step's forward)"),
+           ("mofa::k_composite<1>", "raw2outputs, coarse pass", "one wavefront per ray, 64 samples: coalesced float4 loads of raw, wavefront prefix product"),
+           ("mofa::k_composite<2>", "raw2outputs, fine pass", "the same with two samples per lane (128 samples)"),
+           ("mofa::k_sample_pdf_merge<false>", "sample_pdf + sort(cat) + std", "one wavefront per ray: cdf (fp64 prefix), inverse-cdf search in LDS, merge")]
+MFMA_KINDS = range(8)
+# ALGORITHMIC HBM bytes per ray of the ray-side kernels: coarse compositing reads raw + z (64 x 20 + 12 B) and writes
+# the weights + 5 scalars (256 + 20 B); the fine pass reads 128 x 20 + 12 B and writes its 5 scalars + rgb0 / disp0 / acc0 / z_std (20 + 24 B;
+# its weights are an extra the kernel's contract writes but nobody needs: not counted); the resampler reads z + weights (2 x 256 B) and writes
+# z_samples, the merged 128 positions and z_std (256 + 512 + 4 B).
+HBM_KINDS = {8: 64 * 20 + 12 + 64 * 4 + 20, 9: 128 * 20 + 12 + 20 + 24, 10: 4 * (64 + 64 + 64 + 128 + 1)}
 
 
 def pose_spherical(phi_deg, theta_deg, radius):
@@ -245,7 +259,7 @@ def variant_series(arch, steps, dev, L, bm, tex, exp, K, rays, angles, args):
         ms, launches, pflops = (ctypes.c_double * NK)(), (ctypes.c_int64 * NK)(), (ctypes.c_double * NK)()
         lib.check(L.mofa_prof_end(ms, launches, pflops), "mofa_prof_end")
         assert bool(torch.isfinite(last).all())
-        dom = max(range(NK), key=lambda k: ms[k])
+        dom = max(MFMA_KINDS, key=lambda k: ms[k])
         ach = pflops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         return {"workload": f"{H}x{W} novel view, 64 coarse + 128 fine samples/ray, coarse {arch[1]}x{arch[0]} + fine {arch[3]}x{arch[2]} (VARIANT: "
                             "BASELINE.json's prose size; the headline is the shipped 1024x10 fine network)",
@@ -297,16 +311,110 @@ def make_grad_step(mode, n, render, kw, dev, rank, L, K, bm, tex, exp, timed_com
 
 def roofline_of(ms, launches, pflops, dt):
     """The dominant MFMA kernel of a timed region (largest summed HIP-event time) against the fp32 matrix peak."""
-    NK = lib.PROF_KINDS
-    dom = max(range(NK), key=lambda k: ms[k])
+    dom = max(MFMA_KINDS, key=lambda k: ms[k])
     ach = pflops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
     others = [{"kernel": KERNELS[k][0], "role": KERNELS[k][1], "launches": int(launches[k]), "total_ms": round(ms[k], 2),
-               "tflops": round(pflops[k] / (ms[k] * 1e-3) / 1e12, 2)} for k in range(NK) if k != dom and ms[k] > 0]
+               "tflops": round(pflops[k] / (ms[k] * 1e-3) / 1e12, 2)} for k in MFMA_KINDS if k != dom and ms[k] > 0]
     return dom, {"bound": "mfma", "kernel": f"{KERNELS[dom][0]} ({KERNELS[dom][2]})", "role": KERNELS[dom][1], "achieved": round(ach, 2),
                  "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                  "launches": int(launches[dom]), "avg_launch_ms": round(ms[dom] / max(1, launches[dom]), 4),
                  "algorithmic_gflop_per_launch": round(pflops[dom] / max(1, launches[dom]) / 1e9, 3),
                  "share_of_timed_region": round(ms[dom] * 1e-3 / dt, 4), "other_mfma_kernels": others}
+
+
+def roofline_hbm_of(ms, launches, work, dt, traffic_json=None, digest=None):
+    """SURVEY section 8d's second roofline (VERDICT r5 missing 3): the HBM-bound ray kernels — compositing (coarse / fine pass) and the
+    resampler — against the 8 TB/s HBM peak.  `achieved` = algorithmic bytes (SURVEY's per-ray figure x the rays of the launches, `work`)
+    / the summed HIP-event time of those launches on their own stream; `traffic` = what the L2s' fabric ports moved per launch by
+    rocprofv3 --pmc (profiles/hbm_traffic_rays.json: separate passes on a driver that launches these kernels at the benchmark's
+    shapes), quoted only while the kernel sources hash to what the passes were taken on."""
+    out = []
+    for k, per_ray in HBM_KINDS.items():
+        if ms[k] <= 0:
+            continue
+        n = int(launches[k])
+        gbs = work[k] * per_ray / (ms[k] * 1e-3) / 1e9
+        rec = {"bound": "hbm", "kernel": f"{KERNELS[k][0]} ({KERNELS[k][2]})", "role": KERNELS[k][1], "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+               "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_ray": per_ray, "launches": n,
+               "rays_per_launch_avg": round(work[k] / max(1, n), 1), "avg_launch_us": round(ms[k] / max(1, n) * 1e3, 2),
+               "share_of_timed_region": round(ms[k] * 1e-3 / dt, 6), "traffic": None}
+        tj = (traffic_json or {}).get("kernels", {}).get(KERNELS[k][0])
+        if tj is not None:
+            if traffic_json.get("csrc_sha256") == digest:
+                rec["traffic"] = tj.get("bytes_per_launch")
+                rec["traffic_rays_per_launch"] = tj.get("rays_per_launch")
+                rec["traffic_algorithmic_bytes_same_shape"] = tj.get("algorithmic_bytes_per_launch")
+            else:
+                rec["traffic_source"] = f"null: profiles/hbm_traffic_rays.json was taken on kernel sources {str(traffic_json.get('csrc_sha256'))[:16]}, this build is {str(digest)[:16]}"
+        out.append(rec)
+    return out
+
+
+def bulk_variant(dev, size=256, identities=2, expressions=2, views=3, workers=4):
+    """BASELINE configs[3] inside the headline's line (VERDICT r5 missing 4): render_refine_trainSet.py's job shape (:238-295) on one GPU —
+    `identities` x `expressions` x `views` frames at `size`^2 through `render_path` (texture encoder on the identity's 512^2 UV map, cached
+    per map; the shipped network sizes) with ONE `PngSink` for the job writing PNGs into a temporary directory: rays/s INCLUDING encoder,
+    quantisation, D2H and PNG encoding (every file on disk inside the timed region), the same loop with the output stage disabled
+    (`savedir=None`: frames still return to the host as `render_path` does) on one identity, and the sink's queue high-water mark —
+    the evidence for SURVEY section 8(f3)'s claim that the output stage is off the critical path."""
+    import shutil
+    import tempfile
+    from mofanerf_amd import rays as mrays
+    from mofanerf_amd.io import PngSink
+    render, kw, args = build_product(dev, with_tex=True)
+    K = synth.intrinsics(size, size)
+
+    def job(idents, exprs, angles, out_dir):
+        n = 0
+        with torch.no_grad():
+            for ident in idents:
+                shape = synth.codes(ident)[0].to(dev)
+                uv = torch.from_numpy(np.random.default_rng(ident).uniform(0, 1, (1, 512, 512, 3)).astype(np.float32)).to(dev)
+                d = None
+                if out_dir is not None:
+                    d = os.path.join(out_dir, f"{ident:03d}")
+                    os.makedirs(d, exist_ok=True)
+                for e in range(exprs):
+                    for v, ang in enumerate(angles):
+                        pose = mrays.pose_spherical(float(ang), 0.0, 16.0)[None]
+                        render.render_path(pose, [size, size, float(K[0][0])], K, args.chunk, kw, uvMap=uv, expType=torch.tensor([e]), savedir=d,
+                                           shapeCodes=shape, name=f"{e:02d}_{v}")
+                        n += 1
+        return n
+
+    angles = list(np.linspace(-60, 60, views))
+    job([1000], 1, angles[:1], None)                       # untimed: MIOpen picks its convolution solvers, the nets are packed
+    torch.cuda.synchronize()
+    tmp = tempfile.mkdtemp(prefix="mofa_bulk_")
+    try:
+        render.png_sink = PngSink(workers=workers)         # one sink for the job: PNG encoding overlaps the following frames
+        t0 = time.perf_counter()
+        n_sink = job(list(range(identities)), expressions, angles, tmp)
+        render.png_sink.close()                            # every file is on disk inside the timed region
+        torch.cuda.synchronize()
+        dt_sink = time.perf_counter() - t0
+        high, render.png_sink = render.png_sink.high_water, None
+        files = [os.path.join(r, f) for r, _, fs in os.walk(tmp) for f in fs if f.endswith(".png")]
+        png_bytes = sum(os.path.getsize(f) for f in files)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    t0 = time.perf_counter()
+    n_plain = job([identities], expressions, angles, None)  # a fresh identity (its texture code is not cached), no output stage
+    torch.cuda.synchronize()
+    dt_plain = time.perf_counter() - t0
+    render.check_launches(block=True)
+    assert len(files) == n_sink, (len(files), n_sink)
+    return {"workload": f"render_refine_trainSet.py job shape: {identities} identities x {expressions} expressions x {views} views at {size}x{size} "
+                        f"through render_path (texture encoder per identity, coarse {ARCH[1]}x{ARCH[0]} + fine {ARCH[3]}x{ARCH[2]}, 64 + 128 samples/ray), one PngSink "
+                        f"({workers} workers) writing to a temporary directory (BASELINE.json configs[3], one GPU's share)",
+            "value": round(n_sink * size * size / dt_sink, 1), "unit": "rays/s",
+            "includes": "texture encoder, device quantisation (to8b), pinned D2H, PNG encoding, files on disk",
+            "frames": n_sink, "seconds": round(dt_sink, 3), "ms_per_frame": round(dt_sink / n_sink * 1e3, 2), "png_files": len(files), "png_bytes": png_bytes,
+            "sink_queue_high_water": int(high), "sink_workers": workers,
+            "without_output_stage": {"value": round(n_plain * size * size / dt_plain, 1), "unit": "rays/s", "frames": n_plain, "seconds": round(dt_plain, 3),
+                                     "ms_per_frame": round(dt_plain / n_plain * 1e3, 2),
+                                     "what": "the same loop with savedir=None on one further identity (frames still return to the host as numpy arrays, as render_path does)"},
+            "output_stage_cost_fraction": round(1.0 - (dt_plain / n_plain) / (dt_sink / n_sink), 4)}
 
 
 def step_variant(mode, n, steps, warmup, dev, L, K, bm, tex, exp):
@@ -384,6 +492,8 @@ def main():
                     "loop into variants.fit1024 (render mode, N = 1, shipped sizes; 0 = skip)")
     ap.add_argument("--train-steps", type=int, default=4, help="steps of BASELINE configs[4] (run_train.py step, 4,096 rays) timed after the "
                     "headline loop into variants.train4096 (same conditions; 0 = skip)")
+    ap.add_argument("--bulk-identities", type=int, default=2, help="identities of BASELINE configs[3]'s job shape (x 2 expressions x 3 views at 256^2 "
+                    "through render_path with the texture encoder and the PNG sink) timed after the headline loop into variants.bulk256 (same conditions; 0 = skip)")
     ap.add_argument("--rays", type=int, default=None, help="fit / train: N_rand per GPU (default 1024 / 4096)")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -516,6 +626,10 @@ def main():
             else:
                 tinfo = {"traffic_source": f"null: profiles/{os.path.basename(tpath)} was taken on kernel sources {str(tj.get('csrc_sha256'))[:16]} / "
                                            f"{tj.get('kernel')}, this build is {digest[:16]} / {kname.split(' ')[0]} — re-run tools/gpu_profile_round.sh"}
+        # SURVEY section 8d's second roofline: the HBM-bound ray kernels of the same timed region (compositing, resampling)
+        from mofanerf_amd import build as mbuild2
+        rpath = os.path.join(ROOT, "profiles", "hbm_traffic_rays.json")
+        roof_hbm = roofline_hbm_of(ms, launches, pflops, dt, json.load(open(rpath)) if os.path.exists(rpath) else None, mbuild2.csrc_digest())
         fwd = flops_per_ray(True)
         work = {"render": fwd, "fit": 2 * fwd, "train": 3 * fwd}[a.mode]    # + backward-data (+ weight gradients)
         metric = {"render": "rendered rays/sec (64c+128f samples) at 512^2 novel-view",
@@ -544,6 +658,7 @@ def main():
             "whole_path_tflops": round(work * units_per_s / 1e12, 2),
             "roofline": {**{k: v for k, v in roof.items() if k != "other_mfma_kernels"}, "traffic": traffic,
                          "other_mfma_kernels": roof["other_mfma_kernels"], **tinfo},
+            "roofline_hbm": roof_hbm,
         }
         if mdist.active():
             out["rccl_ranks"] = world
@@ -572,6 +687,8 @@ def main():
                 out["variants"]["fit1024"] = step_variant("fit", 1024, a.fit_steps, 3, dev, L, K, bm, tex, exp)
             if a.train_steps > 0:
                 out["variants"]["train4096"] = step_variant("train", 4096, a.train_steps, 4, dev, L, K, bm, tex, exp)
+            if a.bulk_identities > 0:
+                out["variants"]["bulk256"] = bulk_variant(dev, identities=a.bulk_identities)
         if world == 1 and a.cpu_rays > 0:
             out["cpu_baseline"] = cpu_baseline(a.cpu_rays, backward=(a.mode == "fit"), reps=a.cpu_reps,
                                                tile_reps=a.cpu_tile_reps if (H, W) == (512, 512) else 0)

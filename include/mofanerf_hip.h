@@ -36,10 +36,13 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define MOFA_ABI_VERSION 4 /* 2: MofaNetShape carries the encoding / code widths; explicit-point backward; mask tape; no split modes.
+#define MOFA_ABI_VERSION 5 /* 2: MofaNetShape carries the encoding / code widths; explicit-point backward; mask tape; no split modes.
                              3: MOFA_PROF_KINDS = 6 (mofa_prof_end's arrays grew by the chained kernel's entry); larger mofa_net_workspace_floats
                              4: mofa_device_init(); `verdict` words of mofa_net_forward / mofa_net_backward; MOFA_PROF_KINDS = 7; larger
-                                mofa_net_backward_workspace_floats */
+                                mofa_net_backward_workspace_floats
+                             5: mofa_device_init() runs the chained launch's self-check (third argument); mofa_test_hooks() replaces the two
+                                MOFA_CHAIN_* environment hooks; MOFA_PROF_KINDS = 11 (the mask-writing chained forward and the HBM-bound ray
+                                kernels have their own entries); mofa_net_backward_workspace_floats(.., with_weight_grads) */
 #define MOFA_OK 0
 #define MOFA_EINVAL (-1)
 #define MOFA_EHIP (-2)
@@ -68,13 +71,32 @@ const char* mofa_last_error(void);   /* thread-local text of the calling thread'
  *   - per-device caches (CU count, a one-time function attribute) and the per-device measurement session below. */
 int mofa_config_reload(void);
 
-/* Per-device initialisation — the ONE entry point that allocates (a 32-byte scratch, freed again) and synchronises `stream`.  Call it
- * once per device before the first mofa_net_forward (the shipped host layer does, in HipNet.__init__).  It takes the XCD census the
- * chained launch of the wide networks relies on (k_net_chain: one tile queue per XCD — all eight must receive workgroups) and sets
- * the persistent kernel's LDS attribute.  xcd_workgroups: NULL, or 8 ints receiving the census (workgroups of a 2-per-CU launch seen
- * on each XCD).  Without it — or on a device whose census finds fewer than eight XCDs (compute partitions) — the wide networks run as
- * per-layer launches: bit-identical, slower; mofa_net_forward / mofa_net_backward themselves never allocate or synchronise. */
-int mofa_device_init(void* stream, int32_t* xcd_workgroups);
+/* TEST HOOKS — for tests/ and tools/ only; the shipped host layer never calls this, and NOTHING in the environment reaches these
+ * settings (round 5 read two of them from MOFA_CHAIN_* variables: a stray variable in production turned every wide-network launch into
+ * NaN + MofaError).  Process-wide, effective from the next launch / the next mofa_device_init():
+ *   chain_spin_limit  polls before a dependency wait of the chained launch (k_net_chain) gives up; 0 = the shipped budget (2^22 polls,
+ *                     seconds).  1 forces the "wait out of budget" path: the launch ends incomplete -> NaN outputs + verdict.
+ *   chain_skip_xcd    -1 (none), or 0..7: the chained launch's workgroups on that XCD leave at once — what a CU-masked stream that
+ *                     starves an XCD looks like (an unworked tile queue -> NaN outputs + verdict "tiles missing").
+ *   selfcheck_poison  non-zero: mofa_device_init()'s self-check sees one flipped bit in the chained result (forces its fallback). */
+int mofa_test_hooks(uint32_t chain_spin_limit, int32_t chain_skip_xcd, int32_t selfcheck_poison);
+
+/* Per-device initialisation — the ONE entry point that allocates (scratch of the checks below, ~70 MB, freed again) and synchronises
+ * `stream`.  Call it once per device before the first mofa_net_forward (the shipped host layer does, when a network is bound to a
+ * device).  It decides whether the wide networks of this device may take the chained launch (k_net_chain) — two checks, both needed:
+ *   1. the XCD census: one tile queue per XCD, so all eight must receive workgroups of a 2-per-CU launch.
+ *      xcd_workgroups: NULL, or 8 ints receiving the census.
+ *   2. the SELF-CHECK (ABI 5): the chained launch replaces launch boundaries by an inter-workgroup protocol whose visibility leg
+ *      (a producer's plain stores, acknowledged by the XCD's L2, are what the consumer's `sc1` loads return) is a property of this
+ *      part, not a language guarantee — and the verification kernel behind every chained launch sees incompleteness, not staleness.
+ *      So it is checked here: a fixed 10 x 512 network on 4,096 points (16 row tiles: nearly every tile waits on a dependency) runs
+ *      twice chained and twice per layer through one recycled workspace and the outputs are compared bit for bit on the device
+ *      (~4 ms).  chain_selfcheck: NULL, or receives 1 (identical), 0 (any difference / NaN / incomplete launch: this device takes the
+ *      per-layer launches, mofa_last_error() says why), -1 (not run: the census already said no).
+ * It also sets the persistent kernel's LDS attribute.  Returns MOFA_OK whenever the device is usable — a failed check is a fallback
+ * (per-layer launches: bit-identical, ~1 % slower), not an error.  Without this call the wide networks run per layer too;
+ * mofa_net_forward / mofa_net_backward themselves never allocate or synchronise. */
+int mofa_device_init(void* stream, int32_t* xcd_workgroups, int32_t* chain_selfcheck);
 
 /* Launch verdicts.  A chained launch (k_net_chain) replaces launch boundaries by an inter-workgroup protocol; if that protocol ever
  * fails — a dependency wait out of budget, a tile queue nobody worked (CU-masked stream) — the kernel does NOT compute on incomplete
@@ -160,7 +182,7 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
 size_t mofa_net_packed_t_floats(MofaNetShape s);
 size_t mofa_net_tape_floats(MofaNetShape s, int64_t n_points);
 size_t mofa_net_mask_tape_words(MofaNetShape s, int64_t n_points);   /* uint64 words = tape floats / 64 */
-size_t mofa_net_backward_workspace_floats(MofaNetShape s, int64_t n_points);
+size_t mofa_net_backward_workspace_floats(MofaNetShape s, int64_t n_points, int32_t with_weight_grads);   /* d_weights != NULL (training) or not (fitting): the two forms keep different buffers */
 int mofa_net_pack_t(MofaNetShape s, const float* const* weights, float* packed_t, void* stream);
 int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t, const float* tape, const uint64_t* mask_tape,
                       const float* d_raw, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
@@ -243,15 +265,19 @@ int mofa_positional_encode(const float* x, int64_t n, int32_t n_freqs, float* ou
 
 /* ---- measurement hook ------------------------------------------------------------------------
  * A measurement session of the CALLING THREAD'S CURRENT DEVICE (state is per device, mutex-guarded; with no session
- * open the launch paths read one atomic flag).  Between mofa_prof_begin() and mofa_prof_end() every launch of the MFMA
- * kernels — [0] the per-layer forward kernel k_layer<128,..,PIPE> (128-feature tile, pipelined K loop), [1] the persistent
- * whole-network kernel k_mlp_fused (widths <= 256), [2] the backward-data kernel k_layer<128,..,BWD>, [3] the
- * weight-gradient kernel k_wgrad, [4] the view layer's per-ray-bias instantiation of the forward kernel, [5] the chained
- * wide-network kernel k_net_chain (forward: inference or tape-keeping), [6] its backward-data instantiation — is bracketed by
- * hipEventRecord on its own stream.  mofa_prof_end() synchronises those
- * events (host blocks) and fills three arrays of length MOFA_PROF_KINDS: summed kernel time, launch count, FLOPs
- * executed (2*M*K*N of the padded shapes).  Used by bench.py only. */
-#define MOFA_PROF_KINDS 7
+ * open the launch paths read one atomic flag).  Between mofa_prof_begin() and mofa_prof_end() every launch of the kernels below is
+ * bracketed by hipEventRecord on its own stream.  mofa_prof_end() synchronises those events (host blocks) and fills three arrays of
+ * length MOFA_PROF_KINDS: summed kernel time, launch count, WORK executed.
+ *   MFMA kernels (work = FLOPs, 2*M*K*N of the padded shapes):
+ *     [0] the per-layer forward kernel k_layer<128,..,PIPE> (128-feature tile, pipelined K loop)   [1] the persistent whole-network
+ *     kernel k_mlp_fused (widths <= 256)   [2] the backward-data kernel k_layer<128,..,BWD>   [3] the weight-gradient kernel k_wgrad
+ *     [4] the view layer's per-ray-bias instantiation of the forward kernel   [5] the chained wide-network kernel k_net_chain<0>
+ *     (forward: inference or keeping the fp32 tape)   [6] k_net_chain<2> (the fitting backward's backward-data products)
+ *     [7] k_net_chain<1> (forward, also writing the mask tape)
+ *   HBM-bound ray kernels (work = RAYS; bench.py multiplies by SURVEY section 8d's algorithmic bytes per ray):
+ *     [8] k_composite<1> (S <= 64: the coarse pass)   [9] k_composite<2> (S <= 128: the fine pass)   [10] k_sample_pdf_merge
+ * Used by bench.py only. */
+#define MOFA_PROF_KINDS 11
 int mofa_prof_begin(void);
 int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops);
 

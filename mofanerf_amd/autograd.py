@@ -168,7 +168,7 @@ class NetFn(torch.autograd.Function):
             d_p = torch.empty_like(pc)
         else:
             d_o, d_d = torch.empty_like(ro), torch.empty_like(rd)
-        ws = h.backward_workspace(R * S, dev)
+        ws = h.backward_workspace(R * S, dev, with_weight_grads=bool(ctx.w_shapes))
         dws = [torch.zeros(sh, dtype=torch.float32, device=dev) for sh in ctx.w_shapes]
         lib.check(L.mofa_net_backward(h.shape, lib.ptr(h.packed()), lib.ptr(h.packed_t()), lib.ptr(tape),
                                       mask.data_ptr() if mask is not None else None, lib.ptr(d_raw),

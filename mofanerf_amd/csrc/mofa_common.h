@@ -54,10 +54,16 @@ struct Config {
     int fused = -1;       // MOFA_FUSED=0/1: persistent whole-network kernel off / on
     int pipe = -1;        // MOFA_PIPE=0: the plain K loops (layer kernel, persistent kernel, weight gradient) instead of the pipelined ones
     int chain = -1;       // MOFA_CHAIN=0: per-layer launches for the wide networks instead of the chained launch (k_net_chain)
-    unsigned chain_spin = 1u << 22;   // MOFA_CHAIN_SPIN_LIMIT (tests only): polls before a dependency wait of k_net_chain gives up
-    int chain_skip_xcd = -1;          // MOFA_CHAIN_TEST_SKIP_XCD (tests only): k_net_chain's workgroups on this XCD leave at once (an unworked queue)
 };
 const Config& config();
+
+// Test hooks (mofa_test_hooks(), include/mofanerf_hip.h): the ONLY way to reach k_net_chain's failure paths and the self-check's
+// mismatch path on purpose.  Nothing in the environment sets them (round 5 read two of them from MOFA_* variables: a stray variable
+// in production turned every wide-network launch into NaN + MofaError); they are process-wide atomics only an explicit call changes.
+constexpr unsigned kChainSpinDefault = 1u << 22;   // polls (each >= ~1 us with its s_sleep) before a dependency wait gives up: seconds
+unsigned hook_chain_spin();        // polls before a dependency wait of k_net_chain gives up
+int hook_chain_skip_xcd();         // k_net_chain's workgroups on this XCD leave at once (an unworked queue); -1 = none
+int hook_selfcheck_poison();       // mofa_device_init's chained-vs-per-layer self-check sees one flipped bit (forces its fallback)
 
 constexpr int kMaxDevices = 64;
 #define MOFA_MAX_CHAIN_STEPS 40    /* MFMA layers one chained launch (k_net_chain) can hold: its step table travels as kernel arguments */

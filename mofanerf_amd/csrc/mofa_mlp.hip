@@ -844,7 +844,7 @@ struct ChainArgs {
     long long m_padded, bias_rows;
     int m_tiles, n_steps, tiles_per_m;
     unsigned spin_limit;              // polls (each >= ~1 us with its s_sleep) before a wait gives up: seconds, never a hang
-    int skip_xcd;                     // tests only (MOFA_CHAIN_TEST_SKIP_XCD): workgroups on this XCD leave at once — what a CU-masked stream
+    int skip_xcd;                     // tests only (mofa_test_hooks): workgroups on this XCD leave at once — what a CU-masked stream
                                       // that starves an XCD looks like; -1 = none
     ChainStep S[kMaxChainSteps];
 };
@@ -1097,7 +1097,9 @@ __global__ __launch_bounds__(256, 2) void k_net_chain(const ChainArgs a) {
 // live roofline figure.  Off by default (no events, no overhead).  The measurement session is explicit state the HOST opens and
 // closes (mofa_prof_begin/end); it is kept per device and guarded by a mutex, so two devices or two host threads in one process
 // do not share or corrupt it.  When no session is open the launch paths only read one relaxed atomic.
-constexpr int kProfKinds = MOFA_PROF_KINDS;   // 0: k_layer<128,..,PIPE> (forward), 1: k_mlp_fused, 2: k_layer<BWD>, 3: k_wgrad, 4: k_layer<..PERRAY> (view layer), 5: k_net_chain (forward), 6: k_net_chain<backward>
+constexpr int kProfKinds = MOFA_PROF_KINDS;   // 0: k_layer<128,..,PIPE> (forward), 1: k_mlp_fused, 2: k_layer<BWD>, 3: k_wgrad, 4: k_layer<..PERRAY> (view layer), 5: k_net_chain<0> (forward),
+                                              // 6: k_net_chain<2> (backward-data), 7: k_net_chain<1> (forward + mask bits); the HBM-bound ray kernels (work = rays): 8: k_composite<1>, 9: k_composite<2>,
+                                              // 10: k_sample_pdf_merge
 struct ProfState {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     std::vector<int> kind;
@@ -1372,11 +1374,7 @@ int mofa_prof_begin(void) {
     return MOFA_OK;
 }
 
-/* arrays of MOFA_PROF_KINDS: [0] the per-layer forward MFMA kernel k_layer<128,false,false,false,PIPE> (128-feature tile),
- * [1] the persistent network kernel k_mlp_fused, [2] the backward-data kernel k_layer<128,false,BWD,..>, [3] the weight-gradient
- * kernel k_wgrad, [4] the per-ray-bias instantiation k_layer<128,false,false,PERRAY,..> (view layer), [5] the chained wide-network kernel
- * k_net_chain (forward), [6] its backward-data instantiation.
- * Session of the CURRENT device. */
+/* arrays of MOFA_PROF_KINDS (include/mofanerf_hip.h lists the kinds).  Session of the CURRENT device. */
 int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops) {
     MOFA_REQUIRE(total_ms && launches && padded_flops, "prof_end: null pointer");
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -1440,7 +1438,8 @@ int mofa_internal_fused_forward(const float* arena, float* arena_w, const float*
 // mofa_net_forward / mofa_net_backward use the per-layer launches, which need no census and are bit-identical.
 // The result is keyed on the device of `stream`.  (A stream that later restricts the CUs — hipExtStreamCreateWithCUMask — is not
 // covered by the census; k_chain_verify catches what that does: unworked queues -> NaN outputs + verdict.)
-static std::atomic<int> g_chain_census[kMaxDevices];       // 0: not taken, 1: eight XCDs seen, 2: fewer
+static std::atomic<int> g_chain_census[kMaxDevices];       // 0: not taken, 1: eight XCDs seen AND the self-check passed, 2: fewer / it did not
+extern "C" int mofa_internal_chain_selfcheck(void* stream, int* ok, char* why, size_t why_len);      // mofa_net.hip
 
 static int stream_device(hipStream_t st) {
     hipDevice_t d = 0;
@@ -1448,7 +1447,7 @@ static int stream_device(hipStream_t st) {
     return current_device();
 }
 
-int mofa_device_init(void* stream, int32_t* xcd_workgroups) {
+int mofa_device_init(void* stream, int32_t* xcd_workgroups, int32_t* chain_selfcheck) {
     hipStream_t st = (hipStream_t)stream;
     const int dev = stream_device(st);
     unsigned* counts = nullptr;
@@ -1471,13 +1470,26 @@ int mofa_device_init(void* stream, int32_t* xcd_workgroups) {
         populated += host[i] > 0;
         if (xcd_workgroups) xcd_workgroups[i] = (int32_t)host[i];
     }
-    g_chain_census[dev].store(populated == 8 ? 1 : 2, std::memory_order_release);
     // the persistent 256-wide kernel's 66 KiB of dynamic LDS needs a function attribute once per device (launch_fused would set it on its
     // first launch otherwise: not a synchronisation, but it belongs here)
     if (dev == current_device() && !g_fused_attr[dev].load(std::memory_order_acquire)) {
         if (set_fused_attributes((int)((size_t)kFsFloats * sizeof(float))) != MOFA_OK) return MOFA_EHIP;
         g_fused_attr[dev].store(1, std::memory_order_release);
     }
+    // Eight populated XCDs are necessary for the chained launch, not sufficient: its visibility contract (producer's plain stores seen
+    // by the consumer's sc1 loads through the XCD's L2) is checked HERE, once per device — chained against per-layer launches of a
+    // small fixed network, bit for bit (mofa_net.hip).  A device that fails takes the per-layer launches, and says so.
+    int ok = -1;
+    if (populated == 8) {
+        char why[320] = "";
+        const int rc = mofa_internal_chain_selfcheck(st, &ok, why, sizeof(why));
+        if (rc != MOFA_OK) return rc;
+        if (!ok) set_error("device_init: device %d takes the per-layer launches: %s", dev, why);
+    } else {
+        set_error("device_init: device %d takes the per-layer launches: the census found workgroups on %d of 8 XCDs", dev, populated);
+    }
+    if (chain_selfcheck) *chain_selfcheck = ok;
+    g_chain_census[dev].store(populated == 8 && ok == 1 ? 1 : 2, std::memory_order_release);
     return MOFA_OK;
 }
 
@@ -1499,8 +1511,8 @@ int mofa_internal_chain_launch(int mode, const mofa::ChainStep* steps, int n_ste
     ChainArgs a{};
     a.state = state;
     a.m_padded = m_padded, a.bias_rows = bias_rows, a.m_tiles = (int)(m_padded / kRowTile), a.n_steps = n_steps;
-    a.spin_limit = config().chain_spin;
-    a.skip_xcd = config().chain_skip_xcd;
+    a.spin_limit = hook_chain_spin();         // (the shipped values unless a TEST called mofa_test_hooks(): nothing in the environment)
+    a.skip_xcd = hook_chain_skip_xcd();
     double flops = 0.0;
     int before = 0;
     for (int i = 0; i < n_steps; ++i) {
@@ -1528,7 +1540,7 @@ int mofa_internal_chain_launch(int mode, const mofa::ChainStep* steps, int n_ste
     const int grid = tiles < slots ? (int)round_up(tiles, 8) : slots;       // two resident workgroups per CU
     const size_t lds = 2 * (size_t)(kRowTile + 128) * 16 * sizeof(float) + 64;
     const bool prof = prof_enabled();
-    const int pkind = mode == kChainBackward ? 6 : 5;
+    const int pkind = mode == kChainBackward ? 6 : (mode == kChainForwardMask ? 7 : 5);
     if (prof && prof_open(st, pkind) != MOFA_OK) return MOFA_EHIP;
     if (mode == kChainForward) hipLaunchKernelGGL(k_net_chain<kChainForward>, dim3(grid), dim3(256), lds, st, a);
     else if (mode == kChainForwardMask) hipLaunchKernelGGL(k_net_chain<kChainForwardMask>, dim3(grid), dim3(256), lds, st, a);

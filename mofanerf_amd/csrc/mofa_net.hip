@@ -35,6 +35,7 @@ int mofa_internal_bias_grad_split(const float* g, long long m_padded, long long 
 int mofa_internal_head_weight_grad_split(const float* d_raw, int32_t raw_off, int32_t n_out, const float* x, int32_t k_padded,
                                          int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, float* workspace,
                                          void* stream);
+int mofa_internal_chain_selfcheck(void* stream, int* ok, char* why, size_t why_len);
 }
 
 namespace mofa {
@@ -54,16 +55,11 @@ Config read_env() {
     Config c;
     auto tri = [](const char* name) { const char* e = getenv(name); return e ? (e[0] == '1' ? 1 : 0) : -1; };
     c.fused = tri("MOFA_FUSED"), c.pipe = tri("MOFA_PIPE"), c.chain = tri("MOFA_CHAIN");
-    if (const char* e = getenv("MOFA_CHAIN_SPIN_LIMIT")) {       // tests only: force k_net_chain's dependency waits to give up early
-        const long v = strtol(e, nullptr, 10);
-        if (v > 0) c.chain_spin = (unsigned)v;
-    }
-    if (const char* e = getenv("MOFA_CHAIN_TEST_SKIP_XCD")) {    // tests only: leave one XCD's tile queue unworked
-        const long v = strtol(e, nullptr, 10);
-        c.chain_skip_xcd = (e[0] && v >= 0 && v < 8) ? (int)v : -1;
-    }
     return c;
 }
+std::atomic<unsigned> g_hook_spin{kChainSpinDefault};
+std::atomic<int> g_hook_skip_xcd{-1};
+std::atomic<int> g_hook_poison{0};
 // two slots + an atomic index: readers never see a half-written snapshot, reload is rare and host-side only
 Config g_cfg[2] = {read_env(), Config{}};
 std::atomic<int> g_cfg_cur{0};
@@ -71,6 +67,9 @@ std::atomic<int> g_cus[kMaxDevices];
 }  // namespace
 
 const Config& config() { return g_cfg[g_cfg_cur.load(std::memory_order_acquire)]; }
+unsigned hook_chain_spin() { return g_hook_spin.load(std::memory_order_relaxed); }
+int hook_chain_skip_xcd() { return g_hook_skip_xcd.load(std::memory_order_relaxed); }
+int hook_selfcheck_poison() { return g_hook_poison.load(std::memory_order_relaxed); }
 
 int current_device() {
     int dev = 0;
@@ -201,6 +200,26 @@ bool shape_ok(MofaNetShape s) {
            s.pe_view_freqs >= 0 && s.pe_view_freqs <= MOFA_MAX_PE_FREQS && s.ch_exp >= 0 && s.ch_exp <= MOFA_MAX_CODE && s.ch_shape >= 0 &&
            s.ch_shape <= MOFA_MAX_CODE && s.ch_tex >= 0 && s.ch_tex <= MOFA_MAX_CODE;
 }
+// kernels of the chained launch's self-check (mofa_internal_chain_selfcheck below)
+__global__ __launch_bounds__(256) void k_selfcheck_fill(float* __restrict__ p, long long n, unsigned seed, float scale, float offset) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned h = ((unsigned)i * 2654435761u) ^ seed;
+    h ^= h >> 16, h *= 0x85ebca6bu, h ^= h >> 13, h *= 0xc2b2ae35u, h ^= h >> 16;
+    p[i] = ((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale + offset;      // uniform in [-scale, scale) + offset
+}
+// out[0] += words that differ, out[1] += non-finite values of a, out[2] += non-zero values of a
+__global__ __launch_bounds__(256) void k_selfcheck_compare(const unsigned* __restrict__ a, const unsigned* __restrict__ b, long long n,
+                                                           unsigned* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned x = a[i], y = b[i];
+    if (x != y) atomicAdd(out, 1u);
+    if ((x & 0x7f800000u) == 0x7f800000u) atomicAdd(out + 1, 1u);
+    if ((x & 0x7fffffffu) != 0u) atomicAdd(out + 2, 1u);
+}
+__global__ void k_selfcheck_poison(unsigned* p) { p[0] ^= 1u; }
+
 #define MOFA_SHAPE_FMT "D=%d W=%d multires=%d multires_views=%d ch_exp=%d ch_shape=%d ch_tex=%d"
 #define MOFA_SHAPE_ARGS(s) (s).D, (s).W, (s).pe_point_freqs, (s).pe_view_freqs, (s).ch_exp, (s).ch_shape, (s).ch_tex
 
@@ -220,6 +239,14 @@ int mofa_config_reload(void) {
     return MOFA_OK;
 }
 const char* mofa_last_error(void) { return g_err; }
+
+int mofa_test_hooks(uint32_t chain_spin_limit, int32_t chain_skip_xcd, int32_t selfcheck_poison) {
+    MOFA_REQUIRE(chain_skip_xcd >= -1 && chain_skip_xcd < 8, "test_hooks: chain_skip_xcd=%d (want -1 .. 7)", chain_skip_xcd);
+    g_hook_spin.store(chain_spin_limit ? chain_spin_limit : kChainSpinDefault, std::memory_order_relaxed);
+    g_hook_skip_xcd.store(chain_skip_xcd, std::memory_order_relaxed);
+    g_hook_poison.store(selfcheck_poison ? 1 : 0, std::memory_order_relaxed);
+    return MOFA_OK;
+}
 
 int mofa_net_num_layers(MofaNetShape s) { return shape_ok(s) ? 2 * s.D + 7 : MOFA_EINVAL; }
 
@@ -294,14 +321,16 @@ size_t mofa_net_mask_tape_words(MofaNetShape s, int64_t n_points) {
     return (size_t)round_up(n_points, kRowTile) * make_plan(s).tape_cols / 64;     // one bit per tape float, in 64-bit words
 }
 
-size_t mofa_net_backward_workspace_floats(MofaNetShape s, int64_t n_points) {
+size_t mofa_net_backward_workspace_floats(MofaNetShape s, int64_t n_points, int32_t with_weight_grads) {
     if (!shape_ok(s) || n_points <= 0) return 0;
     const Plan p = make_plan(s);
     const size_t mp = (size_t)round_up(n_points, kRowTile);
-    return mp * (4 * (size_t)p.Wp + (size_t)p.pe_k) + 64 +
-           mofa_weight_grad_workspace_floats(n_points, p.Wp, p.Wp) + 64 +  // split-M partials of the largest dW block
-           3 * mp * (size_t)p.Wp + 2 * (size_t)round_up((int64_t)mofa_internal_chain_state_words((long long)mp), 32) + 64;   // the chained fitting backward: three more gradient
-                                                                                              // buffers (the bias-gradient inputs it keeps) + queue state of its two launches
+    // both forms: four gradient buffers + the encoding gradient + the split-M partial sums of one weight-gradient block (fitting: the
+    // row-split bias sums' partials live there)
+    const size_t base = mp * (4 * (size_t)p.Wp + (size_t)p.pe_k) + 64 + mofa_weight_grad_workspace_floats(n_points, p.Wp, p.Wp) + 64;
+    if (with_weight_grads) return base;
+    // the chained fitting backward: three more gradient buffers (the bias-gradient inputs it keeps) + the queue state of its two launches
+    return base + 3 * mp * (size_t)p.Wp + 2 * (size_t)round_up((int64_t)mofa_internal_chain_state_words((long long)mp), 32) + 64;
 }
 
 int mofa_net_pack_t(MofaNetShape s, const float* const* weights, float* packed_t, void* stream) {
@@ -324,10 +353,13 @@ int mofa_net_pack_t(MofaNetShape s, const float* const* weights, float* packed_t
 #define MOFA_TRY(expr) \
     if ((rc = (expr)) != MOFA_OK) return rc
 
-int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, const float* view_w,
-                     const float* view_b, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
-                     const float* pts, const float* viewdirs, int64_t n_rays, int32_t S, float* workspace,
-                     float* raw_out, float* tape, uint64_t* mask_tape, const float* view_bias_rows, uint32_t* verdict, void* stream) {
+// force_chain: -1 = by configuration + census (every caller but the self-check); 0 = the per-layer launches, 1 = the chained launch —
+// whatever MOFA_* says and whatever the census found (mofa_device_init's self-check runs both forms on the same inputs)
+static int net_forward(MofaNetShape s, const float* packed, const float* folded, const float* view_w,
+                       const float* view_b, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
+                       const float* pts, const float* viewdirs, int64_t n_rays, int32_t S, float* workspace,
+                       float* raw_out, float* tape, uint64_t* mask_tape, const float* view_bias_rows, uint32_t* verdict, void* stream,
+                       int force_chain) {
     MOFA_REQUIRE(shape_ok(s), "net_forward: unsupported shape " MOFA_SHAPE_FMT, MOFA_SHAPE_ARGS(s));
     MOFA_REQUIRE(packed && folded && workspace && raw_out, "net_forward: null pointer");
     MOFA_REQUIRE(!(tape && mask_tape), "net_forward: give the fp32 tape OR the mask-only tape, not both");
@@ -404,20 +436,21 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     // device mofa_device_init() found eight populated XCDs on (no census yet: per-layer launches; nothing here allocates or synchronises).
     // (MOFA_CHAIN=0: per-layer launches — the bit-identical reference form; MOFA_PIPE=0 implies it)
     auto chain_ok = [&]() {
-        if (config().chain == 0 || config().pipe == 0 || steps.size() > MOFA_MAX_CHAIN_STEPS) return false;
+        if (force_chain == 0 || steps.size() > MOFA_MAX_CHAIN_STEPS) return false;
+        if (force_chain < 0 && (config().chain == 0 || config().pipe == 0)) return false;
         for (const Step& st : steps) {
             const Layer& l = p.L[st.li];
             const int kt = l.k_padded[0] / 16 + (st.x2 ? l.k_padded[1] / 16 : 0);
             if (l.n_padded % 128 != 0 || kt < 4 || (kt & 1)) return false;
             if (!st.x1 && (l.n_padded < 512 || st.y == t1)) return false;     // layer 0 through k_pe_panels, as below
         }
-        return mofa_internal_chain_capable(stream) == 1;
+        return force_chain == 1 || mofa_internal_chain_capable(stream) == 1;
     };
     // ---- dispatch: one persistent launch for widths <= 256 (every layer of a point tile lives in one workgroup); wider networks: one
     //      chained launch over the tiles of every layer (inference), else one launch per layer.  MOFA_FUSED=0/1 and MOFA_CHAIN=0 override
     //      the choice (tests / A-B).
     const Config& cfg = config();
-    const bool fused = cfg.fused >= 0 ? cfg.fused == 1 : (p.Wp <= 256 && Mp / kRowTile >= 128);
+    const bool fused = force_chain < 0 && (cfg.fused >= 0 ? cfg.fused == 1 : (p.Wp <= 256 && Mp / kRowTile >= 128));
     if (fused) {
         const float* arena = tape ? tape : workspace;
         const int n = (int)steps.size();
@@ -501,6 +534,90 @@ int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, c
     }
     // a chained launch that did not finish every tile (a wait abandoned, an unworked queue) must not look like a result: NaN + verdict
     if (chain_state) MOFA_TRY(mofa_internal_chain_verify(chain_state, chain_tiles, verdict, raw_out, M * 4, nullptr, 0, nullptr, 0, nullptr, 0, stream));
+    return MOFA_OK;
+}
+
+int mofa_net_forward(MofaNetShape s, const float* packed, const float* folded, const float* view_w,
+                     const float* view_b, const float* rays_o, const float* rays_d, const float* z, int64_t z_row_stride,
+                     const float* pts, const float* viewdirs, int64_t n_rays, int32_t S, float* workspace,
+                     float* raw_out, float* tape, uint64_t* mask_tape, const float* view_bias_rows, uint32_t* verdict, void* stream) {
+    return net_forward(s, packed, folded, view_w, view_b, rays_o, rays_d, z, z_row_stride, pts, viewdirs, n_rays, S, workspace, raw_out, tape,
+                       mask_tape, view_bias_rows, verdict, stream, -1);
+}
+
+// ---- the chained launch's self-check (mofa_device_init) ---------------------------------------------------------
+// k_chain_verify sees an INCOMPLETE chained launch; it cannot see a launch that finished every tile on STALE inputs.  The protocol's
+// visibility leg (plain stores + vmcnt(0) + barrier + a relaxed agent-scope counter bump; consumers fetch with sc1 LDS-DMA loads
+// served by the XCD's L2) is a micro-architectural contract of this part, not a release / acquire pair the language guarantees — if a
+// driver, firmware or partition mode ever breaks it, every tile finishes, the verdict is clean and the pixels are plausibly wrong.
+// So the contract is CHECKED once per device and process, where the census is taken: a fixed 10 x 512 network on 4,096 points (16 row
+// tiles — two per XCD, so nearly every tile waits on a dependency and fetches what another workgroup has just stored) runs twice
+// chained and twice per layer on two point sets through the SAME recycled workspace (the second chained run reads buffers that hold
+// the first run's different activations: a stale line cannot go unnoticed), and the raw outputs are compared bit for bit on the
+// device.  Any difference, any NaN, a raised verdict: this device takes the per-layer launches (bit-identical, ~1 % slower) and
+// mofa_device_init reports it.  Weights / biases / points are generated on the device (hashed uniform values, Xavier-scaled).
+// internal (mofa_device_init): *ok = 1 the chained launch reproduces the per-layer launches bit for bit on this device, 0 = it does not
+// (the text says how).  Allocates, launches, synchronises `stream`, frees.
+int mofa_internal_chain_selfcheck(void* stream, int* ok, char* why, size_t why_len) {
+    hipStream_t st = (hipStream_t)stream;
+    const MofaNetShape s{10, 512, MOFA_DEFAULT_PE_POINT_FREQS, MOFA_DEFAULT_PE_VIEW_FREQS, MOFA_DEFAULT_CH_EXP, MOFA_DEFAULT_CH_SHAPE, MOFA_DEFAULT_CH_TEX};
+    const Plan p = make_plan(s);
+    const int64_t R = 32, S = 128, M = R * S;                      // 16 row tiles
+    const size_t n_packed = (size_t)round_up((int64_t)p.packed_floats, 64), n_folded = (size_t)round_up((int64_t)p.folded_floats, 64);
+    const size_t n_ws = (size_t)round_up((int64_t)mofa_net_workspace_floats(s, M, R), 64), n_vb = (size_t)R * p.Hp, n_pts = (size_t)M * 3, n_raw = (size_t)M * 4;
+    const size_t total = n_packed + n_folded + n_ws + n_vb + 2 * n_pts + 4 * n_raw + 64;
+    float* base = nullptr;
+    *ok = 0;
+    if (hipMalloc((void**)&base, total * sizeof(float)) != hipSuccess) {
+        (void)hipGetLastError();
+        snprintf(why, why_len, "the self-check could not allocate %zu MiB", total * sizeof(float) >> 20);
+        return MOFA_OK;                                              // (not an error of the device: the per-layer launches need nothing)
+    }
+    float* packed = base;
+    float* folded = packed + n_packed;
+    float* ws = folded + n_folded;
+    float* vb = ws + n_ws;
+    float* pts[2] = {vb + n_vb, vb + n_vb + n_pts};
+    float* raw[4] = {pts[1] + n_pts, pts[1] + n_pts + n_raw, pts[1] + n_pts + 2 * n_raw, pts[1] + n_pts + 3 * n_raw};   // per-layer A, B; chained A, B
+    unsigned* words = (unsigned*)(raw[3] + n_raw);                 // [0..7] a verdict, [8..15] compare A, [16..23] compare B
+    auto fill = [&](float* q, size_t n, unsigned seed, float scale, float off) {
+        hipLaunchKernelGGL(k_selfcheck_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, q, (long long)n, seed, scale, off);
+    };
+    int rc = MOFA_OK;
+    fill(packed, n_packed, 0x1234u, 0.108f, 0.f);                  // ~ Xavier-uniform with the ReLU gain at fan-in = fan-out = 512
+    fill(folded, n_folded, 0x2345u, 0.05f, 0.05f);
+    fill(vb, n_vb, 0x3456u, 0.05f, 0.05f);
+    fill(pts[0], n_pts, 0x4567u, 3.0f, 0.f);
+    fill(pts[1], n_pts, 0x5678u, 3.0f, 0.f);
+    if (hipMemsetAsync(words, 0, 64 * sizeof(unsigned), st) != hipSuccess) rc = check_launch("hipMemsetAsync(self-check)");
+    // per-layer A, chained B, chained A (its buffers hold B's activations), per-layer B
+    const int order[4][3] = {{0, 0, 0}, {1, 1, 3}, {1, 0, 2}, {0, 1, 1}};   // {force_chain, point set, raw slot}
+    for (int i = 0; i < 4 && rc == MOFA_OK; ++i)
+        rc = net_forward(s, packed, folded, nullptr, nullptr, nullptr, nullptr, nullptr, 0, pts[order[i][1]], nullptr, R, (int32_t)S, ws,
+                         raw[order[i][2]], nullptr, nullptr, vb, words, st, order[i][0]);
+    if (rc == MOFA_OK) {
+        if (hook_selfcheck_poison()) hipLaunchKernelGGL(k_selfcheck_poison, dim3(1), dim3(1), 0, st, (unsigned*)raw[2] + 5);
+        const unsigned blocks = (unsigned)((n_raw + 255) / 256);
+        hipLaunchKernelGGL(k_selfcheck_compare, dim3(blocks), dim3(256), 0, st, (const unsigned*)raw[2], (const unsigned*)raw[0], (long long)n_raw, words + 8);
+        hipLaunchKernelGGL(k_selfcheck_compare, dim3(blocks), dim3(256), 0, st, (const unsigned*)raw[3], (const unsigned*)raw[1], (long long)n_raw, words + 16);
+        rc = check_launch("k_selfcheck_compare");
+    }
+    unsigned host[24] = {};
+    if (rc == MOFA_OK && (hipMemcpyAsync(host, words, sizeof(host), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
+        rc = check_launch("self-check read-back");
+    else if (rc != MOFA_OK) (void)hipStreamSynchronize(st);
+    (void)hipFree(base);
+    if (rc != MOFA_OK) return rc;
+    const unsigned diff = host[8] + host[16], nonfinite = host[9] + host[17], alive = host[10] < host[18] ? host[10] : host[18];
+    if (host[0] != 0u || host[1] != 2u)
+        snprintf(why, why_len, "the self-check's chained launches did not complete (verdict %u, %u of 2 verified)", host[0], host[1]);
+    else if (nonfinite != 0u || alive < n_raw / 2)
+        snprintf(why, why_len, "the self-check's network produced %u non-finite and %u non-zero of %zu outputs", nonfinite, alive, n_raw);
+    else if (diff != 0u)
+        snprintf(why, why_len, "the chained launch differs from the per-layer launches in %u of %zu output words (inter-workgroup visibility "
+                               "through the XCD's L2 does not hold on this device)", diff, 2 * n_raw);
+    else
+        *ok = 1;
     return MOFA_OK;
 }
 

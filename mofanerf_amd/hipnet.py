@@ -6,6 +6,7 @@ current stream.
 """
 from __future__ import annotations
 
+import threading
 import weakref
 from typing import Optional
 
@@ -68,12 +69,16 @@ class HipNet:
         else:
             self._init_plan(net, point_freqs)
         # launch verdicts (include/mofanerf_hip.h, MOFA_VERDICT_WORDS): sticky words on the device that the verification kernel behind
-        # every chained launch raises, an asynchronous pinned mirror, and the event that says the mirror is current
+        # every chained launch raises, an asynchronous pinned mirror, and the event that says the mirror is current.  The mirror is
+        # written by copies enqueued on ONE stream at a time (the stream the caller runs on; side streams of the multi-stream
+        # inference path do not snapshot — the renderer does, on the main stream after it has joined them), and the state is
+        # guarded by a lock: the PNG sink's workers look at per-frame tokens (verdict_token) of their own, never at this mirror.
         self._verdict: Optional[torch.Tensor] = None
         self._verdict_host: Optional[torch.Tensor] = None
         self._verdict_event: Optional[torch.cuda.Event] = None
+        self._verdict_lock = threading.Lock()
         if torch.cuda.is_available() and next(net.parameters()).is_cuda:
-            lib.device_init(next(net.parameters()).device)       # the XCD census (the library's one synchronising call) — here, not in a forward
+            lib.device_init(next(net.parameters()).device)       # census + self-check (the library's one synchronising call) — here, not in a forward
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
         self._folded: Optional[torch.Tensor] = None
@@ -123,49 +128,82 @@ class HipNet:
         if device.type == "cuda" and device.index is None:       # "cuda" = the current device: compare like with like
             device = torch.device("cuda", torch.cuda.current_device())
         if self._verdict is None or self._verdict.device != device:
-            self._verdict = torch.zeros(lib.VERDICT_WORDS, dtype=torch.int32, device=device)
-            self._verdict_host = torch.zeros(lib.VERDICT_WORDS, dtype=torch.int32).pin_memory()
-            self._verdict_event = None
+            # a network built on the CPU and moved with .cuda() afterwards meets its device HERE for the first time: take the per-device
+            # initialisation now (cached per device and process: later calls cost a dictionary look-up), or the wide networks would
+            # stay on the per-layer launches for the life of the process
+            lib.device_init(device)
+            with self._verdict_lock:
+                self._verdict = torch.zeros(lib.VERDICT_WORDS, dtype=torch.int32, device=device)
+                self._verdict_host = torch.zeros(lib.VERDICT_WORDS, dtype=torch.int32).pin_memory()
+                self._verdict_event = None
         return self._verdict.data_ptr()
 
     def snapshot_verdict(self) -> None:
-        """Enqueue a copy of the verdict words into the pinned mirror behind the launches issued so far (no host synchronisation)."""
+        """Enqueue a copy of the verdict words into the pinned mirror behind the launches issued so far ON THE CURRENT STREAM (no host
+        synchronisation)."""
         if self._verdict is None:
             return
-        self._verdict_host.copy_(self._verdict, non_blocking=True)
-        if self._verdict_event is None:
-            self._verdict_event = torch.cuda.Event()
-        self._verdict_event.record()
+        with self._verdict_lock:
+            self._verdict_host.copy_(self._verdict, non_blocking=True)
+            if self._verdict_event is None:
+                self._verdict_event = torch.cuda.Event()
+            self._verdict_event.record()
+
+    def _raise_incomplete(self, w) -> None:
+        raise lib.MofaError(f"a chained launch (k_net_chain) of {self.shape} did not complete: "
+                            f"{'a dependency wait timed out; ' if w[0] & 1 else ''}{'tiles missing; ' if w[0] & 2 else ''}"
+                            f"last launch finished {w[3]} of {w[4]} tiles, {w[5]} bad of {w[1]} chained launches — its outputs were "
+                            "overwritten with NaN.  (A CU-masked stream or a changed compute partition leaves XCD queues unworked; "
+                            "MOFA_CHAIN=0 selects the per-layer launches.)")
 
     def check_verdict(self, block: bool = False) -> None:
         """Raise ``MofaError`` if a chained launch of this network ended incomplete (its outputs were overwritten with NaN by the
         verification kernel).  ``block=False`` looks only if the last snapshot has already arrived — the form the launch paths use before
         every call, so a failure surfaces at the next call at the latest without ever stalling the host; ``block=True`` waits for it
-        (end of a frame's consumer: PNG hand-off, bench, tests)."""
-        ev = self._verdict_event
-        if ev is None:
-            return
-        if block:
-            ev.synchronize()
-        elif not ev.query():
-            return
-        w = self._verdict_host.tolist()
-        if w[0] != 0:
+        (end of a frame's consumer: bench, tests, ``render_path``).  Call it from the thread that issues the launches: on a failure it
+        re-arms the sticky device words (an enqueue on the current stream)."""
+        with self._verdict_lock:
+            ev = self._verdict_event
+            if ev is None:
+                return
+            if block:
+                ev.synchronize()
+            elif not ev.query():
+                return
+            w = self._verdict_host.tolist()
+            if w[0] == 0:
+                return
             self._verdict.zero_()
             self._verdict_event = None
-            raise lib.MofaError(f"a chained launch (k_net_chain) of {self.shape} did not complete: "
-                                f"{'a dependency wait timed out; ' if w[0] & 1 else ''}{'tiles missing; ' if w[0] & 2 else ''}"
-                                f"last launch finished {w[3]} of {w[4]} tiles, {w[5]} bad of {w[1]} chained launches — its outputs were "
-                                "overwritten with NaN.  (A CU-masked stream or a changed compute partition leaves XCD queues unworked; "
-                                "MOFA_CHAIN=0 selects the per-layer launches.)")
+        self._raise_incomplete(w)
+
+    def verdict_token(self):
+        """A per-FRAME look at the verdict words, for a consumer on another thread (the PNG sink's workers): the words are copied into a
+        pinned buffer of the token's own behind everything issued on the current stream so far, with an event of its own.  ``token()``
+        waits for THAT copy and raises ``MofaError`` if a chained launch before it ended incomplete — pure host work on state nobody
+        else touches (the shared mirror above belongs to the launching thread).  Returns ``None`` when this network never launched."""
+        if self._verdict is None:
+            return None
+        host = torch.empty(lib.VERDICT_WORDS, dtype=torch.int32).pin_memory()
+        host.copy_(self._verdict, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+
+        def look():
+            ev.synchronize()
+            w = host.tolist()
+            if w[0] != 0:
+                self._raise_incomplete(w)
+        return look
 
     def chained_launches(self, block: bool = True) -> int:
         """Number of chained launches verified so far (tests: was the chained form really taken?)."""
         self.snapshot_verdict()
-        if self._verdict_event is None:
-            return 0
-        self._verdict_event.synchronize()
-        return int(self._verdict_host[1])
+        with self._verdict_lock:
+            if self._verdict_event is None:
+                return 0
+            self._verdict_event.synchronize()
+            return int(self._verdict_host[1])
 
     def invalidate(self):
         """Forget the packed / transposed copies of the weights (they are rebuilt on the next call).  Needed only
@@ -211,8 +249,8 @@ class HipNet:
             self._packed_t_key = key
         return self._packed_t
 
-    def backward_workspace(self, n_points: int, device) -> torch.Tensor:
-        n = self._L.mofa_net_backward_workspace_floats(self.shape, n_points)
+    def backward_workspace(self, n_points: int, device, with_weight_grads: bool = False) -> torch.Tensor:
+        n = self._L.mofa_net_backward_workspace_floats(self.shape, n_points, int(bool(with_weight_grads)))
         if self._bws is None or self._bws.numel() < n or self._bws.device != device:
             self._bws = torch.empty(n, dtype=torch.float32, device=device)
         return self._bws
@@ -374,8 +412,10 @@ class HipNet:
 
     # -- forward -----------------------------------------------------------------------------------
     def forward_rays(self, rays_o, rays_d, z, z_row_stride: int, viewdirs, S: int, raw_out: torch.Tensor,
-                     folded: Optional[torch.Tensor] = None, slot: int = 0):
-        """raw_out[R,S,4] = NeRF(PE(o + d z), codes, PE(viewdirs)) for R rays x S samples."""
+                     folded: Optional[torch.Tensor] = None, slot: int = 0, snapshot: bool = True):
+        """raw_out[R,S,4] = NeRF(PE(o + d z), codes, PE(viewdirs)) for R rays x S samples.  ``snapshot=False``: a call on a SIDE
+        stream — the caller snapshots the verdict words itself, on the main stream, once it has joined the side streams (two streams
+        writing the one pinned mirror could overwrite a raised flag with an older, clean copy)."""
         R = viewdirs.shape[0]
         view = self._linears[-3]
         ws = self.workspace(R * S, R, viewdirs.device, slot)
@@ -387,7 +427,8 @@ class HipNet:
                                            lib.ptr(z), z_row_stride, None, lib.ptr(viewdirs), R, S, lib.ptr(ws),
                                            lib.ptr(raw_out), None, None, None, self.verdict_ptr(viewdirs.device), lib.stream()),
                   "mofa_net_forward")
-        self.snapshot_verdict()
+        if snapshot:
+            self.snapshot_verdict()
         return raw_out
 
     def forward_points(self, pts, viewdirs, S: int, raw_out: torch.Tensor, folded: Optional[torch.Tensor] = None):

@@ -36,19 +36,21 @@ class PngSink:
     def __init__(self, workers: int = 2):
         self._pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="png")
         self._pending = []
+        self.high_water = 0      # most frames ever waiting for / in a worker at a submit (bench.py reports it: is the sink keeping up?)
 
     @staticmethod
     def _job(path, host, event, check=None):
         if event is not None:
             event.synchronize()                          # the D2H copy of THIS frame only
         if check is not None:
-            check()                                      # the launches behind this frame are done: their verdict has arrived with it
+            check()                                      # this frame's own verdict snapshot (taken before its copy was enqueued)
         write_png(path, host.numpy() if torch.is_tensor(host) else host)
 
     def submit(self, path: str, rgb, check=None) -> None:
         """``check``: optional callable run on the worker once this frame's copy has landed, before the file is written — the renderer
-        passes its launch-verdict check, so a frame whose chained launch ended incomplete (NaN-poisoned) raises instead of becoming a
-        PNG (the error surfaces at ``close()``)."""
+        passes ``Renderer.frame_check()``: a snapshot of the launch-verdict words taken for THIS frame (own pinned buffer, own event,
+        enqueued behind the frame's launches and before its copy), so a frame whose chained launch ended incomplete (NaN-poisoned)
+        raises instead of becoming a PNG (the error surfaces at ``close()``).  It must be safe on a worker thread: host-side only."""
         event = None
         if torch.is_tensor(rgb):
             q = (255 * rgb.detach().clamp(0, 1)).to(torch.uint8)
@@ -62,6 +64,7 @@ class PngSink:
         else:
             host = (255 * np.clip(rgb, 0, 1)).astype(np.uint8)
         self._pending.append(self._pool.submit(self._job, path, host, event, check))
+        self.high_water = max(self.high_water, sum(1 for f in self._pending if not f.done()))
 
     def close(self) -> None:
         pending, self._pending = self._pending, []

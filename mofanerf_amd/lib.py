@@ -19,7 +19,7 @@ _fp = C.c_void_p      # device pointers travel as integers
 _i32, _i64, _sz = C.c_int32, C.c_int64, C.c_size_t
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class NetShape(C.Structure):
@@ -41,7 +41,8 @@ SIGNATURES = {
     "mofa_abi_version": (C.c_int, []),
     "mofa_last_error": (C.c_char_p, []),
     "mofa_config_reload": (C.c_int, []),
-    "mofa_device_init": (C.c_int, [_fp, C.POINTER(_i32)]),
+    "mofa_test_hooks": (C.c_int, [C.c_uint32, _i32, _i32]),
+    "mofa_device_init": (C.c_int, [_fp, C.POINTER(_i32), C.POINTER(_i32)]),
     "mofa_net_num_layers": (C.c_int, [NetShape]),
     "mofa_net_layer_dims": (C.c_int, [NetShape, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "mofa_pe_k_padded": (C.c_int, [_i32]),
@@ -55,7 +56,7 @@ SIGNATURES = {
     "mofa_net_packed_t_floats": (_sz, [NetShape]),
     "mofa_net_tape_floats": (_sz, [NetShape, _i64]),
     "mofa_net_mask_tape_words": (_sz, [NetShape, _i64]),
-    "mofa_net_backward_workspace_floats": (_sz, [NetShape, _i64]),
+    "mofa_net_backward_workspace_floats": (_sz, [NetShape, _i64, _i32]),
     "mofa_net_pack_t": (C.c_int, [NetShape, C.POINTER(_fp), _fp, _fp]),
     "mofa_net_backward": (C.c_int, [NetShape, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i64, _fp, _i64, _i32, _fp, _fp, _fp, _fp,
                                     _fp, _fp, C.POINTER(_fp), _fp, _fp]),
@@ -132,26 +133,50 @@ def load() -> C.CDLL:
     return _lib
 
 
-PROF_KINDS = 7     # MOFA_PROF_KINDS: k_layer fwd, k_mlp_fused, k_layer<BWD>, k_wgrad, k_layer fwd with per-ray bias (view layer), k_net_chain fwd, k_net_chain bwd
+PROF_KINDS = 11    # MOFA_PROF_KINDS: k_layer fwd, k_mlp_fused, k_layer<BWD>, k_wgrad, k_layer fwd with per-ray bias (view layer), k_net_chain<0> fwd,
+                   # k_net_chain<2> bwd, k_net_chain<1> fwd + mask, and the HBM-bound ray kernels k_composite<1>, k_composite<2>, k_sample_pdf_merge
 VERDICT_WORDS = 8  # MOFA_VERDICT_WORDS
 
 
+class MofaWarning(UserWarning):
+    """A condition the library works around (never a wrong result): e.g. a device whose chained-launch self-check failed takes the
+    per-layer launches."""
+
+
 _device_census = {}     # device index -> workgroups seen per XCD by mofa_device_init
+_device_selfcheck = {}  # device index -> 1 (the chained launch reproduces the per-layer launches), 0 (it does not: per-layer launches), -1 (not run)
 
 
 def device_init(device=None):
     """``mofa_device_init`` for ``device`` (default: the current one), once per device and process: the XCD census the chained launch
-    relies on + the persistent kernel's LDS attribute.  This is the library's ONE synchronising call; it belongs where a network is
-    bound to a device (``HipNet.__init__`` / ``Renderer.bind``), never inside a forward.  Returns the census (8 counts)."""
+    relies on, the chained launch's SELF-CHECK (chained vs per-layer launches of a small fixed network, bit for bit, on the device)
+    and the persistent kernel's LDS attribute.  This is the library's ONE synchronising call; it belongs where a network is bound to
+    a device (``HipNet`` / ``Renderer.bind``), never inside a forward.  A device that fails either check takes the per-layer
+    launches (bit-identical, ~1 % slower) and a ``MofaWarning`` says why.  Returns the census (8 counts)."""
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
     if idx is None:
         idx = torch.cuda.current_device()
     if idx not in _device_census:
-        counts = (_i32 * 8)()
+        counts, ok = (_i32 * 8)(), _i32(-1)
         with torch.cuda.device(idx):
-            check(load().mofa_device_init(torch.cuda.current_stream(idx).cuda_stream, counts), "mofa_device_init")
-        _device_census[idx] = list(counts)
+            check(load().mofa_device_init(torch.cuda.current_stream(idx).cuda_stream, counts, C.byref(ok)), "mofa_device_init")
+        _device_census[idx], _device_selfcheck[idx] = list(counts), int(ok.value)
+        if ok.value != 1:
+            import warnings
+            warnings.warn(f"cuda:{idx}: {load().mofa_last_error().decode()} (bit-identical results, about 1 % slower)", MofaWarning, stacklevel=2)
     return _device_census[idx]
+
+
+def chain_selfcheck(device=None) -> int:
+    """1 / 0 / -1 as ``mofa_device_init`` reported it for ``device`` (taking the initialisation if it has not run yet)."""
+    device_init(device)
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    return _device_selfcheck[torch.cuda.current_device() if idx is None else idx]
+
+
+def test_hooks(chain_spin_limit: int = 0, chain_skip_xcd: int = -1, selfcheck_poison: bool = False) -> None:
+    """``mofa_test_hooks`` (tests / tools only): force the chained launch's failure paths.  Defaults restore the shipped behaviour."""
+    check(load().mofa_test_hooks(int(chain_spin_limit), int(chain_skip_xcd), int(bool(selfcheck_poison))), "mofa_test_hooks")
 
 
 def reload_env() -> None:

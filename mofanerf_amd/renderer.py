@@ -188,6 +188,16 @@ class Renderer(torch.nn.Module):
                 self._hip(n)
         return self
 
+    def frame_check(self):
+        """A callable that waits for the launches issued SO FAR on the current stream and raises ``MofaError`` if one of them was a
+        chained launch that ended incomplete — safe to run on another thread (the PNG sink's workers; ``HipNet.verdict_token``)."""
+        looks = [t for t in (h.verdict_token() for h in list(self._hipnets.values())) if t is not None]
+
+        def check():
+            for look in looks:
+                look()
+        return check
+
     def check_launches(self, block: bool = True):
         """Raise ``MofaError`` if any chained launch issued through this renderer ended incomplete (the kernel abandons a launch rather
         than compute on incomplete inputs, and a verification kernel then overwrites the outputs with NaN — see
@@ -227,16 +237,17 @@ class Renderer(torch.nn.Module):
         tools/create_model_condition.py:50).  Under autograd it is differentiable like the reference's: gradients reach
         ``inputs``, ``viewdirs``, the shape / texture / expression codes (through ``self.shapeCodes``, ``self.decoding_texCodes``,
         ``self.expCodes_Sigma``) and the StyleModule — HIP backward (``mofa_net_backward`` with explicit points).  The network WEIGHTS
-        take part when ``weight_grads`` says so: ``True`` / ``False`` explicitly, ``None`` = what the last ``render()`` (on) /
-        ``render_fitting()`` (``fit_weight_grads``) chose — and only those that ``requires_grad``.  The tape-keeping path is taken only
-        if something actually asks for a gradient: a plain call outside ``no_grad`` whose inputs, codes and (participating) weights
-        all have ``requires_grad=False`` runs the inference kernels and keeps nothing."""
+        take part exactly as in an autograd graph: ``weight_grads=None`` (default) = those that ``requires_grad`` — a property of the
+        call's arguments alone, not of whatever ``render()`` / ``render_fitting()`` ran before it (round 5 defaulted to the last
+        entry point's choice: call-history-dependent); ``False`` leaves them out (a fitting loop that never steps the networks saves
+        the weight-gradient GEMMs and the fp32 tape), ``True`` is the same as ``None``.  The tape-keeping path is taken only if
+        something actually asks for a gradient: a plain call outside ``no_grad`` whose inputs, codes and (participating) weights all
+        have ``requires_grad=False`` runs the inference kernels and keeps nothing."""
         if viewdirs is None:
             raise NotImplementedError(_NO_VIEWDIRS)
         R, S = int(inputs.shape[0]), int(inputs.shape[1])
         h = self._hip(fn)
-        want_w = (self._weight_grads if weight_grads is None else bool(weight_grads)) and any(l.weight.requires_grad or l.bias.requires_grad
-                                                                                                 for l in h._linears)
+        want_w = (weight_grads is None or bool(weight_grads)) and any(l.weight.requires_grad or l.bias.requires_grad for l in h._linears)
         rg = lambda t: torch.is_tensor(t) and t.requires_grad
         needs_grad = torch.is_grad_enabled() and (want_w or rg(inputs) or rg(viewdirs) or rg(self.shapeCodes) or rg(self.decoding_texCodes) or
                                                   rg(self.expCodes_Sigma[self.expType]) or
@@ -400,9 +411,10 @@ class Renderer(torch.nn.Module):
                 j = min(R, i + rays_per)
                 with torch.cuda.stream(side[k % n_str]):
                     h.forward_rays(rays_o[i:j], rays_d[i:j], zv[i:j] if zs else zv, zs, vd[i:j], n_s, raw[i:j], folded,
-                                   slot=k % n_str)
+                                   slot=k % n_str, snapshot=False)
             for s_ in side:
                 main.wait_stream(s_)
+            h.snapshot_verdict()       # ONE snapshot, on the main stream, behind every side stream's launches
             return raw
 
         if getattr(self, "_rays_ref", None) is not self.rays and not getattr(self, "_folds_hoisted", False):
@@ -576,7 +588,10 @@ class Renderer(torch.nn.Module):
                                                        shapeCodes=shapeCodes[i, :].reshape(1, -1), uvMap=uvMap[i, :],
                                                        expType=expType[i], **render_kwargs)
                 if savedir is not None:
-                    sink.submit(out_file(i), rgb, check=lambda: self.check_launches(block=False))
+                    # the verdict of THIS frame's launches travels with the frame: a snapshot + event of its own, taken here (after the
+                    # frame's launches, before its copy), which the worker waits for before it writes the file (the shared
+                    # mirror's event usually belonged to a LATER frame by the time the worker looked)
+                    sink.submit(out_file(i), rgb, check=self.frame_check())
                 frames.append(rgb.detach())
                 disparities.append(disp.detach())
         finally:

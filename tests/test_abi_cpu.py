@@ -44,7 +44,7 @@ def test_library_exports_nothing_but_the_declared_abi():
 
 def test_plan_sizes_and_argument_validation():
     L = lib.load()
-    assert L.mofa_abi_version() == 4 == lib.ABI_VERSION
+    assert L.mofa_abi_version() == 5 == lib.ABI_VERSION
     for D, W in ((8, 256), (10, 1024), (8, 64)):
         s = lib.NetShape(D, W)
         assert L.mofa_net_num_layers(s) == 2 * D + 7 == len(schema.nerf_layers(D, W))
@@ -56,6 +56,9 @@ def test_plan_sizes_and_argument_validation():
         # four activation buffers, the per-ray bias rows, and k_net_chain's queue state (8 heads x 32 words, 32 status words, a counter per row tile, 32 spare)
         assert L.mofa_net_workspace_floats(s, 1000, 10) == 4 * 1024 * Wp + 10 * Hp + 64 + (8 * 32 + 32 + 1024 // 256 + 32)
         assert L.mofa_net_mask_tape_words(s, 1000) * 64 == L.mofa_net_tape_floats(s, 1000)      # one bit per tape float
+        # training does not pay for the three gradient buffers + two queue states only the chained FITTING backward keeps
+        fit_ws, train_ws = L.mofa_net_backward_workspace_floats(s, 1000, 0), L.mofa_net_backward_workspace_floats(s, 1000, 1)
+        assert fit_ws - train_ws >= 3 * 1024 * Wp, (fit_ws, train_ws)
     assert L.mofa_net_num_layers(lib.NetShape(3, 256)) == -1
     assert L.mofa_net_num_layers(lib.NetShape(8, 256, pe_point_freqs=17)) == -1
     assert L.mofa_net_num_layers(lib.NetShape(8, 256, ch_tex=-1)) == -1
@@ -133,8 +136,26 @@ def test_profiler_kinds_agree_between_header_binding_and_bench():
     n = int(re.search(r"#define MOFA_PROF_KINDS (\d+)", hdr).group(1))
     sys.path.insert(0, ROOT)
     import bench
-    assert n == lib.PROF_KINDS == len(bench.KERNELS) == 7
+    assert n == lib.PROF_KINDS == len(bench.KERNELS) == 11
     assert bench.KERNELS[5][0] == "mofa::k_net_chain<0>" and bench.KERNELS[6][0] == "mofa::k_net_chain<2>" and bench.KERNELS[1][0] == "mofa::k_mlp_fused"
+    # the mask-writing chained forward is its own kind (the fit line named <0> while <1> ran); the HBM-bound ray kernels follow
+    assert bench.KERNELS[7][0] == "mofa::k_net_chain<1>" and [k[0] for k in bench.KERNELS[8:]] == ["mofa::k_composite<1>", "mofa::k_composite<2>",
+                                                                                                 "mofa::k_sample_pdf_merge<false>"]
+    assert set(bench.HBM_KINDS) == {8, 9, 10} and all(bench.HBM_KINDS[k] > 1000 for k in bench.HBM_KINDS)
+
+
+def test_failure_hooks_are_an_entry_point_not_environment_variables():
+    """the two hooks that force k_net_chain's failure paths (and the self-check's mismatch) are set through
+    mofa_test_hooks() only — the built library no longer even contains the names of the round-5 environment variables."""
+    L = lib.load()
+    assert L.mofa_test_hooks(0, -1, 0) == 0 and L.mofa_test_hooks(7, 3, 1) == 0 and L.mofa_test_hooks(0, -1, 0) == 0
+    assert L.mofa_test_hooks(0, 8, 0) == -1 and b"chain_skip_xcd" in L.mofa_last_error()
+    assert L.mofa_test_hooks(0, -2, 0) == -1
+    blob = open(build.build(), "rb").read()
+    for name in (b"MOFA_CHAIN_SPIN_LIMIT", b"MOFA_CHAIN_TEST_SKIP_XCD"):
+        assert name not in blob, name
+    for name in (b"MOFA_PIPE", b"MOFA_FUSED", b"MOFA_CHAIN"):          # the three knobs that choose between bit-identical forms are still read
+        assert name in blob, name
 
 
 def test_product_never_imports_the_oracle():

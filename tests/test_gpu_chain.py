@@ -31,12 +31,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _shipped_launch_forms(monkeypatch):
     """These tests are ABOUT the chained launch: whatever MOFA_* knob the surrounding run exports (the suite is also run under
     MOFA_PIPE=0 / MOFA_CHAIN=0 / MOFA_FUSED=0), they start from the shipped forms and set what they vary themselves."""
-    for k in ("MOFA_PIPE", "MOFA_CHAIN", "MOFA_FUSED", "MOFA_CHAIN_SPIN_LIMIT", "MOFA_CHAIN_TEST_SKIP_XCD"):
+    for k in ("MOFA_PIPE", "MOFA_CHAIN", "MOFA_FUSED"):
         monkeypatch.delenv(k, raising=False)
     lib.reload_env()
+    lib.test_hooks()                    # the shipped behaviour (the failure paths are reached through mofa_test_hooks only)
     yield
     monkeypatch.undo()
     lib.reload_env()
+    lib.test_hooks()
 
 
 def dev(a):
@@ -160,9 +162,9 @@ def test_training_backward_keeps_the_per_layer_form_and_agrees(knob):
         assert torch.isfinite(a).all() and torch.equal(a, b), k
 
 
-def test_a_dependency_wait_out_of_budget_is_loud_not_wrong(knob):
+def test_a_dependency_wait_out_of_budget_is_loud_not_wrong():
     """a wait that runs out of budget used to set a bit nobody read and COMPUTE ON INCOMPLETE INPUTS.  Now: with the
-    poll budget forced to one poll (MOFA_CHAIN_SPIN_LIMIT=1; 8 row tiles against 512 workgroups, so most workgroups draw tickets of
+    poll budget forced to one poll (mofa_test_hooks(chain_spin_limit = 1); 8 row tiles against 512 workgroups, so most workgroups draw tickets of
     layers whose inputs cannot be complete yet) the workgroups abandon the launch, the verification kernel overwrites raw — and the
     gradients of a fitting step — with NaN, and the host raises MofaError at its next look; afterwards the network works again."""
     h, o, d, z, vd, folded, vb, G = _setup(10, 1024, 16, 128)
@@ -177,7 +179,7 @@ def test_a_dependency_wait_out_of_budget_is_loud_not_wrong(knob):
     ref = run()
     h.check_verdict(block=True)
     assert torch.isfinite(ref).all()
-    knob("MOFA_CHAIN_SPIN_LIMIT", "1")
+    lib.test_hooks(chain_spin_limit=1)
     bad = run()
     assert torch.isnan(bad).all()                                             # never a plausible-looking result
     with pytest.raises(lib.MofaError, match="did not complete.*timed out"):
@@ -197,17 +199,17 @@ def test_a_dependency_wait_out_of_budget_is_loud_not_wrong(knob):
     assert all(torch.isnan(t.grad).all() for t in (og, dg, fo, vbg))
     with pytest.raises(lib.MofaError, match="did not complete"):
         h.check_verdict(block=True)
-    knob("MOFA_CHAIN_SPIN_LIMIT", str(1 << 22))
+    lib.test_hooks()
     again = run()
     h.check_verdict(block=True)
     assert torch.equal(again, ref)
 
 
 @pytest.mark.parametrize("xcd", [0, 5])
-def test_an_unworked_xcd_queue_is_loud_not_wrong(xcd, knob):
+def test_an_unworked_xcd_queue_is_loud_not_wrong(xcd):
     """ADVICE r4 medium, made deterministic: an XCD that receives no workgroups (a CU-masked stream, a partition change after the census)
     leaves its row tiles unwritten while every other XCD finishes normally — nobody waits across XCDs, so nothing times out.  With the
-    workgroups of one XCD sent home at once (MOFA_CHAIN_TEST_SKIP_XCD) the launch must END, raw must be NaN (not the stale workspace
+    workgroups of one XCD sent home at once (mofa_test_hooks(chain_skip_xcd = x)) the launch must END, raw must be NaN (not the stale workspace
     contents the heads would otherwise read) and the verdict must say "tiles missing" without a time-out; the fitting backward too."""
     h, o, d, z, vd, folded, vb, G = _setup(10, 1024, 40, 128)
     R, S = 40, 128
@@ -215,7 +217,7 @@ def test_an_unworked_xcd_queue_is_loud_not_wrong(xcd, knob):
     h.forward_rays(o, d, z, S, vd, S, ref, folded)
     torch.cuda.synchronize()
     h.check_verdict(block=True)
-    knob("MOFA_CHAIN_TEST_SKIP_XCD", str(xcd))
+    lib.test_hooks(chain_skip_xcd=xcd)
     out = torch.zeros(R, S, 4, device=DEV)
     h.forward_rays(o, d, z, S, vd, S, out, folded)
     torch.cuda.synchronize()
@@ -231,7 +233,7 @@ def test_an_unworked_xcd_queue_is_loud_not_wrong(xcd, knob):
     assert all(torch.isnan(t.grad).all() for t in (og, dg, fo, vbg))
     with pytest.raises(lib.MofaError, match="tiles missing"):
         h.check_verdict(block=True)
-    knob("MOFA_CHAIN_TEST_SKIP_XCD", "-1")
+    lib.test_hooks()
     again = torch.zeros(R, S, 4, device=DEV)
     h.forward_rays(o, d, z, S, vd, S, again, folded)
     torch.cuda.synchronize()
@@ -239,7 +241,7 @@ def test_an_unworked_xcd_queue_is_loud_not_wrong(xcd, knob):
     assert torch.equal(again, ref)
 
 
-def test_renderer_surfaces_an_incomplete_launch(knob, tmp_path):
+def test_renderer_surfaces_an_incomplete_launch(tmp_path):
     """End to end: a frame whose chained launch ended incomplete is NaN, `check_launches()` raises, and `render_path` refuses to
     turn it into a PNG."""
     from harness import make_product
@@ -252,7 +254,7 @@ def test_renderer_surfaces_an_incomplete_launch(knob, tmp_path):
         good = render.render_fitting(16, 16, K, chunk=256, c2w=pose, shapeCodes=bm, uvCodes=tex, expType=20, expCodes=exp, **kw)[0]
         render.check_launches()
         assert torch.isfinite(good).all()
-        knob("MOFA_CHAIN_SPIN_LIMIT", "1")
+        lib.test_hooks(chain_spin_limit=1)
         bad = render.render_fitting(16, 16, K, chunk=256, c2w=pose, shapeCodes=bm, uvCodes=tex, expType=20, expCodes=exp, **kw)[0]
         torch.cuda.synchronize()
         assert torch.isnan(bad).all()
@@ -386,8 +388,9 @@ h.forward_rays(o, d, z, S, vd, S, raw, folded)
 assert h.chained_launches() == 0, "chained launch without a census"
 import os
 real = ctypes.CDLL(lib.LIB_PATH).mofa_device_init
-real.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
-assert real(torch.cuda.current_stream().cuda_stream, None) == 0
+real.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+ok = ctypes.c_int32(-7)
+assert real(torch.cuda.current_stream().cuda_stream, None, ctypes.byref(ok)) == 0 and ok.value == 1, ok.value
 raw2 = torch.zeros(R, S, 4, device="cuda")
 h.forward_rays(o, d, z, S, vd, S, raw2, folded)
 assert h.chained_launches() == 1
@@ -428,3 +431,93 @@ def test_run_network_keeps_nothing_when_nothing_asks_for_a_gradient():
     assert raw_g.grad_fn is not None and float((raw_g.detach() - ref).abs().max()) <= 2e-5 * (1.0 + float(ref.abs().max()))
     raw_g.sum().backward()
     assert torch.isfinite(pts_g.grad).all() and all(p.grad is None for p in fine.parameters())
+
+
+def test_stray_environment_variables_cannot_reach_the_failure_hooks(monkeypatch):
+    """round 5 read its two test hooks from MOFA_CHAIN_* variables, so a stray variable in production turned every
+    wide-network launch into NaN + MofaError.  The hooks are reachable through mofa_test_hooks() only: with both old variables exported
+    (and the knobs re-read) the chained launch runs normally."""
+    h, o, d, z, vd, folded, vb, _ = _setup(10, 1024, 16, 128)
+    monkeypatch.setenv("MOFA_CHAIN_SPIN_LIMIT", "1")
+    monkeypatch.setenv("MOFA_CHAIN_TEST_SKIP_XCD", "off")
+    lib.reload_env()
+    before = h.chained_launches()
+    raw = torch.zeros(16, 128, 4, device=DEV)
+    h.forward_rays(o, d, z, 128, vd, 128, raw, folded)
+    torch.cuda.synchronize()
+    h.check_verdict(block=True)
+    assert h.chained_launches() - before == 1 and torch.isfinite(raw).all()
+
+
+def test_device_init_self_check_passes_and_its_failure_falls_back_loudly(tmp_path):
+    """k_chain_verify sees an incomplete launch, not a stale read — so the chained launch's visibility
+    contract is CHECKED per device in mofa_device_init (chained vs per-layer launches of a fixed 10 x 512 network, bit for bit, on the
+    device).  Here: (1) the check passes on this MI355X; (2) in a fresh process with the compare poisoned (mofa_test_hooks) the device is
+    marked "per-layer launches", a MofaWarning says why, NO chained launch runs — and the frame equals this process's chained one
+    bit for bit (the fallback is the bit-identical form, not an approximation)."""
+    assert lib.chain_selfcheck(DEV) == 1
+    h, o, d, z, vd, folded, vb, _ = _setup(10, 1024, 24, 128)
+    ref = torch.zeros(24, 128, 4, device=DEV)
+    before = h.chained_launches()
+    h.forward_rays(o, d, z, 128, vd, 128, ref, folded)
+    torch.cuda.synchronize()
+    assert h.chained_launches() - before == 1
+    out = tmp_path / "raw.pt"
+    code = r'''
+import sys, warnings, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from mofanerf_amd import lib
+lib.test_hooks(selfcheck_poison=True)
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    census = lib.device_init("cuda")
+assert all(c > 0 for c in census), census
+assert lib.chain_selfcheck("cuda") == 0
+msgs = [str(x.message) for x in w if issubclass(x.category, lib.MofaWarning)]
+assert len(msgs) == 1 and "per-layer launches" in msgs[0] and "differs" in msgs[0], msgs
+lib.test_hooks()
+from test_gpu_chain import _setup
+h, o, d, z, vd, folded, vb, _ = _setup(10, 1024, 24, 128)
+raw = torch.zeros(24, 128, 4, device="cuda")
+h.forward_rays(o, d, z, 128, vd, 128, raw, folded)
+torch.cuda.synchronize()
+h.check_verdict(block=True)
+assert h.chained_launches() == 0, "a device that failed the self-check took the chained launch"
+torch.save(raw.cpu(), %r)
+print("SELFCHECK_FALLBACK_OK", msgs[0][:160])
+''' % (ROOT, os.path.join(ROOT, "tests"), str(out))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SELFCHECK_FALLBACK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert torch.equal(torch.load(out), ref.cpu())
+    print(r.stdout.strip().splitlines()[-1])
+
+
+def test_a_network_moved_to_the_gpu_after_binding_still_gets_its_census():
+    """ADVICE r5: HipNet took the census only if the module was on the GPU when it was constructed; `HipNet(net); net.cuda()` left the
+    wide networks on the per-layer launches for the life of the process.  Now the first launch on a device takes it (fresh process)."""
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from mofanerf_amd import lib, synth
+from mofanerf_amd.model import NeRF
+from mofanerf_amd.hipnet import HipNet
+net = NeRF(D=8, W=512, input_ch=93, input_ch_views=27, input_ch_textureCodes=256, input_ch_shapeCodes=50, use_viewdirs=True)
+net.load_state_dict(synth.nerf_state(8, 512, 1))
+h = HipNet(net)                         # still on the CPU
+assert not lib._device_census
+net.cuda()
+g = torch.Generator(device="cuda").manual_seed(0)
+R, S = 40, 64
+o = torch.rand(R, 3, device="cuda", generator=g); d = torch.randn(R, 3, device="cuda", generator=g) * 0.3
+z = torch.sort(torch.rand(R, S, device="cuda", generator=g) * 18 + 8, -1)[0].contiguous()
+vd = torch.nn.functional.normalize(d, dim=-1).contiguous()
+bm, tex, e = synth.codes(3)
+folded = h.fold(e.cuda(), bm.cuda(), tex.cuda()).clone()
+raw = torch.zeros(R, S, 4, device="cuda")
+h.forward_rays(o, d, z, S, vd, S, raw, folded)
+assert lib._device_census and h.chained_launches() == 1, (lib._device_census, h.chained_launches())
+assert bool(torch.isfinite(raw).all())
+print("LAZY_CENSUS_OK")
+''' % (ROOT,)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "LAZY_CENSUS_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

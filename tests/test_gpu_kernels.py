@@ -24,7 +24,7 @@ def dev(x):
 
 def test_library_loaded_from_tree():
     assert lib.LIB_PATH.endswith("mofanerf_amd/libmofanerf_hip.so")
-    assert L().mofa_abi_version() == 4
+    assert L().mofa_abi_version() == 5
 
 
 def test_positional_encode_golden(golden):

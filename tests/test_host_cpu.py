@@ -253,3 +253,28 @@ def test_bench_roofline_of_picks_the_kernel_with_the_largest_summed_time():
     assert r["launches"] == 10 and abs(r["avg_launch_ms"] - 70.5) < 1e-9 and abs(r["algorithmic_gflop_per_launch"] - 10520.0) < 1e-6
     assert abs(r["share_of_timed_region"] - 0.94) < 1e-9
     assert [o["kernel"] for o in r["other_mfma_kernels"]] == ["mofa::k_mlp_fused"] and abs(r["other_mfma_kernels"][0]["tflops"] - 140.1) < 0.01
+
+
+def test_bench_roofline_hbm_prices_the_ray_kernels_against_the_hbm_peak():
+    """SURVEY section 8d's second roofline (VERDICT r5 missing 3): compositing / resampling kernels, algorithmic bytes per ray x the rays the
+    launches processed / their HIP-event time, against 8 TB/s; PMC traffic quoted only under the same source digest."""
+    import ctypes
+    import bench
+    from mofanerf_amd import lib
+    NK = lib.PROF_KINDS
+    ms, launches, work = (ctypes.c_double * NK)(), (ctypes.c_int64 * NK)(), (ctypes.c_double * NK)()
+    ms[5], launches[5], work[5] = 705.0, 10, 10 * 10.52e12                       # an MFMA kind: not part of the HBM list
+    ms[8], launches[8], work[8] = 0.2, 2, 2 * 131072.0                            # two coarse composites of 131,072 rays, 100 us each
+    ms[10], launches[10], work[10] = 0.5, 2, 2 * 131072.0
+    assert bench.HBM_KINDS == {8: 1568, 9: 2616, 10: 1284}                        # SURVEY 8d's per-ray figures (VERDICT r5: 1,568 / 2,616 / ~1.3 k)
+    tj = {"csrc_sha256": "abc", "kernels": {"mofa::k_composite<1>": {"bytes_per_launch": 250e6, "rays_per_launch": 131072, "algorithmic_bytes_per_launch": 205520896}}}
+    r = bench.roofline_hbm_of(ms, launches, work, dt=1.0, traffic_json=tj, digest="abc")
+    assert [x["kernel"].split(" ")[0] for x in r] == ["mofa::k_composite<1>", "mofa::k_sample_pdf_merge<false>"]
+    c = r[0]
+    assert c["bound"] == "hbm" and c["unit"] == "GB/s" and c["peak"] == 8000.0 and c["launches"] == 2 and abs(c["avg_launch_us"] - 100.0) < 1e-9
+    assert abs(c["achieved"] - 131072 * 1568 / 100e-6 / 1e9) < 0.1 and abs(c["frac"] - c["achieved"] / 8000.0) < 1e-4 and c["traffic"] == 250e6
+    assert r[1]["traffic"] is None
+    stale = bench.roofline_hbm_of(ms, launches, work, dt=1.0, traffic_json=tj, digest="other")
+    assert stale[0]["traffic"] is None and "null" in stale[0]["traffic_source"]
+    dom, mf = bench.roofline_of(ms, launches, work, dt=1.0)                       # the MFMA roofline never picks a ray kernel
+    assert dom == 5
