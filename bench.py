@@ -49,7 +49,7 @@ H = W = 512
 ARCH = (8, 256, 10, 1024)
 N_SAMPLES, N_IMPORTANCE = 64, 64
 # (symbol, role, description) per profiler kind of libmofanerf_hip.so (include/mofanerf_hip.h, MOFA_PROF_KINDS); k_layer's template =
-# <BN, L0, BWD, PERRAY, PIPE, policy>.  Kinds 0-7 are the fp32-MFMA kernels (work = FLOPs), 8-10 the HBM-bound ray kernels (work = rays).
+# <BN, L0, BWD, PERRAY, PIPE, policy>.  Kinds 0-7 and 11 are the fp32-MFMA kernels (work = FLOPs), 8-10 the HBM-bound ray kernels (work = rays).
 KERNELS = [("mofa::k_layer<128,false,false,false,true,mofa::ShippedPolicy>", "forward", "fp32 MFMA Linear+bias+ReLU, software-pipelined K loop"),
            ("mofa::k_mlp_fused", "forward, persistent", "persistent fp32-MFMA network kernel, 256-wide layers pipelined across layer boundaries"),
            ("mofa::k_layer<128,false,true,false,true,mofa::ShippedPolicy>", "BWD backward-data", "fp32 MFMA backward-data GEMM + ReLU mask, the same K loop"),
@@ -62,8 +62,10 @@ KERNELS = [("mofa::k_layer<128,false,false,false,true,mofa::ShippedPolicy>", "fo
                                                                     "(the fitting step's forward)"),
            ("mofa::k_composite<1>", "raw2outputs, coarse pass", "one wavefront per ray, 64 samples: coalesced float4 loads of raw, wavefront prefix product"),
            ("mofa::k_composite<2>", "raw2outputs, fine pass", "the same with two samples per lane (128 samples)"),
-           ("mofa::k_sample_pdf_merge<false>", "sample_pdf + sort(cat) + std", "one wavefront per ray: cdf (fp64 prefix), inverse-cdf search in LDS, merge")]
-MFMA_KINDS = range(8)
+           ("mofa::k_sample_pdf_merge<false>", "sample_pdf + sort(cat) + std", "one wavefront per ray: cdf (fp64 prefix), inverse-cdf search in LDS, merge"),
+           ("mofa::k_net_chain_train", "BWD backward-data + weight gradients, chained", "the training backward of a wide network in two launches: backward-data "
+                                                                                        "tiles and the weight gradient's [128 x 256] units behind the same queues")]
+MFMA_KINDS = (0, 1, 2, 3, 4, 5, 6, 7, 11)
 # ALGORITHMIC HBM bytes per ray of the ray-side kernels: coarse compositing reads raw + z (64 x 20 + 12 B) and writes
 # the weights + 5 scalars (256 + 20 B); the fine pass reads 128 x 20 + 12 B and writes its 5 scalars + rgb0 / disp0 / acc0 / z_std (20 + 24 B;
 # its weights are an extra the kernel's contract writes but nobody needs: not counted); the resampler reads z + weights (2 x 256 B) and writes

@@ -41,7 +41,7 @@ extern "C" {
                              4: mofa_device_init(); `verdict` words of mofa_net_forward / mofa_net_backward; MOFA_PROF_KINDS = 7; larger
                                 mofa_net_backward_workspace_floats
                              5: mofa_device_init() runs the chained launch's self-check (third argument); mofa_test_hooks() replaces the two
-                                MOFA_CHAIN_* environment hooks; MOFA_PROF_KINDS = 11 (the mask-writing chained forward and the HBM-bound ray
+                                MOFA_CHAIN_* environment hooks; MOFA_PROF_KINDS = 12 (the mask-writing chained forward, the chained training backward and the HBM-bound ray
                                 kernels have their own entries); mofa_net_backward_workspace_floats(.., with_weight_grads) */
 #define MOFA_OK 0
 #define MOFA_EINVAL (-1)
@@ -273,11 +273,12 @@ int mofa_positional_encode(const float* x, int64_t n, int32_t n_freqs, float* ou
  *     kernel k_mlp_fused (widths <= 256)   [2] the backward-data kernel k_layer<128,..,BWD>   [3] the weight-gradient kernel k_wgrad
  *     [4] the view layer's per-ray-bias instantiation of the forward kernel   [5] the chained wide-network kernel k_net_chain<0>
  *     (forward: inference or keeping the fp32 tape)   [6] k_net_chain<2> (the fitting backward's backward-data products)
- *     [7] k_net_chain<1> (forward, also writing the mask tape)
+ *     [7] k_net_chain<1> (forward, also writing the mask tape)   [11] k_net_chain_train (the training backward of a wide network as
+     chained launches: backward-data products and weight gradients)
  *   HBM-bound ray kernels (work = RAYS; bench.py multiplies by SURVEY section 8d's algorithmic bytes per ray):
  *     [8] k_composite<1> (S <= 64: the coarse pass)   [9] k_composite<2> (S <= 128: the fine pass)   [10] k_sample_pdf_merge
  * Used by bench.py only. */
-#define MOFA_PROF_KINDS 11
+#define MOFA_PROF_KINDS 12
 int mofa_prof_begin(void);
 int mofa_prof_end(double* total_ms, int64_t* launches, double* padded_flops);
 

@@ -80,11 +80,49 @@ struct ChainStep {
     unsigned long long* bits;   // forward with a mask tape: where (y > 0) goes as bits (NULL: none); backward: the mask bits (NULL: none)
     int k1p, k2p, n_padded, n_tiles;
     int bias_row_div;           // forward: 0, or points per bias row (the view layer's per-ray rows)
-    int flags;                  // forward: bit 0 = ReLU; backward: bit 0 = accumulate into y
+    int flags;                  // forward: bit 0 = ReLU; backward: bit 0 = accumulate into y; bit 1 (k_net_chain_train only) = this step is a
+                                // WEIGHT GRADIENT dW = G^T X: x1 = G panels [n_padded / 16][m_padded][16], x2 = X panels [k1p][m_padded][16],
+                                // y = partial sums [split][n_padded][16 k1p], aux = bias partial sums [split][n_padded] or NULL,
+                                // n_tiles = (n_padded / 128) * (16 k1p / 256) output tiles per split
     int tiles_before;           // filled by the launcher: tiles of the earlier steps over one row tile
-    int pad_;
+    int spt;                    // weight-gradient steps: row tiles per split of the points (wg_split of THIS product; 0 otherwise)
 };
 enum ChainMode { kChainForward = 0, kChainForwardMask = 1, kChainBackward = 2 };
+constexpr int kChainStepWgrad = 2;   // ChainStep::flags bit
+
+// How the weight gradient dW = G^T X splits its contraction over the points (training).  ONE plan for the per-layer kernel (k_wgrad:
+// grid.y = splits) and for the chained training backward (k_net_chain_train: a split's units are queue entries of the XCD that owns its
+// rows), so that both sum the same points in the same order — bit-identical partial sums, one deterministic second stage.  Splits are whole
+// row tiles (256 points) and never straddle the row ranges k_net_chain gives the XCDs (XCD x owns row tiles [x mpx, (x + 1) mpx)).
+struct WgSplit {
+    int m_tiles;   // row tiles of the batch
+    int mpx;       // row tiles per XCD range: ceil(m_tiles / 8)
+    int spt;       // row tiles per split
+    int nspx;      // splits per full XCD range: ceil(mpx / spt)
+    int total;     // splits in all (the last populated range may hold fewer)
+};
+__host__ __device__ inline WgSplit wg_split(long long m_padded, int out_tiles /* output tiles of the product: (N / TN) * (K / TK) */) {
+    WgSplit w;
+    w.m_tiles = (int)(m_padded / kRowTile);
+    w.mpx = (w.m_tiles + 7) >> 3;
+    int want = (128 + out_tiles - 1) / out_tiles;      // ~1024 units per product: two rounds of the chip's 512 workgroup slots
+    if (want < 1) want = 1;
+    w.spt = (w.mpx + want - 1) / want;
+    if (w.spt < 1) w.spt = 1;
+    w.nspx = (w.mpx + w.spt - 1) / w.spt;
+    const int full = w.m_tiles / w.mpx, rem = w.m_tiles - full * w.mpx;
+    w.total = full * w.nspx + (rem + w.spt - 1) / w.spt;
+    return w;
+}
+// row tiles [first, first + count) of split s
+__host__ __device__ inline void wg_split_rows(const WgSplit& w, int s, int& first, int& count) {
+    const int x = s / w.nspx, j = s - x * w.nspx;
+    first = x * w.mpx + j * w.spt;
+    int end = first + w.spt, xend = (x + 1) * w.mpx;
+    if (xend > w.m_tiles) xend = w.m_tiles;
+    if (end > xend) end = xend;
+    count = end - first;
+}
 
 int current_device();              // hipGetDevice, clamped to [0, kMaxDevices)
 int compute_units(int device);     // multiProcessorCount, cached per device

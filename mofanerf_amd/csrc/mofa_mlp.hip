@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "mofa_layer.h"
+#include "mofa_wgrad.h"
 
 namespace mofa {
 namespace {
@@ -878,6 +879,22 @@ __global__ __launch_bounds__(256) void k_chain_verify(const unsigned* __restrict
     for (long long i = t0; i < n3; i += stride) p3[i] = nan;
 }
 
+// The same look at a chained launch's status for MANY output buffers (the training backward's weight gradients: 2D + 7 tensors the
+// second-stage sums were written into): an incomplete launch turns every one of them into NaN too (the verdict words are k_chain_verify's).
+constexpr int kMaxPoison = 80;
+struct PoisonArgs {
+    float* p[kMaxPoison];
+    long long n[kMaxPoison];
+    int count;
+};
+__global__ __launch_bounds__(256) void k_chain_poison(const unsigned* __restrict__ status, unsigned expect, const PoisonArgs a) {
+    if (status[0] == 0u && status[1] == expect) return;
+    const float nan = __builtin_nanf("");
+    const long long stride = (long long)gridDim.x * 256, t0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (int b = 0; b < a.count; ++b)
+        for (long long i = t0; i < a.n[b]; i += stride) a.p[b][i] = nan;
+}
+
 // What a workgroup of k_net_chain carries from tile to tile.  It rides into the K loop as the policy's `Probe` (the hook the loop calls
 // after every panel's wait + barrier), because two things belong BEHIND the next tile's first panel rather than between two tiles:
 //   * the completion signal of the tile just finished — the loop's first `s_waitcnt vmcnt(0)` + barrier is the point where every
@@ -1093,13 +1110,236 @@ __global__ __launch_bounds__(256, 2) void k_net_chain(const ChainArgs a) {
     hook.signal_prev();
 }
 
+// ======================================================================================================
+// k_net_chain_train (round 6): the TRAINING backward of a wide network's sub-batch — backward-data products AND weight gradients — behind
+// the same per-XCD queues.  Until round 5 this was the last per-layer path (two launches per layer and sub-batch, 65 % of a training
+// step): every layer's gradient G feeds a weight-gradient GEMM dW = G^T X between two backward-data products, and G's buffer is
+// recycled two products later.  Here the weight gradient's units are QUEUE ENTRIES too:
+//   * a step is either a backward-data product (tiles of 256 rows x 128 features, exactly k_net_chain<backward>'s) or a weight gradient
+//     (flags bit 1): its units are the [128 x 256] output tiles of k_wgrad over ONE SPLIT of the points — wg_split's plan (mofa_common.h):
+//     whole row tiles, never straddling an XCD's row range, the same splits the per-layer kernel sums, so the partial sums are
+//     bit-identical and the same deterministic second stage (k_wgrad_reduce, after the launch) finishes them;
+//   * the dependency rule is unchanged — a tile of step s over rows R starts when every tile of the steps before s over R has finished —
+//     with R a RANGE of row tiles for a weight-gradient unit: it waits for the counters of all its rows and bumps them all when done.
+//     That one rule orders everything the per-layer stream order did: dW_l reads G_l after the product that wrote it; the product that
+//     overwrites G_l's buffer waits for dW_l's units over those rows;
+//   * queue order per XCD stays step-major (the driver lists the steps in the per-layer form's own order), so a unit only ever waits for
+//     entries RUNNING workgroups hold: no deadlock for any residency; a weight-gradient unit is ~6 tiles' worth of work, drawn like any
+//     other entry;
+//   * G panels were written by other workgroups of the same launch: requested with sc1 (served by the XCD's L2), like the activation
+//     panels of the products; X panels (the tape), masks and weights come from earlier launches;
+//   * the same loud failure: bounded waits, abandon, k_chain_verify behind the launch.
+// ======================================================================================================
+struct TrainChainArgs {
+    unsigned* state;
+    long long m_padded, n_points;
+    int m_tiles, n_steps;
+    unsigned spin_limit;
+    int skip_xcd;                     // tests only (mofa_test_hooks)
+    int pipe;                         // weight-gradient units: software-pipelined chunk loop (MOFA_PIPE; the products always are)
+    ChainStep S[kMaxChainSteps];
+};
+static_assert(sizeof(TrainChainArgs) <= 4096, "kernel arguments are limited to 4 KiB");
+
+struct TrainChainPolicy : ShippedPolicy {
+    // ChainPolicy::Probe generalised to entries that own a RANGE of row tiles: the signal bumps every counter of the finished entry's
+    // rows, the early look (and the wait) is wave 0's — lane i takes counters i, i + 64, ... of the next entry's rows.
+    struct Probe {
+        const TrainChainArgs& a;
+        unsigned* done;
+        unsigned* status;
+        int m_lo, m_cnt, total, tid;
+        int prev_first = -1, prev_cnt = 0;   // rows whose completion is still to be signalled
+        bool first = false;                  // the current entry's first panel / chunk has not been passed yet
+        int s_next = 0, qlo_next = 0;        // (wave 0) the next entry's step and that step's first entry number
+        int qn = 0;                          // (wave 0, uniform) next entry number
+        unsigned seen = 0xffffffffu, need = 0;   // (wave 0) this lane's minimum over its share of the next entry's counters, seen early / what they must reach
+        __device__ __forceinline__ Probe(const TrainChainArgs& a_, unsigned* done_, unsigned* status_, int m_lo_, int m_cnt_, int total_, int tid_)
+            : a(a_), done(done_), status(status_), m_lo(m_lo_), m_cnt(m_cnt_), total(total_), tid(tid_) {}
+        // entries of step s in this XCD's queue: a product owns the XCD's row tiles, a weight gradient its splits of them
+        __device__ __forceinline__ int cnt(int s) const {
+            const ChainStep& st = a.S[s];
+            return st.n_tiles * ((st.flags & kChainStepWgrad) ? (m_cnt + st.spt - 1) / st.spt : m_cnt);
+        }
+        // rows [mf, mf + mc) of entry r of step st
+        __device__ __forceinline__ void rows(const ChainStep& st, int r, int& mf, int& mc) const {
+            if (st.flags & kChainStepWgrad) {
+                const int j = r / st.n_tiles;
+                mf = m_lo + j * st.spt;
+                mc = m_cnt - j * st.spt < st.spt ? m_cnt - j * st.spt : st.spt;
+            } else {
+                mf = m_lo + r / st.n_tiles, mc = 1;
+            }
+        }
+        __device__ __forceinline__ unsigned look(int mf, int mc) const {      // (wave 0) this lane's minimum over its share of the counters
+            unsigned v = 0xffffffffu;
+            for (int i = tid; i < mc; i += 64) {
+                const unsigned c = __hip_atomic_load(done + mf + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = c < v ? c : v;
+            }
+            return v;
+        }
+        __device__ __forceinline__ void signal_prev() {       // (after a vmcnt(0) + barrier that covers the previous entry's stores)
+            if (prev_first >= 0 && tid < 64) {
+                for (int i = tid; i < prev_cnt; i += 64) __hip_atomic_fetch_add(done + prev_first + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0) __hip_atomic_fetch_add(status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            prev_first = -1;
+        }
+        __device__ __forceinline__ void entry() {}
+        __device__ __forceinline__ void kloop_begin() {}
+        __device__ __forceinline__ void first_panel_landed() {}
+        __device__ __forceinline__ void kloop_end() {}
+        __device__ __forceinline__ void stores_issued() {}
+        __device__ __forceinline__ void panel() {
+            if (!first) return;
+            first = false;
+            signal_prev();
+            if (tid < 64 && qn < total) {
+                while (qn >= qlo_next + cnt(s_next)) qlo_next += cnt(s_next), ++s_next;
+                int mf, mc;
+                rows(a.S[s_next], qn - qlo_next, mf, mc);
+                need = (unsigned)a.S[s_next].tiles_before;
+                seen = look(mf, mc);
+            }
+        }
+    };
+};
+
+__global__ __launch_bounds__(256, 2) void k_net_chain_train(const TrainChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BM = kRowTile, BN = 128, NI = 2, NJ = 4, STAGE = (BM + BN) * 16;
+    constexpr int kWgLds = 2 * (128 / 16 + 256 / 16) * (WgCfg<128, 256>::MC * 16 + 16);     // floats of the weight-gradient unit's two stages (> 2 * STAGE)
+    static_assert(kWgLds >= 2 * STAGE, "the slot words sit behind the larger of the two tile forms");
+    int* const slot = (int*)(smem + kWgLds);          // [0] next entry number, [1] "its inputs are known to be complete", [2] "the wait ended well"
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    if ((int)xcc == a.skip_xcd) return;
+    const int mpx = (a.m_tiles + 7) >> 3;
+    const int m_lo = (int)xcc * mpx;
+    const int m_cnt = m_lo < a.m_tiles ? (a.m_tiles - m_lo < mpx ? a.m_tiles - m_lo : mpx) : 0;
+    unsigned* const head = a.state + xcc * kChainHeadStride;
+    unsigned* const status = a.state + kChainStatus;
+    unsigned* const done = a.state + kChainDone;
+    TrainChainPolicy::Probe hook(a, done, status, m_lo, m_cnt, 0, tid);
+    int total = 0;
+    for (int i = 0; i < a.n_steps; ++i) total += hook.cnt(i);
+    hook.total = total;
+
+    if (tid == 0) slot[0] = (int)__hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), slot[1] = 0;
+    __syncthreads();
+    // (entry numbers and everything derived from them are workgroup-uniform: say so, or they live in vector registers next to 128 accumulators)
+    int q = __builtin_amdgcn_readfirstlane(slot[0]), ready = 0;
+    int s = 0, qlo = 0;
+    while (q < total) {
+        while (q >= qlo + hook.cnt(s)) qlo += hook.cnt(s), ++s;          // entry numbers only grow: the step pointer only advances
+        const ChainStep& st = a.S[s];
+        const int r = q - qlo;
+        int mf, mc;
+        hook.rows(st, r, mf, mc);
+        if (!ready) {
+            // (as in k_net_chain: the previous entry's signal must go out BEFORE waiting — this entry may depend on it)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            hook.signal_prev();
+            if (tid < 64) {
+                const unsigned need = (unsigned)st.tiles_before;
+                unsigned spins = 0;
+                int ok = 1;
+                while (!__all(hook.look(mf, mc) >= need ? 1 : 0)) {
+                    __builtin_amdgcn_s_sleep(8);
+                    ++spins;
+                    if (spins >= a.spin_limit || ((spins & 255u) == 0u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        if (tid == 0) __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                }
+                if (tid == 0) slot[2] = ok;
+            }
+            __syncthreads();                             // the inputs of this entry are complete — for every wave
+            if (!__builtin_amdgcn_readfirstlane(slot[2])) break;
+        }
+        if (tid < 64) {                                  // the ticket after this one (wave 0 keeps it uniform: its lanes share the early look)
+            unsigned t = 0;
+            if (tid == 0) t = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hook.qn = (int)__builtin_amdgcn_readfirstlane(t);
+        }
+        hook.first = true;
+
+        if (st.flags & kChainStepWgrad) {
+            // one [128 x 256] tile of dW over the points of split j: k_wgrad's unit (mofa_wgrad.h), G requested with sc1
+            const int u = r - (r / st.n_tiles) * st.n_tiles, j = r / st.n_tiles;
+            const int n_tiles_n = st.n_padded >> 7;
+            const int nt = u % n_tiles_n, kt = u / n_tiles_n;
+            const int k_padded = st.k1p * 16;
+            const long long gs = (long long)xcc * ((mpx + st.spt - 1) / st.spt) + j;        // the split's global index (wg_split: nspx per full range)
+            const long long total_chunks = (a.n_points + 15) / 16;
+            const long long c_begin = (long long)mf * (kRowTile / 16);
+            long long c_end = c_begin + (long long)mc * (kRowTile / 16);
+            if (c_end > total_chunks) c_end = total_chunks;
+            wgrad_unit<128, 256, TrainChainPolicy::Probe, 16>(st.x1, st.x2, a.m_padded, a.n_points, st.n_padded, k_padded, nt * 128, kt * 256, c_begin, c_end,
+                                                              st.y + gs * st.n_padded * k_padded,
+                                                              st.aux ? const_cast<float*>(st.aux) + gs * st.n_padded : nullptr, a.pipe, smem, hook);
+        } else {
+            const int nt = r - (r / st.n_tiles) * st.n_tiles;
+            int lane_t = lane, tid_t = tid;              // (this form's lane constants are formed per tile, not kept across the other form's accumulators)
+            asm volatile("" : "+v"(lane_t), "+v"(tid_t));
+            const long long m0 = (long long)mf * BM;
+            const int n0 = nt * BN;
+            f32x16 acc[NI][NJ];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+            kloop_pipelined<NI, NJ, BM, BN, TrainChainPolicy, 16>(st.x1 + m0 * 16, nullptr, st.w + (long long)n0 * 16, a.m_padded * 16,
+                                                                  (long long)st.n_padded * 16, st.k1p, st.k1p, smem, tid_t, wave, lane_t, wm * (32 * NJ), wn * 64,
+                                                                  acc, hook);
+            float* const y = st.y;
+            const long long mrow = m0 + wm * (32 * NJ);
+            const int nf = n0 + wn * 64;
+            float* const win = smem + wave * 1024;       // wave-private window inside stage 0 (free after the loop's last barrier)
+            if (st.flags & 1) {                          // += the running sum another step of this launch left there
+                if (st.aux) chain_store_bwd_acc<NI, NJ, 1>(acc, y, st.aux, a.m_padded, mrow, nf, lane_t, win, nullptr);
+                else chain_store_bwd_acc<NI, NJ, 0>(acc, y, nullptr, a.m_padded, mrow, nf, lane_t, win, nullptr);
+            } else {
+                if (st.aux) store_tile_staged_bwd<NI, NJ, false, 1>(acc, y, st.aux, a.m_padded, mrow, nf, lane_t, win);
+                else store_tile_staged_bwd<NI, NJ, false, 0>(acc, y, nullptr, a.m_padded, mrow, nf, lane_t, win);
+            }
+        }
+        if (hook.first) {                                // (an entry without a single panel / chunk: cannot happen for the shapes the launcher admits)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            hook.panel();
+        }
+        hook.prev_first = mf, hook.prev_cnt = mc;        // signalled behind the next entry's first panel (or below / above when there is a wait)
+        if (tid < 64) {
+            const int ok = __all(hook.seen >= hook.need ? 1 : 0);
+            if (tid == 0) slot[0] = hook.qn, slot[1] = (hook.qn >= total || ok) ? 1 : 0;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                 // the windows and stages are free for the next entry's requests
+        q = __builtin_amdgcn_readfirstlane(slot[0]), ready = __builtin_amdgcn_readfirstlane(slot[1]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last entry of this workgroup
+    __syncthreads();
+    hook.signal_prev();
+}
+
 // Optional per-launch timing of the dominant kernels with HIP events recorded on the launch stream; used by bench.py for the
 // live roofline figure.  Off by default (no events, no overhead).  The measurement session is explicit state the HOST opens and
 // closes (mofa_prof_begin/end); it is kept per device and guarded by a mutex, so two devices or two host threads in one process
 // do not share or corrupt it.  When no session is open the launch paths only read one relaxed atomic.
 constexpr int kProfKinds = MOFA_PROF_KINDS;   // 0: k_layer<128,..,PIPE> (forward), 1: k_mlp_fused, 2: k_layer<BWD>, 3: k_wgrad, 4: k_layer<..PERRAY> (view layer), 5: k_net_chain<0> (forward),
                                               // 6: k_net_chain<2> (backward-data), 7: k_net_chain<1> (forward + mask bits); the HBM-bound ray kernels (work = rays): 8: k_composite<1>, 9: k_composite<2>,
-                                              // 10: k_sample_pdf_merge
+                                              // 10: k_sample_pdf_merge; 11: k_net_chain_train (training backward: products + weight gradients)
 struct ProfState {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     std::vector<int> kind;
@@ -1549,6 +1789,65 @@ int mofa_internal_chain_launch(int mode, const mofa::ChainStep* steps, int n_ste
     return check_launch("k_net_chain");
 }
 
+// internal (used by mofa_net.hip): the steps of one chained TRAINING-backward launch (k_net_chain_train): backward-data products and weight
+// gradients (flags bit 1, `spt` = wg_split's plan for that product).  *tiles_out = entries the launch must finish.
+int mofa_internal_chain_train_launch(const mofa::ChainStep* steps, int n_steps, long long m_padded, long long n_points, unsigned* state,
+                                     long long* tiles_out, void* stream) {
+    MOFA_REQUIRE(n_steps > 0 && n_steps <= kMaxChainSteps, "chain_train_launch: %d steps (max %d)", n_steps, kMaxChainSteps);
+    MOFA_REQUIRE(m_padded > 0 && m_padded % kRowTile == 0 && m_padded / kRowTile < (1 << 24) && n_points > 0 && n_points <= m_padded &&
+                     m_padded - n_points < kRowTile,
+                 "chain_train_launch: m_padded=%lld n_points=%lld", m_padded, n_points);
+    MOFA_REQUIRE(steps && state, "chain_train_launch: bad arguments");
+    TrainChainArgs a{};
+    a.state = state;
+    a.m_padded = m_padded, a.n_points = n_points, a.m_tiles = (int)(m_padded / kRowTile), a.n_steps = n_steps;
+    a.spin_limit = hook_chain_spin();
+    a.skip_xcd = hook_chain_skip_xcd();
+    a.pipe = config().pipe != 0 ? 1 : 0;
+    double flops = 0.0;
+    int before = 0;
+    for (int i = 0; i < n_steps; ++i) {
+        ChainStep s = steps[i];
+        if (s.flags & kChainStepWgrad) {
+            MOFA_REQUIRE(s.x1 && s.x2 && s.y, "chain_train_launch: weight-gradient step %d has a null operand", i);
+            MOFA_REQUIRE(s.n_padded > 0 && s.n_padded % 128 == 0 && s.k1p > 0 && (s.k1p * 16) % 256 == 0,
+                         "chain_train_launch: weight-gradient step %d (%d x %d) does not fit the 128 x 256 tile", i, s.n_padded, s.k1p * 16);
+            s.n_tiles = (s.n_padded / 128) * (s.k1p * 16 / 256);
+            MOFA_REQUIRE(s.spt == wg_split(m_padded, s.n_tiles).spt, "chain_train_launch: weight-gradient step %d does not carry wg_split's plan", i);
+            flops += 2.0 * (double)n_points * (double)s.n_padded * 16.0 * (double)s.k1p;
+        } else {
+            MOFA_REQUIRE(s.x1 && s.y && s.w && s.k2p == 0, "chain_train_launch: step %d has a null operand / a second source", i);
+            MOFA_REQUIRE(s.n_padded > 0 && s.n_padded % 128 == 0 && s.k1p >= 4 && (s.k1p & 1) == 0,
+                         "chain_train_launch: step %d (n_padded=%d, %d K panels) does not fit the pipelined 128-feature tile", i, s.n_padded, s.k1p);
+            MOFA_REQUIRE(!s.bits, "chain_train_launch: step %d carries mask bits (training keeps the fp32 tape)", i);
+            s.n_tiles = s.n_padded / 128;
+            flops += 2.0 * (double)m_padded * (double)s.n_padded * 16.0 * (double)s.k1p;
+        }
+        s.tiles_before = before;
+        a.S[i] = s;
+        before += s.n_tiles;
+    }
+    // entries per XCD: products own their row tiles, weight gradients their splits (the kernel's own arithmetic)
+    const int mpx = (a.m_tiles + 7) >> 3;
+    long long tiles = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int m_lo = x * mpx, m_cnt = m_lo < a.m_tiles ? (a.m_tiles - m_lo < mpx ? a.m_tiles - m_lo : mpx) : 0;
+        for (int i = 0; i < n_steps; ++i)
+            tiles += (long long)a.S[i].n_tiles * ((a.S[i].flags & kChainStepWgrad) ? (m_cnt + a.S[i].spt - 1) / a.S[i].spt : m_cnt);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(state, 0, mofa_internal_chain_state_words(m_padded) * sizeof(unsigned), st) != hipSuccess) return check_launch("hipMemsetAsync(chain state)");
+    if (tiles_out) *tiles_out = tiles;
+    const int slots = 2 * compute_units(stream_device(st));
+    const int grid = tiles < slots ? (int)round_up(tiles, 8) : slots;       // two resident workgroups per CU
+    constexpr size_t lds = 2 * (size_t)(128 / 16 + 256 / 16) * (WgCfg<128, 256>::MC * 16 + 16) * sizeof(float) + 64;
+    const bool prof = prof_enabled();
+    if (prof && prof_open(st, 11) != MOFA_OK) return MOFA_EHIP;
+    hipLaunchKernelGGL(k_net_chain_train, dim3(grid), dim3(256), lds, st, a);
+    if (prof) prof_close(st, 11, flops);
+    return check_launch("k_net_chain_train");
+}
+
 // internal (used by mofa_net.hip): behind a chained launch (and whatever consumed its outputs into p0 / p1 / p2): verify, poison, verdict
 int mofa_internal_chain_verify(const unsigned* state, long long tiles, unsigned* verdict, float* p0, long long n0, float* p1, long long n1,
                                float* p2, long long n2, float* p3, long long n3, void* stream) {
@@ -1561,6 +1860,17 @@ int mofa_internal_chain_verify(const unsigned* state, long long tiles, unsigned*
     hipLaunchKernelGGL(k_chain_verify, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, state + kChainStatus, (unsigned)tiles, verdict, p0, n0, p1,
                        n1, p2, n2, p3, n3);
     return check_launch("k_chain_verify");
+}
+
+// internal (used by mofa_net.hip): NaN into `count` more buffers if the chained launch behind `state` ended incomplete
+int mofa_internal_chain_poison(const unsigned* state, long long tiles, float* const* ptrs, const long long* sizes, int count, void* stream) {
+    for (int b0 = 0; b0 < count; b0 += kMaxPoison) {
+        PoisonArgs a{};
+        a.count = count - b0 < kMaxPoison ? count - b0 : kMaxPoison;
+        for (int i = 0; i < a.count; ++i) a.p[i] = ptrs[b0 + i], a.n[i] = ptrs[b0 + i] ? sizes[b0 + i] : 0;
+        hipLaunchKernelGGL(k_chain_poison, dim3(256), dim3(256), 0, (hipStream_t)stream, state + kChainStatus, (unsigned)tiles, a);
+    }
+    return check_launch("k_chain_poison");
 }
 
 // internal (used by mofa_net.hip): bits of (y > 0) for a panel buffer of n_floats (a multiple of 256) floats

@@ -36,6 +36,11 @@ int mofa_internal_head_weight_grad_split(const float* d_raw, int32_t raw_off, in
                                          int64_t m_padded, int64_t n_points, int32_t ncols, float* dst, int32_t ld, float* workspace,
                                          void* stream);
 int mofa_internal_chain_selfcheck(void* stream, int* ok, char* why, size_t why_len);
+int mofa_internal_chain_train_launch(const mofa::ChainStep* steps, int n_steps, long long m_padded, long long n_points, unsigned* state,
+                                     long long* tiles_out, void* stream);
+int mofa_internal_chain_poison(const unsigned* state, long long tiles, float* const* ptrs, const long long* sizes, int count, void* stream);
+int mofa_internal_wgrad_reduce(const float* partial, int splits, int n_padded, int k_padded, int n_out, int ncols, float* dst, int ld,
+                               int col0, float* bias_out, void* stream);
 }
 
 namespace mofa {
@@ -200,6 +205,32 @@ bool shape_ok(MofaNetShape s) {
            s.pe_view_freqs >= 0 && s.pe_view_freqs <= MOFA_MAX_PE_FREQS && s.ch_exp >= 0 && s.ch_exp <= MOFA_MAX_CODE && s.ch_shape >= 0 &&
            s.ch_shape <= MOFA_MAX_CODE && s.ch_tex >= 0 && s.ch_tex <= MOFA_MAX_CODE;
 }
+// ---- the chained TRAINING backward (k_net_chain_train): which shapes take it, and what its weight-gradient partial sums need ------------
+// Every product of the network must fit the chain's two tile forms: backward-data 256 x 128 (outputs Wp wide, contraction Wp or Hp in an
+// even number >= 4 of 16-panels) and the weight gradient's 128 x 256 (N in {Wp, Hp} a multiple of 128, K = Wp a multiple of 256); both
+// launches' step tables (products + weight gradients) must fit MOFA_MAX_CHAIN_STEPS.
+bool train_chain_shape(const Plan& p, int D) {
+    const int n2 = D - 5;
+    return p.Wp % 256 == 0 && p.Hp % 128 == 0 && 2 * (n2 + 9) <= MOFA_MAX_CHAIN_STEPS;
+}
+// partial sums [splits][N][K + 1] of one weight-gradient step (wg_split's plan for this product)
+size_t train_partial_floats(int64_t m_padded, int n_padded, int k_padded) {
+    const WgSplit sp = wg_split(m_padded, (n_padded / 128) * (k_padded / 256));
+    return (size_t)round_up((int64_t)((size_t)sp.total * n_padded * ((size_t)k_padded + 1)), 64);
+}
+// the weight-gradient scratch of a training backward: one product's partials (per-layer launches), or — for the shapes the chained
+// form takes — the partials of EVERY weight gradient of the larger of its two launches (shape stack + xyzEncode 3..1: D + 4 products of
+// Wp x Wp), which are reduced behind the launch
+size_t train_wws_floats(const Plan& p, int D, int64_t n_points) {
+    const int64_t mp = round_up(n_points, kRowTile);
+    size_t n = mofa_weight_grad_workspace_floats(n_points, p.Wp, p.Wp);
+    if (train_chain_shape(p, D)) {
+        const size_t chain = (size_t)(D + 4) * train_partial_floats(mp, p.Wp, p.Wp);
+        if (chain > n) n = chain;
+    }
+    return n;
+}
+
 // kernels of the chained launch's self-check (mofa_internal_chain_selfcheck below)
 __global__ __launch_bounds__(256) void k_selfcheck_fill(float* __restrict__ p, long long n, unsigned seed, float scale, float offset) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -325,12 +356,14 @@ size_t mofa_net_backward_workspace_floats(MofaNetShape s, int64_t n_points, int3
     if (!shape_ok(s) || n_points <= 0) return 0;
     const Plan p = make_plan(s);
     const size_t mp = (size_t)round_up(n_points, kRowTile);
-    // both forms: four gradient buffers + the encoding gradient + the split-M partial sums of one weight-gradient block (fitting: the
-    // row-split bias sums' partials live there)
-    const size_t base = mp * (4 * (size_t)p.Wp + (size_t)p.pe_k) + 64 + mofa_weight_grad_workspace_floats(n_points, p.Wp, p.Wp) + 64;
-    if (with_weight_grads) return base;
-    // the chained fitting backward: three more gradient buffers (the bias-gradient inputs it keeps) + the queue state of its two launches
-    return base + 3 * mp * (size_t)p.Wp + 2 * (size_t)round_up((int64_t)mofa_internal_chain_state_words((long long)mp), 32) + 64;
+    // both forms: four gradient buffers + the encoding gradient + weight-gradient scratch (fitting: the row-split bias sums' partials live
+    // there) + the queue state of two chained launches
+    const size_t head = mp * (4 * (size_t)p.Wp + (size_t)p.pe_k) + 64;
+    const size_t tail = 2 * (size_t)round_up((int64_t)mofa_internal_chain_state_words((long long)mp), 32) + 64;
+    // training: the scratch holds the partial sums of every weight gradient of one chained launch (train_wws_floats); no further buffers
+    if (with_weight_grads) return head + train_wws_floats(p, s.D, n_points) + 64 + tail;
+    // fitting: three more gradient buffers — the bias-gradient inputs its chained backward keeps
+    return head + mofa_weight_grad_workspace_floats(n_points, p.Wp, p.Wp) + 64 + 3 * mp * (size_t)p.Wp + tail;
 }
 
 int mofa_net_pack_t(MofaNetShape s, const float* const* weights, float* packed_t, void* stream) {
@@ -641,10 +674,10 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
     float* gS = workspace + 2 * act;   // accumulates d sigmaCodes
     float* gX = workspace + 3 * act;   // accumulates d xyz_code
     float* dpe = workspace + 4 * act;  // [Mp, pe_k]
-    float* wws = dpe + (size_t)Mp * p.pe_k + 64;  // split-M partial sums of the weight-gradient GEMM
-    float* extra = wws + mofa_weight_grad_workspace_floats(M, p.Wp, p.Wp) + 64;   // three more gradient buffers (chained form only)
+    float* wws = dpe + (size_t)Mp * p.pe_k + 64;  // split-M partial sums of the weight-gradient GEMMs (training: of a whole chained launch)
+    float* extra = wws + (d_weights ? train_wws_floats(p, s.D, M) : mofa_weight_grad_workspace_floats(M, p.Wp, p.Wp)) + 64;   // fitting: three more gradient buffers (chained form only)
     unsigned* cstate[2];        // queue state of the two chained launches, each on a 128-byte boundary of the workspace (the queue heads own a line each)
-    cstate[0] = (unsigned*)(workspace + round_up((extra + 3 * act) - workspace, 32));
+    cstate[0] = (unsigned*)(workspace + round_up((extra + (d_weights ? 0 : 3 * act)) - workspace, 32));
     cstate[1] = cstate[0] + round_up((int64_t)mofa_internal_chain_state_words((long long)Mp), 32);
     // (output > 0) of layer li: the saved fp32 activation itself, or its bits in the mask-only tape — never both
     struct Mask {
@@ -664,9 +697,13 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
     // contribution (an elementwise accumulate into d sigmaCodes) separates the two launches, and the five bias-gradient column sums
     // the fitting needs (the code-conditioned layers) run after the launch that produced their input — which therefore must survive
     // the launch: those gradients are kept in buffers the chain does not recycle (three more than the per-layer form's four).
-    // Training (weight gradients) keeps the per-layer form: every layer's gradient feeds a weight-gradient GEMM between two products.
-    const bool chain = !d_weights && config().chain != 0 && config().pipe != 0 && p.Wp % 128 == 0 && p.Wp >= 64 && p.Hp % 32 == 0 && p.Hp >= 64 &&
-                       n2 + 7 <= MOFA_MAX_CHAIN_STEPS && n2 + 9 <= MOFA_MAX_CHAIN_STEPS && mofa_internal_chain_capable(stream) == 1;
+    // Training (weight gradients; round 6): the same two launches as k_net_chain_train — every layer's gradient feeds a weight-gradient GEMM
+    // between two products, so the weight gradients' units are queue entries too (wg_split's plan: the per-layer kernel's own splits, so
+    // the partial sums are bit-identical); their partials live in the scratch until the second-stage sums behind the launch.
+    const bool chain_knobs = config().chain != 0 && config().pipe != 0;
+    const bool chain = chain_knobs && mofa_internal_chain_capable(stream) == 1 &&
+                       (d_weights ? train_chain_shape(p, s.D)
+                                  : (p.Wp % 128 == 0 && p.Wp >= 64 && p.Hp % 32 == 0 && p.Hp >= 64 && n2 + 7 <= MOFA_MAX_CHAIN_STEPS && n2 + 9 <= MOFA_MAX_CHAIN_STEPS));
     bool chaining = false;                       // products are being recorded (between begin_chain() and flush())
     std::vector<ChainStep> seg;
     struct Deferred {
@@ -675,6 +712,12 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
     };
     std::vector<Deferred> deferred;             // bias gradients whose input the open segment produces
     std::vector<const float*> kept;             // ... and the buffers they read: not to be overwritten before flush()
+    struct Reduce {                             // (training) second-stage sums of the weight gradients the open segment's launch leaves as partials
+        int li, part, splits;
+        const float* partial;
+    };
+    std::vector<Reduce> reduces;
+    float* wpart = wws;                         // next free partial region of the open segment
     long long ctiles[2] = {0, 0};
     int nseg = 0;
     float *cur = nullptr, *spare = nullptr;
@@ -697,11 +740,21 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
         chaining = false;
         if (seg.empty()) return MOFA_OK;
         MOFA_REQUIRE(nseg < 2, "net_backward: internal error (more than two chained segments)");
-        MOFA_TRY(mofa_internal_chain_launch(kChainBackward, seg.data(), (int)seg.size(), Mp, 1, cstate[nseg], &ctiles[nseg], stream));
+        if (d_weights) {
+            MOFA_TRY(mofa_internal_chain_train_launch(seg.data(), (int)seg.size(), Mp, M, cstate[nseg], &ctiles[nseg], stream));
+        } else {
+            MOFA_TRY(mofa_internal_chain_launch(kChainBackward, seg.data(), (int)seg.size(), Mp, 1, cstate[nseg], &ctiles[nseg], stream));
+        }
         ++nseg;
         for (const Deferred& d : deferred)
             MOFA_TRY(mofa_internal_bias_grad_split(d.g, Mp, M, p.L[d.li].n_padded, d_folded + p.L[d.li].folded_off, wws, stream));
-        seg.clear(), deferred.clear(), kept.clear();
+        for (const Reduce& r : reduces) {       // the deterministic second stage, in the per-layer form's own order
+            const Layer& l = p.L[r.li];
+            MOFA_TRY(mofa_internal_wgrad_reduce(r.partial, r.splits, l.n_padded, l.k_padded[r.part], l.n_out, l.ncols[r.part], d_weights[r.li], l.ld,
+                                                l.col0[r.part], (r.part == 0 && l.fold != kView) ? d_folded + l.folded_off : nullptr, stream));
+        }
+        seg.clear(), deferred.clear(), kept.clear(), reduces.clear();
+        wpart = wws;
         return MOFA_OK;
     };
     // dW[li][:, col0[part] : +ncols[part]] = G^T X   (training only: d_weights != NULL; the constant columns are the host's)
@@ -709,6 +762,17 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
         if (!d_weights) return MOFA_OK;
         const Layer& l = p.L[li];
         MOFA_REQUIRE(d_weights[li], "net_backward: d_weights[%d] is null", li);
+        if (chaining) {                          // a queue entry of the open segment's launch; summed behind it (flush)
+            const WgSplit sp = wg_split(Mp, (l.n_padded / 128) * (l.k_padded[part] / 256));
+            const bool bias = part == 0 && l.fold != kView;
+            ChainStep c{};
+            c.x1 = g, c.x2 = x, c.y = wpart, c.aux = bias ? wpart + (size_t)sp.total * l.n_padded * l.k_padded[part] : nullptr;
+            c.k1p = l.k_padded[part] / 16, c.n_padded = l.n_padded, c.flags = kChainStepWgrad, c.spt = sp.spt;
+            seg.push_back(c);
+            reduces.push_back({li, part, sp.total, wpart});
+            wpart += train_partial_floats(Mp, l.n_padded, l.k_padded[part]);
+            return MOFA_OK;
+        }
         return mofa_weight_grad(g, l.n_padded, x, l.k_padded[part], Mp, M, l.n_out, l.ncols[part], d_weights[li], l.ld,
                                 l.col0[part], (part == 0 && l.fold != kView) ? d_folded + l.folded_off : nullptr, wws,
                                 stream);
@@ -762,9 +826,9 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
             MOFA_TRY(mofa_internal_head_weight_grad_split(d_raw, 3, 1, T(p.bim_skip + n2 - 1), a.k_padded[0], Mp, M, a.ld,
                                                           d_weights[p.alpha], a.ld, wws, stream));
         }
-        MOFA_TRY(wgrad(p.view, 0, g0, T(p.uv_skip + n2 - 1)));
     }
     chaining = chain;                                            // ---- first chained launch: view layer + texture stack
+    MOFA_TRY(wgrad(p.view, 0, g0, T(p.uv_skip + n2 - 1)));
     // view layer -> d rgbCodes, masked by the last uv layer's ReLU
     MOFA_TRY(bdata(p.view, 0, g0, Mk(p.uv_skip + n2 - 1), 0, g1));
     cur = g1, spare = g0;
@@ -834,10 +898,17 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
         MOFA_TRY(mofa_pe_backward(dpe, Mp, rays_o, rays_d, z, z_row_stride, n_rays, S, s.pe_point_freqs, d_rays_o, d_rays_d, stream));
     }
     // chained launches that did not finish every tile must not look like gradients: NaN into everything this call returns + verdict
-    for (int i = 0; i < nseg; ++i)
+    for (int i = 0; i < nseg; ++i) {
         MOFA_TRY(mofa_internal_chain_verify(cstate[i], ctiles[i], verdict, d_folded, (long long)p.folded_floats, d_view_bias_rows,
                                             (long long)n_rays * p.L[p.view].n_padded, pts ? d_pts : d_rays_o, pts ? M * 3 : n_rays * 3,
                                             pts ? nullptr : d_rays_d, n_rays * 3, stream));
+        if (d_weights) {                         // ... and into every weight gradient (their second-stage sums read the launch's partials)
+            std::vector<float*> wp(p.L.size());
+            std::vector<long long> wn(p.L.size());
+            for (size_t li = 0; li < p.L.size(); ++li) wp[li] = d_weights[li], wn[li] = (long long)p.L[li].n_out * p.L[li].ld;
+            MOFA_TRY(mofa_internal_chain_poison(cstate[i], ctiles[i], wp.data(), wn.data(), (int)wp.size(), stream));
+        }
+    }
     return MOFA_OK;
 }
 #undef MOFA_TRY

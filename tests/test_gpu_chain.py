@@ -141,11 +141,15 @@ def test_chained_fitting_backward_is_bit_identical_to_per_layer_launches(D, W, R
             assert torch.equal(a, b), (key, k, float((a - b).abs().max()))
 
 
-def test_training_backward_keeps_the_per_layer_form_and_agrees(knob):
-    """With weight gradients every layer's gradient feeds a weight-gradient GEMM between two backward-data products: the backward stays
-    per-layer (only its tape-keeping FORWARD is chained) — and the whole step agrees bit for bit with MOFA_CHAIN=0."""
-    h, o, d, z, vd, folded, vb, G = _setup(8, 512, 21, 64)
-    S = 64
+@pytest.mark.parametrize("D,W,R,S", [(10, 1024, 40, 128), (8, 512, 21, 64), (8, 256, 300, 64), (10, 1024, 3, 128), (8, 768, 77, 64), (6, 512, 130, 64)])
+def test_chained_training_backward_is_bit_identical_to_per_layer_launches(D, W, R, S, knob):
+    """training's backward was the last per-layer path (every layer's gradient feeds a weight-gradient GEMM between two
+    backward-data products).  Round 6: the weight gradients' units are queue entries of the same chained launches (k_net_chain_train) —
+    the per-layer kernel's own tile over the per-layer kernel's own splits of the points (wg_split), partial sums finished by the same
+    second stage — so EVERYTHING the step returns must equal MOFA_CHAIN=0's bit for bit: raw, the gradients to rays / folded biases /
+    view-bias rows, and every weight gradient.  (3 x 128 and 21 x 64 points: ragged last row tile, XCDs without rows; width 256: the coarse
+    network's backward chains too; 768: Hp = 384; D = 6: one-layer second halves.)  The verdict words must say the chained launches ran."""
+    h, o, d, z, vd, folded, vb, G = _setup(D, W, R, S)
     runs = {}
     for chain in ("0", "1"):
         knob("MOFA_CHAIN", chain)
@@ -156,10 +160,35 @@ def test_training_backward_keeps_the_per_layer_form_and_agrees(knob):
         raw = NetFn.apply(h, og, dg, z, S, S, fo, vbg, None, *ws)
         (raw * G).sum().backward()
         torch.cuda.synchronize()
-        assert h.chained_launches() - before == (1 if chain == "1" else 0)
+        # the tape-keeping forward (width > 256) + the backward's two launches
+        assert h.chained_launches() - before == ((3 if W > 256 else 2) if chain == "1" else 0)
+        h.check_verdict(block=True)
         runs[chain] = [raw.detach().clone(), og.grad, dg.grad, fo.grad, vbg.grad] + [w.grad for w in ws]
     for k, (a, b) in enumerate(zip(runs["0"], runs["1"])):
-        assert torch.isfinite(a).all() and torch.equal(a, b), k
+        assert torch.isfinite(a).all() and torch.equal(a, b), (k, float((a - b).abs().max()))
+    assert all(float(t.abs().sum()) > 0 for t in runs["1"][5:-2])           # the weight gradients are there (not a vacuous comparison)
+
+
+def test_an_incomplete_training_backward_poisons_the_weight_gradients_too():
+    """The chained training backward leaves the weight gradients as partial sums that are reduced BEHIND the launch: if the launch ends
+    incomplete (forced: one poll of budget) the second stage would sum garbage — so the verification behind it overwrites every weight
+    gradient with NaN as well (k_chain_poison), next to d_folded / d_view_bias_rows / d_rays, and the host raises."""
+    h, o, d, z, vd, folded, vb, G = _setup(10, 1024, 16, 128)
+    S = 128
+    og, dg = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
+    fo, vbg = folded.clone().requires_grad_(True), vb.clone().requires_grad_(True)
+    ws = [l.weight.detach().clone().requires_grad_(True) for l in h._linears]
+    raw = NetFn.apply(h, og, dg, z, S, S, fo, vbg, None, *ws)
+    torch.cuda.synchronize()
+    h.check_verdict(block=True)
+    lib.test_hooks(chain_spin_limit=1)
+    (raw * G).sum().backward()
+    torch.cuda.synchronize()
+    lib.test_hooks()
+    mfma = [w for w, l in zip(ws, h._linears) if l.out_features > 4]
+    assert all(torch.isnan(t.grad).all() for t in (og, dg, fo, vbg)) and all(torch.isnan(w.grad).all() for w in mfma)
+    with pytest.raises(lib.MofaError, match="did not complete"):
+        h.check_verdict(block=True)
 
 
 def test_a_dependency_wait_out_of_budget_is_loud_not_wrong():

@@ -192,7 +192,9 @@ def test_run_network_is_differentiable_like_the_reference(weight_grads):
     the expression latent and the StyleModule — and the network weights when weight gradients are on — against the oracle's fp32
     autograd of the same arithmetic.  netchunk = 200 forces several sub-batches (explicit-point HIP backward per sub-batch)."""
     render, kw, _ = make_product((8, 64, 10, 64), 0, 200, DEV)
-    render._weight_grads = weight_grads
+    # (round 6: what an EARLIER render() / render_fitting() chose no longer matters — set it the wrong way round on purpose; the weights take
+    #  part because they require grad, and stay out only when the CALL says weight_grads=False)
+    render._weight_grads = not weight_grads
     rng = np.random.default_rng(8)
     pts = T(rng.uniform(-8, 8, (19, 33, 3)).astype(np.float32))
     vd = torch.nn.functional.normalize(T(rng.normal(size=(19, 3)).astype(np.float32)), dim=-1)
@@ -212,7 +214,7 @@ def test_run_network_is_differentiable_like_the_reference(weight_grads):
     dv = lambda t: t.to(DEV).requires_grad_(True)
     pts_g, vd_g, bm_g, tex_g = dv(pts), dv(vd), dv(bm), dv(tex)
     render.shapeCodes, render.expType, render.decoding_texCodes = bm_g, 3, tex_g
-    raw = kw["network_query_fn"](pts_g, vd_g, kw["network_fine"])
+    raw = kw["network_query_fn"](pts_g, vd_g, kw["network_fine"]) if weight_grads else kw["network_query_fn"](pts_g, vd_g, kw["network_fine"], weight_grads=False)
     assert raw.grad_fn is not None and raw.shape == (19, 33, 4)
     (raw * G.to(DEV)).sum().backward()
     torch.cuda.synchronize()

@@ -15,7 +15,8 @@ src, dst = sys.argv[1], sys.argv[2]
 m = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(os.path.join(src, "pmc_rays_*.csv"))):
     for r in csv.DictReader(open(f)):
-        m[r["Kernel_Name"].split("(")[0].replace(" ", "").replace("void", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
+        m[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 R = 196608
 out = {"csrc_sha256": build.csrc_digest(), "rays_per_launch": R, "launches_averaged": 4, "kernels": {},
        "note": "one rocprofv3 --pmc pass per counter group (no tracing next to --pmc) over tools/pmc_rays.py; per-dispatch counters averaged over the "

@@ -12,6 +12,8 @@ Arms (shipped fine network 1024 x 10 unless stated):
     compared with the per-layer form's
   * forward keeping the fp32 tape (training forward)
   * the coarse 256 x 8 network's fitting pass: the pipelined persistent kernel writing the mask tape (k_mlp_fused<true>) + its chained backward
+  * (round 6) a training step's network pass: tape-keeping forward + the chained training backward (k_net_chain_train), every weight gradient
+    compared with the per-layer form's — at the benchmark's sub-batch with a competing stream, on a ragged 6-row-tile batch, on the coarse network
 
     python tools/stress_chain.py [scale]        # scale 1.0 = >= 5,000 chained launches (about 5 minutes of GPU)
 Exit code 1 on any mismatch or verdict.
@@ -131,6 +133,41 @@ def fit_arm(name, R, S, n, fp32_tape=False, D=10, W=1024, per_step=3):
     report(name, launches, mism, t0)
 
 
+def train_arm(name, R, S, n, D=10, W=1024, busy=False, per_step=3):
+    """A training step's network pass (round 6): tape-keeping forward + the chained training backward (k_net_chain_train: backward-data tiles
+    AND weight-gradient units behind the queues) — raw, the ray / bias gradients and EVERY weight gradient against the per-layer form."""
+    h, o, d, z, vd, folded, vb, G = setup(D, W, R, S)
+
+    def step():
+        og, dg = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
+        fo, vbg = folded.clone().requires_grad_(True), vb.clone().requires_grad_(True)
+        ws = [l.weight.detach().clone().requires_grad_(True) for l in h._linears]
+        raw = NetFn.apply(h, og, dg, z, S, S, fo, vbg, None, *ws)
+        (raw * G).sum().backward()
+        return [raw.detach(), og.grad, dg.grad, fo.grad, vbg.grad] + [w.grad for w in ws]
+
+    knob("MOFA_CHAIN", "0")
+    ref = [t.clone() for t in step()]
+    torch.cuda.synchronize()
+    knob("MOFA_CHAIN", "1")
+    before = h.chained_launches()
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=DEV)
+    t0, mism = time.perf_counter(), 0
+    for i in range(n):
+        if busy and i % 2 == 0:
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    a @ a
+        got = step()
+        mism += int(not all(torch.equal(x, y) for x, y in zip(got, ref)))
+    torch.cuda.synchronize()
+    h.check_verdict(block=True)
+    launches = h.chained_launches() - before
+    assert launches == per_step * n, f"{launches} chained launches for {n} steps (expected {per_step} each)"
+    report(name, launches, mism, t0)
+
+
 def tape_forward_arm(name, R, S, n, D=10, W=1024):
     """The training forward (fp32 tape), chained: raw and EVERY float of the tape against the per-layer form."""
     h, o, d, z, vd, folded, vb, _ = setup(D, W, R, S)
@@ -177,5 +214,9 @@ fit_arm("fitting step, fp32 tape (256 rays x 128)", 256, 128, n_of(60), fp32_tap
 fit_arm("coarse network 256 x 8 fitting pass (1024 rays x 64): k_mlp_fused<true> writes the mask tape, 2 chained backward launches", 1024, 64, n_of(200),
         D=8, W=256, per_step=2)
 tape_forward_arm("training forward keeping the fp32 tape (512 rays x 128)", 512, 128, n_of(120))
+train_arm("training step fine pass (512 rays x 128): tape forward + chained training backward (products + weight gradients)", 512, 128, n_of(60))
+train_arm("training step fine pass, 1536 rays x 128 (the benchmark's sub-batch: 768 row tiles), competing stream", 1536, 128, n_of(20), busy=True)
+train_arm("training step, 21 rays x 64 of a 512 x 8 network (6 row tiles, ragged last tile)", 21, 64, n_of(300), D=8, W=512)
+train_arm("training step coarse pass 256 x 8 (1024 rays x 64): persistent forward, chained training backward", 1024, 64, n_of(100), D=8, W=256, per_step=2)
 print(f"TOTAL: {total_chained} chained launches, {bad} mismatching, every verdict clean", flush=True)
 sys.exit(1 if bad else 0)
