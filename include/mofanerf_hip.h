@@ -62,9 +62,10 @@ int mofa_abi_version(void);
 const char* mofa_last_error(void);   /* thread-local text of the calling thread's last failure */
 
 /* Library-wide state is limited to what is listed here; everything else is in caller-owned buffers.
- *   - three run-time knobs, each choosing between BIT-IDENTICAL forms of the exact-fp32 path — MOFA_PIPE=0 (plain instead of
+ *   - four run-time knobs, each choosing between BIT-IDENTICAL forms of the exact-fp32 path — MOFA_PIPE=0 (plain instead of
  *     software-pipelined K loops), MOFA_FUSED=0/1 (per-layer launches / persistent network kernel for widths <= 256), MOFA_CHAIN=0
- *     (per-layer launches instead of the chained launch of the wider networks); there is no reduced-precision
+ *     (per-layer launches instead of the chained launch of the wider networks), MOFA_CHAIN_TRAIN=1 (the TRAINING backward — products and
+ *     weight gradients — as chained launches too; off by default: measured a tie); there is no reduced-precision
  *     mode: read from the environment ONCE when the library is loaded into an immutable snapshot;
  *     no launch path calls getenv.  mofa_config_reload() re-reads them (tests that change a knob inside one process call it explicitly).
  *     Measurement arms (scheduling experiments, time stamps, ablations) are NOT in this library: csrc/measure/, tools/build_measure.py.

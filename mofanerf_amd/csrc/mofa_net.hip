@@ -59,7 +59,7 @@ namespace {
 Config read_env() {
     Config c;
     auto tri = [](const char* name) { const char* e = getenv(name); return e ? (e[0] == '1' ? 1 : 0) : -1; };
-    c.fused = tri("MOFA_FUSED"), c.pipe = tri("MOFA_PIPE"), c.chain = tri("MOFA_CHAIN");
+    c.fused = tri("MOFA_FUSED"), c.pipe = tri("MOFA_PIPE"), c.chain = tri("MOFA_CHAIN"), c.chain_train = tri("MOFA_CHAIN_TRAIN");
     return c;
 }
 std::atomic<unsigned> g_hook_spin{kChainSpinDefault};
@@ -205,13 +205,13 @@ bool shape_ok(MofaNetShape s) {
            s.pe_view_freqs >= 0 && s.pe_view_freqs <= MOFA_MAX_PE_FREQS && s.ch_exp >= 0 && s.ch_exp <= MOFA_MAX_CODE && s.ch_shape >= 0 &&
            s.ch_shape <= MOFA_MAX_CODE && s.ch_tex >= 0 && s.ch_tex <= MOFA_MAX_CODE;
 }
-// ---- the chained TRAINING backward (k_net_chain_train): which shapes take it, and what its weight-gradient partial sums need ------------
-// Every product of the network must fit the chain's two tile forms: backward-data 256 x 128 (outputs Wp wide, contraction Wp or Hp in an
+// ---- the chained TRAINING backward (k_net_chain_train; opt-in: MOFA_CHAIN_TRAIN=1): which shapes take it, and what its weight-gradient
+// partial sums need.  Every product of the network must fit the chain's two tile forms: backward-data 256 x 128 (outputs Wp wide, contraction Wp or Hp in an
 // even number >= 4 of 16-panels) and the weight gradient's 128 x 256 (N in {Wp, Hp} a multiple of 128, K = Wp a multiple of 256); both
 // launches' step tables (products + weight gradients) must fit MOFA_MAX_CHAIN_STEPS.
 bool train_chain_shape(const Plan& p, int D) {
     const int n2 = D - 5;
-    return p.Wp % 256 == 0 && p.Hp % 128 == 0 && 2 * (n2 + 9) <= MOFA_MAX_CHAIN_STEPS;
+    return config().chain_train == 1 && p.Wp % 256 == 0 && p.Hp % 128 == 0 && 2 * (n2 + 9) <= MOFA_MAX_CHAIN_STEPS;
 }
 // partial sums [splits][N][K + 1] of one weight-gradient step (wg_split's plan for this product)
 size_t train_partial_floats(int64_t m_padded, int n_padded, int k_padded) {
@@ -697,9 +697,12 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
     // contribution (an elementwise accumulate into d sigmaCodes) separates the two launches, and the five bias-gradient column sums
     // the fitting needs (the code-conditioned layers) run after the launch that produced their input — which therefore must survive
     // the launch: those gradients are kept in buffers the chain does not recycle (three more than the per-layer form's four).
-    // Training (weight gradients; round 6): the same two launches as k_net_chain_train — every layer's gradient feeds a weight-gradient GEMM
-    // between two products, so the weight gradients' units are queue entries too (wg_split's plan: the per-layer kernel's own splits, so
-    // the partial sums are bit-identical); their partials live in the scratch until the second-stage sums behind the launch.
+    // Training (weight gradients; round 6, opt-in MOFA_CHAIN_TRAIN=1): the same two launches as k_net_chain_train — every layer's gradient
+    // feeds a weight-gradient GEMM between two products, so the weight gradients' units are queue entries too (wg_split's plan: the
+    // per-layer kernel's own splits, so the partial sums are bit-identical); their partials live in the scratch until the second-stage
+    // sums behind the launch.  Built, verified bit-identical, and measured 0.2-0.4 % slower than the per-layer launches (the queues mix
+    // products and weight gradients in time: 2.6 TB/s of steady fabric traffic, waves parked 10.6 % against 3.4 / 4.4 %), so the default
+    // training backward stays per-layer (profiles/r06_ab_chain_train.md).
     const bool chain_knobs = config().chain != 0 && config().pipe != 0;
     const bool chain = chain_knobs && mofa_internal_chain_capable(stream) == 1 &&
                        (d_weights ? train_chain_shape(p, s.D)

@@ -60,12 +60,19 @@ def test_plan_sizes_and_argument_validation():
         # inputs), training (round 6, widths the chained training backward takes) the partial sums of every weight gradient of one launch
         fit_ws, train_ws = L.mofa_net_backward_workspace_floats(s, 1000, 0), L.mofa_net_backward_workspace_floats(s, 1000, 1)
         one = L.mofa_weight_grad_workspace_floats(1000, Wp, Wp)
-        if Wp % 256 == 0:
-            splits = 4                                                   # 4 row tiles, one per XCD range, one split each
-            assert one == splits * Wp * (Wp + 1)
-            assert train_ws - (fit_ws - 3 * 1024 * Wp - one) == (D + 4) * ((splits * Wp * (Wp + 1) + 63) // 64 * 64), (fit_ws, train_ws)
-        else:
-            assert fit_ws - train_ws == 3 * 1024 * Wp, (fit_ws, train_ws)
+        assert fit_ws - train_ws == 3 * 1024 * Wp, (fit_ws, train_ws)
+        if Wp % 256 == 0:           # opt-in MOFA_CHAIN_TRAIN=1: the scratch then holds every weight gradient's partial sums of one chained launch
+            import os as _os
+            _os.environ["MOFA_CHAIN_TRAIN"] = "1"
+            lib.reload_env()
+            try:
+                splits = 4                                               # 4 row tiles, one per XCD range, one split each
+                assert one == splits * Wp * (Wp + 1)
+                chained = L.mofa_net_backward_workspace_floats(s, 1000, 1)
+                assert chained - (train_ws - one) == (D + 4) * ((splits * Wp * (Wp + 1) + 63) // 64 * 64), (chained, train_ws)
+            finally:
+                del _os.environ["MOFA_CHAIN_TRAIN"]
+                lib.reload_env()
     assert L.mofa_net_num_layers(lib.NetShape(3, 256)) == -1
     assert L.mofa_net_num_layers(lib.NetShape(8, 256, pe_point_freqs=17)) == -1
     assert L.mofa_net_num_layers(lib.NetShape(8, 256, ch_tex=-1)) == -1
@@ -161,7 +168,7 @@ def test_failure_hooks_are_an_entry_point_not_environment_variables():
     blob = open(build.build(), "rb").read()
     for name in (b"MOFA_CHAIN_SPIN_LIMIT", b"MOFA_CHAIN_TEST_SKIP_XCD"):
         assert name not in blob, name
-    for name in (b"MOFA_PIPE", b"MOFA_FUSED", b"MOFA_CHAIN"):          # the three knobs that choose between bit-identical forms are still read
+    for name in (b"MOFA_PIPE", b"MOFA_FUSED", b"MOFA_CHAIN", b"MOFA_CHAIN_TRAIN"):   # the knobs that choose between bit-identical forms are still read
         assert name in blob, name
 
 

@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _shipped_launch_forms(monkeypatch):
     """These tests are ABOUT the chained launch: whatever MOFA_* knob the surrounding run exports (the suite is also run under
     MOFA_PIPE=0 / MOFA_CHAIN=0 / MOFA_FUSED=0), they start from the shipped forms and set what they vary themselves."""
-    for k in ("MOFA_PIPE", "MOFA_CHAIN", "MOFA_FUSED"):
+    for k in ("MOFA_PIPE", "MOFA_CHAIN", "MOFA_FUSED", "MOFA_CHAIN_TRAIN"):
         monkeypatch.delenv(k, raising=False)
     lib.reload_env()
     lib.test_hooks()                    # the shipped behaviour (the failure paths are reached through mofa_test_hooks only)
@@ -144,15 +144,17 @@ def test_chained_fitting_backward_is_bit_identical_to_per_layer_launches(D, W, R
 @pytest.mark.parametrize("D,W,R,S", [(10, 1024, 40, 128), (8, 512, 21, 64), (8, 256, 300, 64), (10, 1024, 3, 128), (8, 768, 77, 64), (6, 512, 130, 64)])
 def test_chained_training_backward_is_bit_identical_to_per_layer_launches(D, W, R, S, knob):
     """training's backward was the last per-layer path (every layer's gradient feeds a weight-gradient GEMM between two
-    backward-data products).  Round 6: the weight gradients' units are queue entries of the same chained launches (k_net_chain_train) —
+    backward-data products).  Round 6 (opt-in, MOFA_CHAIN_TRAIN=1: measured a tie, so the default stays per layer — DESIGN.md 9): the
+    weight gradients' units are queue entries of the same chained launches (k_net_chain_train) —
     the per-layer kernel's own tile over the per-layer kernel's own splits of the points (wg_split), partial sums finished by the same
     second stage — so EVERYTHING the step returns must equal MOFA_CHAIN=0's bit for bit: raw, the gradients to rays / folded biases /
     view-bias rows, and every weight gradient.  (3 x 128 and 21 x 64 points: ragged last row tile, XCDs without rows; width 256: the coarse
     network's backward chains too; 768: Hp = 384; D = 6: one-layer second halves.)  The verdict words must say the chained launches ran."""
     h, o, d, z, vd, folded, vb, G = _setup(D, W, R, S)
     runs = {}
-    for chain in ("0", "1"):
+    for chain, train in (("0", "0"), ("1", "1"), ("1", "0")):
         knob("MOFA_CHAIN", chain)
+        knob("MOFA_CHAIN_TRAIN", train)
         before = h.chained_launches()
         og, dg = o.clone().requires_grad_(True), d.clone().requires_grad_(True)
         fo, vbg = folded.clone().requires_grad_(True), vb.clone().requires_grad_(True)
@@ -160,19 +162,22 @@ def test_chained_training_backward_is_bit_identical_to_per_layer_launches(D, W, 
         raw = NetFn.apply(h, og, dg, z, S, S, fo, vbg, None, *ws)
         (raw * G).sum().backward()
         torch.cuda.synchronize()
-        # the tape-keeping forward (width > 256) + the backward's two launches
-        assert h.chained_launches() - before == ((3 if W > 256 else 2) if chain == "1" else 0)
+        # the tape-keeping forward (width > 256) + — with MOFA_CHAIN_TRAIN=1 — the backward's two launches; the DEFAULT training backward is per layer
+        fwd = 1 if W > 256 else 0
+        assert h.chained_launches() - before == (0 if chain == "0" else fwd + (2 if train == "1" else 0))
         h.check_verdict(block=True)
-        runs[chain] = [raw.detach().clone(), og.grad, dg.grad, fo.grad, vbg.grad] + [w.grad for w in ws]
-    for k, (a, b) in enumerate(zip(runs["0"], runs["1"])):
-        assert torch.isfinite(a).all() and torch.equal(a, b), (k, float((a - b).abs().max()))
-    assert all(float(t.abs().sum()) > 0 for t in runs["1"][5:-2])           # the weight gradients are there (not a vacuous comparison)
+        runs[(chain, train)] = [raw.detach().clone(), og.grad, dg.grad, fo.grad, vbg.grad] + [w.grad for w in ws]
+    for key in (("1", "1"), ("1", "0")):
+        for k, (a, b) in enumerate(zip(runs[("0", "0")], runs[key])):
+            assert torch.isfinite(a).all() and torch.equal(a, b), (key, k, float((a - b).abs().max()))
+    assert all(float(t.abs().sum()) > 0 for t in runs[("1", "1")][5:-2])    # the weight gradients are there (not a vacuous comparison)
 
 
-def test_an_incomplete_training_backward_poisons_the_weight_gradients_too():
+def test_an_incomplete_training_backward_poisons_the_weight_gradients_too(knob):
     """The chained training backward leaves the weight gradients as partial sums that are reduced BEHIND the launch: if the launch ends
     incomplete (forced: one poll of budget) the second stage would sum garbage — so the verification behind it overwrites every weight
     gradient with NaN as well (k_chain_poison), next to d_folded / d_view_bias_rows / d_rays, and the host raises."""
+    knob("MOFA_CHAIN_TRAIN", "1")
     h, o, d, z, vd, folded, vb, G = _setup(10, 1024, 16, 128)
     S = 128
     og, dg = o.clone().requires_grad_(True), d.clone().requires_grad_(True)

@@ -150,6 +150,7 @@ def train_arm(name, R, S, n, D=10, W=1024, busy=False, per_step=3):
     ref = [t.clone() for t in step()]
     torch.cuda.synchronize()
     knob("MOFA_CHAIN", "1")
+    knob("MOFA_CHAIN_TRAIN", "1")               # (opt-in: the default training backward is per layer)
     before = h.chained_launches()
     side = torch.cuda.Stream()
     a = torch.randn(4096, 4096, device=DEV)
@@ -164,6 +165,7 @@ def train_arm(name, R, S, n, D=10, W=1024, busy=False, per_step=3):
     torch.cuda.synchronize()
     h.check_verdict(block=True)
     launches = h.chained_launches() - before
+    knob("MOFA_CHAIN_TRAIN", "0")
     assert launches == per_step * n, f"{launches} chained launches for {n} steps (expected {per_step} each)"
     report(name, launches, mism, t0)
 
