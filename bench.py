@@ -60,8 +60,8 @@ KERNELS = [("mofa::k_layer<128,false,false,false,true,mofa::ShippedPolicy>", "fo
            ("mofa::k_net_chain<2>", "BWD backward-data, chained", "the backward-data products of a wide network's fitting step in two launches of the same queues"),
            ("mofa::k_net_chain<1>", "forward + mask tape, chained", "the chained forward whose contiguous-store epilogue also writes (y > 0) as one bit per activation "
                                                                     "(the fitting step's forward)"),
-           ("mofa::k_composite<1,2>", "raw2outputs, coarse pass", "two rays per wavefront (loads of both in flight), 64 samples each: coalesced float4 loads of raw, wavefront prefix product"),
-           ("mofa::k_composite<2,2>", "raw2outputs, fine pass", "the same with two samples per lane (128 samples)"),
+           ("mofa::k_composite<1>", "raw2outputs, coarse pass", "one wavefront per ray, 64 samples: coalesced float4 loads of raw, wavefront prefix product"),
+           ("mofa::k_composite<2>", "raw2outputs, fine pass", "the same with two samples per lane (128 samples)"),
            ("mofa::k_sample_pdf_merge<false>", "sample_pdf + sort(cat) + std", "one wavefront per ray: cdf (fp64 prefix), inverse-cdf search in LDS, merge"),
            ("mofa::k_net_chain_train", "BWD backward-data + weight gradients, chained", "the training backward of a wide network in two launches: backward-data "
                                                                                         "tiles and the weight gradient's [128 x 256] units behind the same queues")]

@@ -277,7 +277,7 @@ int mofa_positional_encode(const float* x, int64_t n, int32_t n_freqs, float* ou
  *     [7] k_net_chain<1> (forward, also writing the mask tape)   [11] k_net_chain_train (the training backward of a wide network as
      chained launches: backward-data products and weight gradients)
  *   HBM-bound ray kernels (work = RAYS; bench.py multiplies by SURVEY section 8d's algorithmic bytes per ray):
- *     [8] k_composite<1,2> (S <= 64: the coarse pass)   [9] k_composite<2,2> (S <= 128: the fine pass)   [10] k_sample_pdf_merge
+ *     [8] k_composite<1> (S <= 64: the coarse pass)   [9] k_composite<2> (S <= 128: the fine pass)   [10] k_sample_pdf_merge
  * Used by bench.py only. */
 #define MOFA_PROF_KINDS 12
 int mofa_prof_begin(void);

@@ -1338,7 +1338,7 @@ __global__ __launch_bounds__(256, 2) void k_net_chain_train(const TrainChainArgs
 // closes (mofa_prof_begin/end); it is kept per device and guarded by a mutex, so two devices or two host threads in one process
 // do not share or corrupt it.  When no session is open the launch paths only read one relaxed atomic.
 constexpr int kProfKinds = MOFA_PROF_KINDS;   // 0: k_layer<128,..,PIPE> (forward), 1: k_mlp_fused, 2: k_layer<BWD>, 3: k_wgrad, 4: k_layer<..PERRAY> (view layer), 5: k_net_chain<0> (forward),
-                                              // 6: k_net_chain<2> (backward-data), 7: k_net_chain<1> (forward + mask bits); the HBM-bound ray kernels (work = rays): 8: k_composite<1,2>, 9: k_composite<2,2>,
+                                              // 6: k_net_chain<2> (backward-data), 7: k_net_chain<1> (forward + mask bits); the HBM-bound ray kernels (work = rays): 8: k_composite<1>, 9: k_composite<2>,
                                               // 10: k_sample_pdf_merge; 11: k_net_chain_train (training backward: products + weight gradients)
 struct ProfState {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;

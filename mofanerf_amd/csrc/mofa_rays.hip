@@ -85,11 +85,7 @@ __global__ __launch_bounds__(256) void k_rays_pose_backward(int W, float fx, flo
 // ---- raw2outputs (models/render_class.py:440-482) --------------------------------------------------
 // One wavefront per ray; lane l owns samples [l*SPL, l*SPL+SPL).  T_i = prod_{j<i} (1 - alpha_j + 1e-10)
 // is an in-lane running product combined with a 6-step wavefront exclusive prefix product.
-// RPW rays per wavefront (round 6): a wave is a dependent chain — loads, ~300 VALU instructions, shuffles, stores — and with one ray per
-// wave the chip held 32 waves x 1 KiB of loads in flight per CU: 3.4-3.8 TB/s by Little's law (roofline_hbm 0.43-0.48, waves parked 42-54 %,
-// profiles/hbm_traffic_rays.json).  Every load of the wave's RPW rays is issued BEFORE the first one is used, so twice the bytes are in flight
-// per wave; each ray's arithmetic is unchanged (bit-identical results).
-template <int SPL, int RPW>
+template <int SPL>
 __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw, const float* __restrict__ z,
                                                    long long z_row_stride, const float* __restrict__ rays_d,
                                                    const float* __restrict__ noise, long long n_rays, int S,
@@ -97,90 +93,71 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
                                                    float* __restrict__ disp_out, float* __restrict__ acc_out,
                                                    float* __restrict__ depth_out, float* __restrict__ weights_out) {
     const int lane = threadIdx.x & 63;
-    const long long ray0 = ((long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * RPW;
-    if (ray0 >= n_rays) return;
+    const long long ray = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const float dx = rays_d[ray * 3], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+    const float dnorm = __fsqrt_rn(dx * dx + dy * dy + dz * dz);
+    const float* zr = z + ray * z_row_stride;
+    const f32x4* rr = (const f32x4*)(raw + ray * (long long)S * 4);
+
+    float zv[SPL + 1], alpha[SPL], cr[SPL], cg[SPL], cb[SPL];
     const int s0 = lane * SPL;
-    // phase 1: all loads (a ray index past the end repeats the last ray: valid addresses, its results are not stored)
-    f32x4 rv[RPW][SPL];
-    float zv[RPW][SPL + 1], nz[RPW][SPL], dx[RPW], dy[RPW], dz[RPW];
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        const long long ray = ray0 + r < n_rays ? ray0 + r : n_rays - 1;
-        dx[r] = rays_d[ray * 3], dy[r] = rays_d[ray * 3 + 1], dz[r] = rays_d[ray * 3 + 2];
-        const float* zr = z + ray * z_row_stride;
-        const f32x4* rr = (const f32x4*)(raw + ray * (long long)S * 4);
+    for (int t = 0; t <= SPL; ++t) zv[t] = (s0 + t < S) ? zr[s0 + t] : 0.f;
+    float run = 1.0f;  // product of this lane's (1 - alpha + 1e-10)
 #pragma unroll
-        for (int t = 0; t <= SPL; ++t) zv[r][t] = (s0 + t < S) ? zr[s0 + t] : 0.f;
-#pragma unroll
-        for (int t = 0; t < SPL; ++t) {
-            const int s = s0 + t;
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            rv[r][t] = s < S ? rr[s] : zero;
-            nz[r][t] = (noise && s < S) ? noise[ray * (long long)S + s] : 0.f;
+    for (int t = 0; t < SPL; ++t) {
+        const int s = s0 + t;
+        if (s < S) {
+            const f32x4 v = rr[s];
+            float dist = (s + 1 < S) ? (zv[t + 1] - zv[t]) : 1e10f;
+            dist = dist * dnorm;
+            float sig = v.w;
+            if (noise) sig = sig + noise[ray * (long long)S + s];
+            sig = relu_np(sig);
+            alpha[t] = 1.0f - expf(-sig * dist);
+            cr[t] = 1.0f / (1.0f + expf(-v.x));
+            cg[t] = 1.0f / (1.0f + expf(-v.y));
+            cb[t] = 1.0f / (1.0f + expf(-v.z));
+            run = run * ((1.0f - alpha[t]) + 1e-10f);
+        } else {
+            alpha[t] = 0.f, cr[t] = cg[t] = cb[t] = 0.f;
         }
     }
-    // phase 2: one ray after the other, the arithmetic of the one-ray kernel
+    // exclusive prefix product across lanes
+    float incl = run;
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        const long long ray = ray0 + r;
-        if (ray >= n_rays) break;                          // wave-uniform
-        const float dnorm = __fsqrt_rn(dx[r] * dx[r] + dy[r] * dy[r] + dz[r] * dz[r]);
-        float alpha[SPL], cr[SPL], cg[SPL], cb[SPL];
-        float run = 1.0f;  // product of this lane's (1 - alpha + 1e-10)
-#pragma unroll
-        for (int t = 0; t < SPL; ++t) {
-            const int s = s0 + t;
-            if (s < S) {
-                const f32x4 v = rv[r][t];
-                float dist = (s + 1 < S) ? (zv[r][t + 1] - zv[r][t]) : 1e10f;
-                dist = dist * dnorm;
-                float sig = v.w;
-                if (noise) sig = sig + nz[r][t];
-                sig = relu_np(sig);
-                alpha[t] = 1.0f - expf(-sig * dist);
-                cr[t] = 1.0f / (1.0f + expf(-v.x));
-                cg[t] = 1.0f / (1.0f + expf(-v.y));
-                cb[t] = 1.0f / (1.0f + expf(-v.z));
-                run = run * ((1.0f - alpha[t]) + 1e-10f);
-            } else {
-                alpha[t] = 0.f, cr[t] = cg[t] = cb[t] = 0.f;
-            }
-        }
-        // exclusive prefix product across lanes
-        float incl = run;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const float up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl = incl * up;
-        }
-        float T = __shfl_up(incl, 1, 64);
-        if (lane == 0) T = 1.0f;
+    for (int o = 1; o < 64; o <<= 1) {
+        const float up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl = incl * up;
+    }
+    float T = __shfl_up(incl, 1, 64);
+    if (lane == 0) T = 1.0f;
 
-        float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+    float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
 #pragma unroll
-        for (int t = 0; t < SPL; ++t) {
-            const int s = s0 + t;
-            if (s < S) {
-                const float w = alpha[t] * T;
-                weights_out[ray * (long long)S + s] = w;
-                sr += w * cr[t], sg += w * cg[t], sb += w * cb[t];
-                sd += w * zv[r][t];
-                sa += w;
-                T = T * ((1.0f - alpha[t]) + 1e-10f);
-            }
+    for (int t = 0; t < SPL; ++t) {
+        const int s = s0 + t;
+        if (s < S) {
+            const float w = alpha[t] * T;
+            weights_out[ray * (long long)S + s] = w;
+            sr += w * cr[t], sg += w * cg[t], sb += w * cb[t];
+            sd += w * zv[t];
+            sa += w;
+            T = T * ((1.0f - alpha[t]) + 1e-10f);
         }
-        sr = wave_sum(sr), sg = wave_sum(sg), sb = wave_sum(sb), sd = wave_sum(sd), sa = wave_sum(sa);
-        if (lane == 0) {
-            if (white_bkgd) {
-                const float bg = 1.0f - sa;
-                sr += bg, sg += bg, sb += bg;
-            }
-            rgb_out[ray * 3] = sr, rgb_out[ray * 3 + 1] = sg, rgb_out[ray * 3 + 2] = sb;
-            const float q = __fdiv_rn(sd, sa);  // 0/0 -> NaN, and torch.max propagates it (render_class.py:476)
-            disp_out[ray] = (q != q) ? q : __fdiv_rn(1.0f, fmaxf(1e-10f, q));
-            acc_out[ray] = sa;
-            depth_out[ray] = sd;
+    }
+    sr = wave_sum(sr), sg = wave_sum(sg), sb = wave_sum(sb), sd = wave_sum(sd), sa = wave_sum(sa);
+    if (lane == 0) {
+        if (white_bkgd) {
+            const float bg = 1.0f - sa;
+            sr += bg, sg += bg, sb += bg;
         }
+        rgb_out[ray * 3] = sr, rgb_out[ray * 3 + 1] = sg, rgb_out[ray * 3 + 2] = sb;
+        const float q = __fdiv_rn(sd, sa);  // 0/0 -> NaN, and torch.max propagates it (render_class.py:476)
+        disp_out[ray] = (q != q) ? q : __fdiv_rn(1.0f, fmaxf(1e-10f, q));
+        acc_out[ray] = sa;
+        depth_out[ray] = sd;
     }
 }
 
@@ -440,15 +417,13 @@ int mofa_composite_forward(const float* raw, const float* z, int64_t z_row_strid
                            float* disp, float* acc, float* depth, float* weights, void* stream) {
     MOFA_REQUIRE(raw && z && rays_d && rgb && disp && acc && depth && weights, "composite_forward: null pointer");
     MOFA_REQUIRE(n_rays > 0 && S >= 2, "composite_forward: need S >= 2 (got %d)", S);
-    constexpr int kRaysPerWave = 2;
-    const dim3 grid(blocks_for(n_rays, kWavesPerBlock)), block(256);                                  // (the > 256-sample kernel: one ray per wave)
-    const dim3 grid2(blocks_for(n_rays, kWavesPerBlock * kRaysPerWave));
+    const dim3 grid(blocks_for(n_rays, kWavesPerBlock)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const int pkind = S <= 64 ? 8 : (S <= 128 ? 9 : -1);            // the two instantiations of the benchmark's passes
     const int prof = pkind >= 0 ? mofa_internal_prof_open(stream, pkind) : 0;
     if (prof < 0) return MOFA_EHIP;
-#define MOFA_COMPOSITE(SPL)                                                                                                       \
-    hipLaunchKernelGGL((k_composite<SPL, kRaysPerWave>), grid2, block, 0, st, raw, z, (long long)z_row_stride, rays_d, noise, \
+#define MOFA_COMPOSITE(SPL)                                                                                     \
+    hipLaunchKernelGGL((k_composite<SPL>), grid, block, 0, st, raw, z, (long long)z_row_stride, rays_d, noise, \
                        (long long)n_rays, S, white_bkgd, rgb, disp, acc, depth, weights)
     if (S <= 64) MOFA_COMPOSITE(1);
     else if (S <= 128) MOFA_COMPOSITE(2);

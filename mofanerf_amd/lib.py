@@ -134,7 +134,7 @@ def load() -> C.CDLL:
 
 
 PROF_KINDS = 12    # MOFA_PROF_KINDS: k_layer fwd, k_mlp_fused, k_layer<BWD>, k_wgrad, k_layer fwd with per-ray bias (view layer), k_net_chain<0> fwd,
-                   # k_net_chain<2> bwd, k_net_chain<1> fwd + mask, and the HBM-bound ray kernels k_composite<1,2>, k_composite<2,2>, k_sample_pdf_merge; 11: k_net_chain_train
+                   # k_net_chain<2> bwd, k_net_chain<1> fwd + mask, and the HBM-bound ray kernels k_composite<1>, k_composite<2>, k_sample_pdf_merge; 11: k_net_chain_train
 VERDICT_WORDS = 8  # MOFA_VERDICT_WORDS
 
 

@@ -153,7 +153,7 @@ def test_profiler_kinds_agree_between_header_binding_and_bench():
     assert n == lib.PROF_KINDS == len(bench.KERNELS) == 12 and bench.KERNELS[11][0] == "mofa::k_net_chain_train" and 11 in bench.MFMA_KINDS
     assert bench.KERNELS[5][0] == "mofa::k_net_chain<0>" and bench.KERNELS[6][0] == "mofa::k_net_chain<2>" and bench.KERNELS[1][0] == "mofa::k_mlp_fused"
     # the mask-writing chained forward is its own kind (the fit line named <0> while <1> ran); the HBM-bound ray kernels follow
-    assert bench.KERNELS[7][0] == "mofa::k_net_chain<1>" and [k[0] for k in bench.KERNELS[8:11]] == ["mofa::k_composite<1,2>", "mofa::k_composite<2,2>",
+    assert bench.KERNELS[7][0] == "mofa::k_net_chain<1>" and [k[0] for k in bench.KERNELS[8:11]] == ["mofa::k_composite<1>", "mofa::k_composite<2>",
                                                                                                    "mofa::k_sample_pdf_merge<false>"]
     assert set(bench.HBM_KINDS) == {8, 9, 10} and all(bench.HBM_KINDS[k] > 1000 for k in bench.HBM_KINDS)
 

@@ -267,9 +267,9 @@ def test_bench_roofline_hbm_prices_the_ray_kernels_against_the_hbm_peak():
     ms[8], launches[8], work[8] = 0.2, 2, 2 * 131072.0                            # two coarse composites of 131,072 rays, 100 us each
     ms[10], launches[10], work[10] = 0.5, 2, 2 * 131072.0
     assert bench.HBM_KINDS == {8: 1568, 9: 2616, 10: 1284}                        # SURVEY 8d's per-ray figures (1,568 / 2,616 / ~1.3 k)
-    tj = {"csrc_sha256": "abc", "kernels": {"mofa::k_composite<1,2>": {"bytes_per_launch": 250e6, "rays_per_launch": 131072, "algorithmic_bytes_per_launch": 205520896}}}
+    tj = {"csrc_sha256": "abc", "kernels": {"mofa::k_composite<1>": {"bytes_per_launch": 250e6, "rays_per_launch": 131072, "algorithmic_bytes_per_launch": 205520896}}}
     r = bench.roofline_hbm_of(ms, launches, work, dt=1.0, traffic_json=tj, digest="abc")
-    assert [x["kernel"].split(" ")[0] for x in r] == ["mofa::k_composite<1,2>", "mofa::k_sample_pdf_merge<false>"]
+    assert [x["kernel"].split(" ")[0] for x in r] == ["mofa::k_composite<1>", "mofa::k_sample_pdf_merge<false>"]
     c = r[0]
     assert c["bound"] == "hbm" and c["unit"] == "GB/s" and c["peak"] == 8000.0 and c["launches"] == 2 and abs(c["avg_launch_us"] - 100.0) < 1e-9
     assert abs(c["achieved"] - 131072 * 1568 / 100e-6 / 1e9) < 0.1 and abs(c["frac"] - c["achieved"] / 8000.0) < 1e-4 and c["traffic"] == 250e6

@@ -23,7 +23,7 @@ out = {"csrc_sha256": build.csrc_digest(), "rays_per_launch": R, "launches_avera
                "four launches of each kernel; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE as reported"}
 for kind, per_ray in bench.HBM_KINDS.items():
     name = bench.KERNELS[kind][0]
-    c = next((v for k, v in m.items() if k.replace("mofa::", "").replace(" ", "") == name.replace("mofa::", "").replace(" ", "")), None)
+    c = next((v for k, v in m.items() if k.replace("mofa::", "") == name.replace("mofa::", "")), None)
     if c is None:
         continue
     a = {k: sum(v) / len(v) for k, v in c.items()}

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Driver for rocprofv3 --pmc passes over the HBM-bound ray kernels at the benchmark's shapes (one render_rays chunk of the 512 x 512 frame:
-196,608 rays): k_composite<1,2> (64 coarse samples, one shared z row), k_sample_pdf_merge<false> (64 + 64, det) and k_composite<2,2> (128 merged
+196,608 rays): k_composite<1> (64 coarse samples, one shared z row), k_sample_pdf_merge<false> (64 + 64, det) and k_composite<2> (128 merged
 samples, per-ray z), four launches each.  tools/gpu_profile_rays.sh wraps it, one pass per counter group; tools/make_traffic_rays_json.py turns
 the passes into profiles/hbm_traffic_rays.json (what bench.py quotes as roofline_hbm[*].traffic)."""
 import os, sys
