@@ -346,6 +346,14 @@ def roofline_hbm_of(ms, launches, work, dt, traffic_json=None, digest=None):
                 rec["traffic"] = tj.get("bytes_per_launch")
                 rec["traffic_rays_per_launch"] = tj.get("rays_per_launch")
                 rec["traffic_algorithmic_bytes_same_shape"] = tj.get("algorithmic_bytes_per_launch")
+                if tj.get("sq_insts_valu_per_ray"):
+                    # what actually binds these kernels (round 6): a ray is ONE wavefront, and its vector instructions alone — exp / sigmoid /
+                    # division, the prefix product and five butterflies; the fp64 cdf scan and searches — take this long on the chip's 1,024
+                    # SIMDs (4 cycles per wave64 instruction at the measured 2.39 GHz): SURVEY 8d classed them HBM-bound a priori
+                    floor_us = rec["rays_per_launch_avg"] * tj["sq_insts_valu_per_ray"] * 4 / (1024 * 2.39e9) * 1e6
+                    rec["valu_insts_per_ray_pmc"] = tj["sq_insts_valu_per_ray"]
+                    rec["valu_issue_floor_us"] = round(floor_us, 2)
+                    rec["binding"] = "valu issue" if floor_us >= 0.8 * rec["avg_launch_us"] else "hbm"
             else:
                 rec["traffic_source"] = f"null: profiles/hbm_traffic_rays.json was taken on kernel sources {str(traffic_json.get('csrc_sha256'))[:16]}, this build is {str(digest)[:16]}"
         out.append(rec)
@@ -401,7 +409,7 @@ def bulk_variant(dev, size=256, identities=2, expressions=2, views=3, workers=4)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     t0 = time.perf_counter()
-    n_plain = job([identities], expressions, angles, None)  # a fresh identity (its texture code is not cached), no output stage
+    n_plain = job([identities], 1, angles, None)            # a fresh identity (its texture code is not cached), one expression, no output stage
     torch.cuda.synchronize()
     dt_plain = time.perf_counter() - t0
     render.check_launches(block=True)
@@ -415,7 +423,7 @@ def bulk_variant(dev, size=256, identities=2, expressions=2, views=3, workers=4)
             "sink_queue_high_water": int(high), "sink_workers": workers,
             "without_output_stage": {"value": round(n_plain * size * size / dt_plain, 1), "unit": "rays/s", "frames": n_plain, "seconds": round(dt_plain, 3),
                                      "ms_per_frame": round(dt_plain / n_plain * 1e3, 2),
-                                     "what": "the same loop with savedir=None on one further identity (frames still return to the host as numpy arrays, as render_path does)"},
+                                     "what": "the same loop with savedir=None on one further identity and one expression (frames still return to the host as numpy arrays, as render_path does)"},
             "output_stage_cost_fraction": round(1.0 - (dt_plain / n_plain) / (dt_sink / n_sink), 4)}
 
 

@@ -510,15 +510,20 @@ __global__ __launch_bounds__(256) void k_composite_backward_long(
     }
 }
 
-// ---- head bias gradient: out[c] = sum_m d_raw[m][off + c]  (single block; 4 floats per point) ------------------
-__global__ __launch_bounds__(1024) void k_raw_colsum(const float* __restrict__ d_raw, long long n_points, int off, int n,
-                                                     float* __restrict__ out) {
+// ---- head bias gradients: the four column sums of d_raw [n_points][4] (rgb head: columns 0..2, sigma head: column 3) in ONE pass ----
+// Round 6: this was one 1,024-thread workgroup per head walking all the points — 95 us per call at a training sub-batch, twice per
+// backward (0.16 % of a training step on a single CU).  Now up to 256 workgroups sum contiguous ranges of the points into partial rows
+// and a second kernel adds the rows in index order: deterministic, independent of the device; both heads from one read of d_raw.
+constexpr int kRawColsumRows = 16384;       // points per workgroup (a multiple of the 1,024-thread stride)
+__global__ __launch_bounds__(1024) void k_raw_colsum(const float* __restrict__ d_raw, long long n_points, float* __restrict__ partial) {
     __shared__ float red[1024][4];
+    const long long lo = (long long)blockIdx.x * kRawColsumRows;
+    long long hi = lo + kRawColsumRows;
+    if (hi > n_points) hi = n_points;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (long long m = threadIdx.x; m < n_points; m += 1024) {      // one 16-byte load per point: the 4 raw columns
+    for (long long m = lo + threadIdx.x; m < hi; m += 1024) {      // one 16-byte load per point: the 4 raw columns
         const f32x4 v = *(const f32x4*)(d_raw + m * 4);
-        const float r[4] = {v.x, v.y, v.z, v.w};
-        for (int c = 0; c < n; ++c) acc[c] += r[off + c];
+        acc[0] += v.x, acc[1] += v.y, acc[2] += v.z, acc[3] += v.w;
     }
     for (int c = 0; c < 4; ++c) red[threadIdx.x][c] = acc[c];
     __syncthreads();
@@ -527,7 +532,16 @@ __global__ __launch_bounds__(1024) void k_raw_colsum(const float* __restrict__ d
             for (int c = 0; c < 4; ++c) red[threadIdx.x][c] += red[threadIdx.x + s][c];
         __syncthreads();
     }
-    if (threadIdx.x < 4) out[threadIdx.x] = threadIdx.x < n ? red[0][threadIdx.x] : 0.f;
+    if (threadIdx.x < 4) partial[(long long)blockIdx.x * 4 + threadIdx.x] = red[0][threadIdx.x];
+}
+// out_rgb[0..3] = {sum col 0, 1, 2, 0}, out_sigma[0..3] = {sum col 3, 0, 0, 0} (the heads' folded-bias slots are 4 floats wide)
+__global__ void k_raw_colsum_combine(const float* __restrict__ partial, int rows, float* __restrict__ out_rgb, float* __restrict__ out_sigma) {
+    const int c = threadIdx.x;
+    if (c >= 4) return;
+    float t = 0.f;
+    for (int r = 0; r < rows; ++r) t += partial[r * 4 + c];
+    if (c < 3) out_rgb[c] = t;
+    else out_rgb[3] = 0.f, out_sigma[0] = t, out_sigma[1] = 0.f, out_sigma[2] = 0.f, out_sigma[3] = 0.f;
 }
 
 inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
@@ -563,8 +577,11 @@ static int head_backward(const float* d_raw, int32_t raw_off, int32_t n_out, con
     return check_launch("k_head_backward");
 }
 
-int mofa_internal_raw_colsum(const float* d_raw, long long n_points, int off, int n, float* out, void* stream) {
-    hipLaunchKernelGGL(k_raw_colsum, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_raw, n_points, off, n, out);
+// internal (mofa_net_backward): both heads' bias gradients; `scratch`: 4 floats per 16,384 points
+int mofa_internal_raw_colsum(const float* d_raw, long long n_points, float* out_rgb, float* out_sigma, float* scratch, void* stream) {
+    const int rows = (int)((n_points + kRawColsumRows - 1) / kRawColsumRows);
+    hipLaunchKernelGGL(k_raw_colsum, dim3(rows), dim3(1024), 0, (hipStream_t)stream, d_raw, n_points, scratch);
+    hipLaunchKernelGGL(k_raw_colsum_combine, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, rows, out_rgb, out_sigma);
     return check_launch("k_raw_colsum");
 }
 
@@ -676,10 +693,25 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ g, c
                        partial + (long long)split * n_padded * k_padded, bias_partial ? bias_partial + (long long)split * n_padded : nullptr, pipe, smem, hook);
 }
 
-// dst[n][col0 + k] = sum_s partial[s][n][k]   for n < n_out, k < ncols  (natural PyTorch [out, in] gradient layout)
+// dst[n][col0 + k] = sum_s partial[s][n][k]   for n < n_out, k < ncols  (natural PyTorch [out, in] gradient layout) — and, from the blocks
+// behind those (round 6: it was a launch of its own, 112 per training step of 17 us each), the bias gradient bias_out[n] = sum_s
+// bias_partial[s][n]: 64 columns per block, the splits dealt round-robin to 4 thread groups, combined through LDS in a fixed order
+// (deterministic; a single thread walking all the splits of its column was a 60 us latency chain).
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int splits, int n_padded,
                                                       int k_padded, int n_out, int ncols, float* __restrict__ dst,
-                                                      int ld, int col0) {
+                                                      int ld, int col0, int main_blocks, const float* __restrict__ bias_partial,
+                                                      float* __restrict__ bias_out) {
+    if ((int)blockIdx.x >= main_blocks) {            // block-uniform: the bias columns
+        __shared__ float red[4][64];
+        const int col = ((int)blockIdx.x - main_blocks) * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+        float s = 0.f;
+        if (col < n_padded)
+            for (int sp = grp; sp < splits; sp += 4) s += bias_partial[(long long)sp * n_padded + col];
+        red[grp][threadIdx.x & 63] = s;
+        __syncthreads();
+        if (grp == 0 && col < n_padded) bias_out[col] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        return;
+    }
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)n_out * ncols) return;
     const int n = (int)(idx / ncols), k = (int)(idx - (long long)n * ncols);
@@ -696,20 +728,6 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     }
     for (; sp < splits; ++sp) s += p[(long long)sp * stride];
     dst[(long long)n * ld + col0 + k] = s;
-}
-
-// out[n] = sum_s partial[s][n]: 64 columns per block, the splits dealt round-robin to 4 thread groups, combined through LDS in a
-// fixed order (deterministic) — a single thread walking all the splits of its column was a 60 us latency chain
-__global__ __launch_bounds__(256) void k_bias_reduce(const float* __restrict__ partial, int splits, int n_padded,
-                                                     float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
-    float s = 0.f;
-    if (col < n_padded)
-        for (int sp = grp; sp < splits; sp += 4) s += partial[(long long)sp * n_padded + col];
-    red[grp][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (grp == 0 && col < n_padded) out[col] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
 // head weight gradient: dst[o][k] = sum_m d_raw[m][off+o] * X[m][k]; blockIdx.x = 16-feature panel of X, blockIdx.y = slice of the
@@ -870,11 +888,9 @@ int mofa_internal_wgrad_reduce(const float* partial, int splits, int n_padded, i
                                int col0, float* bias_out, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const long long total = (long long)n_out * ncols;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, splits,
-                       n_padded, k_padded, n_out, ncols, dst, ld, col0);
-    if (bias_out)
-        hipLaunchKernelGGL(k_bias_reduce, dim3((unsigned)((n_padded + 63) / 64)), dim3(256), 0, st,
-                           partial + (size_t)splits * n_padded * k_padded, splits, n_padded, bias_out);
+    const int main_blocks = (int)((total + 255) / 256), bias_blocks = bias_out ? (n_padded + 63) / 64 : 0;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(main_blocks + bias_blocks)), dim3(256), 0, st, partial, splits,
+                       n_padded, k_padded, n_out, ncols, dst, ld, col0, main_blocks, partial + (size_t)splits * n_padded * k_padded, bias_out);
     return check_launch("k_wgrad_reduce");
 }
 

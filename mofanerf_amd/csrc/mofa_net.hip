@@ -16,7 +16,7 @@ int mofa_internal_fold_bias(const float* w, int n_out, int ld, int col0, int nco
                             const float* bias, float* out, int n_padded, void* stream);
 int mofa_internal_dense_rows(const float* w, int n_out, int ld, int col0, int ncols, float* dst, int k_padded,
                              void* stream);
-int mofa_internal_raw_colsum(const float* d_raw, long long n_points, int off, int n, float* out, void* stream);
+int mofa_internal_raw_colsum(const float* d_raw, long long n_points, float* out_rgb, float* out_sigma, float* scratch, void* stream);
 int mofa_internal_fused_forward(const float* arena, float* arena_w, const float* packed, const float* folded,
                                 const float* view_bias_rows, long long bias_rows, const float* rays_o, const float* rays_d,
                                 const float* z, long long z_row_stride, const float* pts, long long n_points, int S,
@@ -814,8 +814,7 @@ int mofa_net_backward(MofaNetShape s, const float* packed, const float* packed_t
     if (!d_weights && hipMemsetAsync(d_folded, 0, p.folded_floats * sizeof(float), (hipStream_t)stream) != hipSuccess)
         return check_launch("hipMemsetAsync(d_folded)");
     // heads' bias gradients
-    MOFA_TRY(mofa_internal_raw_colsum(d_raw, M, 3, 1, d_folded + p.L[p.alpha].folded_off, stream));
-    MOFA_TRY(mofa_internal_raw_colsum(d_raw, M, 0, 3, d_folded + p.L[p.rgb].folded_off, stream));
+    MOFA_TRY(mofa_internal_raw_colsum(d_raw, M, d_folded + p.L[p.rgb].folded_off, d_folded + p.L[p.alpha].folded_off, wws, stream));
     // rgb head -> gradient at the view layer's output (masked by its ReLU); its per-ray sums are d(view bias rows)
     {
         const Layer& r = p.L[p.rgb];

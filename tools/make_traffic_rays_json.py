@@ -41,6 +41,8 @@ for kind, per_ray in bench.HBM_KINDS.items():
     for k in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU"):
         if k in a:
             rec[k.lower() + "_per_ray"] = round(a[k] / R, 1)
+    if "SQ_INSTS_VALU" in a:      # one ray = one wavefront: its vector instructions x 4 cycles (wave64 on a 16-lane SIMD) over 1,024 SIMDs at 2.39 GHz
+        rec["valu_issue_floor_us_per_launch"] = round(a["SQ_INSTS_VALU"] * 4 / (1024 * 2.39e9) * 1e6, 1)
     out["kernels"][name] = rec
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out)[:2000])
