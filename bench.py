@@ -353,7 +353,8 @@ def roofline_hbm_of(ms, launches, work, dt, traffic_json=None, digest=None):
                     floor_us = rec["rays_per_launch_avg"] * tj["sq_insts_valu_per_ray"] * 4 / (1024 * 2.39e9) * 1e6
                     rec["valu_insts_per_ray_pmc"] = tj["sq_insts_valu_per_ray"]
                     rec["valu_issue_floor_us"] = round(floor_us, 2)
-                    rec["binding"] = "valu issue" if floor_us >= 0.8 * rec["avg_launch_us"] else "hbm"
+                    rec["binding"] = ("valu issue" if floor_us >= 0.8 * rec["avg_launch_us"] else
+                                      "launch latency (a few thousand rays per launch)" if rec["avg_launch_us"] < 25.0 else "hbm")
             else:
                 rec["traffic_source"] = f"null: profiles/hbm_traffic_rays.json was taken on kernel sources {str(traffic_json.get('csrc_sha256'))[:16]}, this build is {str(digest)[:16]}"
         out.append(rec)

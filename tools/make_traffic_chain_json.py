@@ -14,6 +14,10 @@ m = collections.defaultdict(list)
 for f in sorted(glob.glob(os.path.join(src, "pmc_chain_*.csv"))):
     for r in csv.DictReader(open(f)):
         m[r["Counter_Name"]].append(float(r["Counter_Value"]))
+# every process's first two k_net_chain<0> dispatches are mofa_device_init's self-check (a 10 x 512 network on 4,096 points: ~1/40 of a
+# benchmark launch in every counter) — they are not the kernel this file describes: keep the dispatches within a factor 5 of the largest
+m = {c: [x for x in v if x >= 0.2 * max(v)] for c, v in m.items()}
+launches = {c: len(v) for c, v in m.items()}
 m = {c: sum(v) / len(v) for c, v in m.items()}
 M, D, W = 196608, 10, 1024
 mac = schema.mac_per_point(D, W, folded=True) - (W * 1 + (W // 2) * 3)                 # the MFMA layers (the two heads are k_head)
@@ -24,7 +28,7 @@ act_in = M * 64 * 4 + (n_mfma - 1 + 2) * M * W * 4
 out = {"kernel": "mofa::k_net_chain<0>",
        "shape": f"fine network {W} x {D} ({n_mfma} MFMA layers) on M = {M} points (768 row tiles): {2 * mac * M / 1e12:.2f} TFLOP per launch",
        "csrc_sha256": build.csrc_digest(),
-       "launches_averaged": 4,
+       "launches_averaged": min(launches.values()),
        "fetch_size_corrected_x2_bytes": int(m["FETCH_SIZE"] * 2048), "write_size_bytes": int(m["WRITE_SIZE"] * 1024),
        "bytes_per_launch": int(m["FETCH_SIZE"] * 2048 + m["WRITE_SIZE"] * 1024),
        "algorithmic_read_bytes": act_in + mac * 4,
@@ -33,7 +37,7 @@ out = {"kernel": "mofa::k_net_chain<0>",
        "algorithmic_note": "every layer's output written once and read once by its consumer(s) (the two skip layers read their block's input a second "
                            "time), the encoding panels read once, every weight once",
        "note": "one rocprofv3 --pmc pass per counter group (no tracing next to --pmc) over tools/pmc_chain.py; per-dispatch counters averaged over the "
-               "four launches; mfma_busy_fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)"}
+               "four launches (mofa_device_init's two small self-check launches of the same kernel left out); mfma_busy_fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)"}
 if "GRBM_GUI_ACTIVE" in m:
     out["mfma_busy_fraction"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * m["GRBM_GUI_ACTIVE"] / 8), 4)
 if "TCC_HIT_sum" in m:
