@@ -6,7 +6,8 @@ tools/gpu_profile_train.sh wraps it."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tools.stress_chain_setup import setup  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from stress_chain_setup import setup  # noqa: E402
 from mofanerf_amd.autograd import NetFn  # noqa: E402
 
 R, S = 1536, 128
