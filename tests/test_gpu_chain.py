@@ -275,11 +275,15 @@ def test_an_unworked_xcd_queue_is_loud_not_wrong(xcd):
     assert torch.equal(again, ref)
 
 
-def test_renderer_surfaces_an_incomplete_launch(tmp_path):
+@pytest.mark.parametrize("n_streams", [1, 2])
+def test_renderer_surfaces_an_incomplete_launch(n_streams, tmp_path):
     """End to end: a frame whose chained launch ended incomplete is NaN, `check_launches()` raises, and `render_path` refuses to
-    turn it into a PNG."""
+    turn it into a PNG — also with the sub-batches on two side streams (two streams copying into the one pinned mirror
+    could overwrite a raised flag with an older clean copy; the side streams no longer snapshot, the renderer does once on the main
+    stream after joining them) and with the PNG worker looking at the frame's OWN verdict token."""
     from harness import make_product
     render, kw, _ = make_product((8, 64, 10, 512), 0, 4096, DEV)
+    render.n_streams = n_streams
     bm, tex, exp = [t.to(DEV) for t in synth.codes(0)]
     K = synth.intrinsics(16, 16)
     from mofanerf_amd import rays
