@@ -251,3 +251,37 @@ def test_inline_asm_writelanes_keep_the_valu_sgpr_wait_states(tmp_path):
             j -= 1
     assert total >= 64, total            # the mask writers are there (16 ballots x 2 halves per 4 KiB slice, several instantiations)
     assert hazards == 0, hazards
+
+
+def test_weight_gradient_split_plan_partitions_the_row_tiles():
+    """`wg_split` (csrc/mofa_common.h) — ONE plan of how the weight gradient splits its contraction over the points, shared by the per-layer
+    kernel and the chained training backward: whole row tiles, never straddling the row ranges k_net_chain gives the eight XCDs, every row tile
+    in exactly one split.  Restated here and tied to the library through the workspace size it implies (splits x N x (K + 1) floats)."""
+    L = lib.load()
+
+    def plan(n_points, n_padded, k_padded):
+        tn = 128 if n_padded % 128 == 0 else 64
+        tk = 256 if (tn == 128 and k_padded % 256 == 0) else (128 if k_padded % 128 == 0 else 64)
+        out_tiles = (n_padded // tn) * (k_padded // tk)
+        m_tiles = (n_points + 255) // 256
+        mpx = (m_tiles + 7) // 8
+        want = max(1, (128 + out_tiles - 1) // out_tiles)
+        spt = max(1, (mpx + want - 1) // want)
+        nspx = (mpx + spt - 1) // spt
+        full, rem = divmod(m_tiles, mpx)
+        total = full * nspx + (rem + spt - 1) // spt
+        rows = []
+        for s in range(total):
+            x, j = divmod(s, nspx)
+            first = x * mpx + j * spt
+            end = min(first + spt, min((x + 1) * mpx, m_tiles))
+            assert first // mpx == (end - 1) // mpx == x, "a split straddles two XCD ranges"
+            rows += list(range(first, end))
+        assert rows == list(range(m_tiles)), (n_points, n_padded, k_padded)     # every row tile exactly once, in order
+        return total
+
+    for n_points in (1, 255, 257, 1344, 4096, 131072, 196608, 196609, 524288, 300 * 64):
+        for n_padded, k_padded in ((1024, 1024), (512, 1024), (256, 256), (128, 256), (1024, 64), (64, 64), (768, 768)):
+            assert L.mofa_weight_grad_workspace_floats(n_points, n_padded, k_padded) == plan(n_points, n_padded, k_padded) * n_padded * (k_padded + 1), \
+                (n_points, n_padded, k_padded)
+    assert plan(196608, 1024, 1024) == 32 and plan(196608, 512, 1024) == 64 and plan(196608, 256, 256) == 384      # the benchmark's training sub-batch
