@@ -79,8 +79,8 @@ class NetFn(torch.autograd.Function):
       (``h.force_fp32_tape`` — ``Renderer.fit_tape = "fp32"`` — keeps the fp32 tape instead: the A/B arm).
     * ``"recompute"`` (``Renderer.tape_recompute``) — keep only the inputs and re-run the sub-batch's forward in tape mode inside the
       backward: one sub-batch's tape at a time (bounded by netchunk, not by N_rand), for one extra forward pass per step.  The
-      re-run must reproduce the forward the loss saw: the weights are checked (``h._key()``); the library's two run-time knobs
-      (MOFA_PIPE / MOFA_FUSED / MOFA_CHAIN) select between bit-identical forms of the one exact-fp32 arithmetic, so a ``reload_env()`` between
+      re-run must reproduce the forward the loss saw: the weights are checked (``h._key()``); the library's run-time knobs
+      (MOFA_PIPE / MOFA_FUSED / MOFA_CHAIN / MOFA_CHAIN_TRAIN) select between bit-identical forms of the one exact-fp32 arithmetic, so a ``reload_env()`` between
       forward and backward cannot change it (there is no other arithmetic mode in the library).
 
     ``pts`` given (``run_network(inputs, viewdirs, fn)`` under autograd): explicit points instead of ``o + d z``; the backward then
