@@ -665,13 +665,13 @@ int mofa_composite_backward(const float* raw, const float* z, int64_t z_row_stri
 // Weight gradient  dW[n][k] = sum_m G[m][n] * X[m][k]   (training, run_train.py:349) on fp32 MFMA.
 // The contraction runs over POINTS, so both operands are read "down the rows" of their panels: a lane (i = l&31,
 // g = l>>5) feeds A = G[m0+g][n0+i] and B = X[m0+g][k0+i] as single dwords (fp32 MFMA operands are one VGPR, so no
-// packing constraint).  Work is split over M: grid = tiles(n) x tiles(k) x splits; each workgroup reduces its slice
-// of points into a [TN x TK] partial, a second kernel sums the partials (deterministic, no atomics).
+// packing constraint).  Work is split over M: one workgroup per (output tile, split of the points), placed XCD-aware; each reduces its
+// slice of points into a [TN x TK] partial, a second kernel sums the partials (deterministic, no atomics).
 // ======================================================================================================
 namespace mofa {
 namespace {
 
-// The per-layer launch: grid = tiles(n) x tiles(k) x splits of the points (wg_split: whole row tiles, the chained form's plan)
+// The per-layer launch: one workgroup per (unit = output tile, split of the points — wg_split: whole row tiles, the chained form's plan)
 template <int TN, int TK>
 __global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ g, const float* __restrict__ x,
                                                   long long m_padded, long long n_points, int n_padded, int k_padded,
@@ -680,10 +680,19 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const float* __restrict__ g, c
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int MC = WgCfg<TN, TK>::MC;
     const int n_tiles = n_padded / TN;
-    const int nt = blockIdx.x % n_tiles, kt = blockIdx.x / n_tiles;
-    const int split = blockIdx.y;
+    // XCD-aware placement (round 6): workgroup b runs on XCD b % 8 (round-robin dispatch).  XCD x takes the splits of ITS row range (the
+    // plan's ranges are k_net_chain's), the units of one split on consecutive slots of that XCD: they start together and stream the
+    // split's G / X panels in step, so a G panel is fetched once for its 4 readers and an X panel once for its 8 — measured at the
+    // benchmark's training sub-batch: 7.78 -> 2.21 GB per launch through the L2s' fabric ports (algorithmic: 1.74), L2 hit 0.19 -> 0.76,
+    // +0.3 % (profiles/r06_ab_wgrad_xcd.md).  Same units, same splits, same partial sums: placement only.
+    const int units = n_tiles * (k_padded / TK);
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int j = local / units;
+    const int unit = local - j * units, split = xcd * sp.nspx + j;
+    const int nt = unit % n_tiles, kt = unit / n_tiles;
     int first, count;
     wg_split_rows(sp, split, first, count);
+    if (count <= 0) return;
     const long long total_chunks = (n_points + MC - 1) / MC;
     const long long c_begin = (long long)first * (kRowTile / MC);
     long long c_end = c_begin + (long long)count * (kRowTile / MC);
@@ -822,7 +831,8 @@ int launch_wgrad(const float* g, const float* x, long long m_padded, long long n
                  WgSplit sp, float* partial, float* bias_partial, hipStream_t st) {
     constexpr int PSTR = WgCfg<TN, TK>::MC * 16 + 16;
     const size_t lds = 2 * (size_t)(TN / 16 + TK / 16) * PSTR * sizeof(float);
-    const dim3 grid((n_padded / TN) * (k_padded / TK), sp.total);
+    const int units = (n_padded / TN) * (k_padded / TK);
+    const dim3 grid(8 * sp.nspx * units);                  // (slots of XCD ranges that hold fewer splits — the last, the empty ones — return at once)
     const int prof = mofa_internal_prof_open(st, 3);       // measurement session open? (bench.py --mode train)
     if (prof < 0) return MOFA_EHIP;
     hipLaunchKernelGGL((k_wgrad<TN, TK>), grid, dim3(256), lds, st, g, x, m_padded, n_points, n_padded, k_padded,
