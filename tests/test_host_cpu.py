@@ -278,3 +278,18 @@ def test_bench_roofline_hbm_prices_the_ray_kernels_against_the_hbm_peak():
     assert stale[0]["traffic"] is None and "null" in stale[0]["traffic_source"]
     dom, mf = bench.roofline_of(ms, launches, work, dt=1.0)                       # the MFMA roofline never picks a ray kernel
     assert dom == 5
+
+
+def test_committed_traffic_profiles_were_taken_on_the_committed_kernel_sources():
+    """bench.py quotes `roofline.traffic` / `roofline_hbm[*].traffic` from profiles/hbm_traffic_chain.json / hbm_traffic_rays.json only while the
+    kernel sources hash to what the rocprofv3 --pmc passes were taken on (`csrc_sha256` = build.csrc_digest()); otherwise the driver's line says
+    `traffic: null`.  The committed pair must therefore describe the committed sources — a source change without re-running
+    tools/gpu_profile_round6.sh fails HERE, not silently in the driver's line."""
+    import json
+    from mofanerf_amd import build
+    digest = build.csrc_digest()
+    for name in ("hbm_traffic_chain.json", "hbm_traffic_rays.json"):
+        tj = json.load(open(os.path.join(os.path.dirname(HERE), "profiles", name)))
+        assert tj["csrc_sha256"] == digest, f"profiles/{name} was taken on kernel sources {tj['csrc_sha256'][:16]}, the tree is {digest[:16]}"
+    chain = json.load(open(os.path.join(os.path.dirname(HERE), "profiles", "hbm_traffic_chain.json")))
+    assert chain["kernel"].startswith("mofa::k_net_chain<0>") and chain["bytes_per_launch"] > chain["algorithmic_bytes_per_launch"] > 0
