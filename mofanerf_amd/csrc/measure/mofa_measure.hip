@@ -372,6 +372,58 @@ __global__ __launch_bounds__(256, 2) void k_mfma_peak_probe(float* __restrict__ 
     if (s_ == 123.456f) out[0] = s_;   // keeps the accumulators alive
 }
 
+// ---- measurement aid (round 6): does the VECTOR pipe issue packed-fp32 FMAs in the shadow of the fp32 MFMAs? ---------------------------
+// The matrix pipe is the ceiling of every kernel in this library (157.3 TFLOP/s; the layer kernel sits at 0.95 of it), and the part's
+// vector fp32 peak is the same 157.3 TFLOP/s on a different pipe.  A v_mfma_f32_32x32x2_f32 occupies the matrix core for 16 passes of 4
+// cycles; this probe issues V independent v_pk_fma_f32 (64 lanes x 2 FMAs = 256 FLOP each) behind every MFMA of the peak probe's stream
+// and reports both rates — the bound of a layer kernel whose workgroups compute a strip of their output tile on the vector pipe.
+template <int V>
+__global__ __launch_bounds__(256, 2) void k_mfma_valu_probe(float* __restrict__ out, int iters) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    f32x2 vacc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) vacc[j] = f32x2{0.f, 0.f};
+    unsigned h = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u + 12345u);
+    float a[8], b[8];
+    f32x2 va[4], vb[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h = h * 1664525u + 1013904223u;
+        a[e] = __uint_as_float(0x3A000000u | (h & 0x05FFFFFFu) | ((h >> 3) & 0x80000000u));
+        h = h * 1664525u + 1013904223u;
+        b[e] = __uint_as_float(0x3A000000u | (h & 0x05FFFFFFu) | ((h >> 5) & 0x80000000u));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) va[e] = f32x2{a[e], a[e + 4]}, vb[e] = f32x2{b[e], b[e + 4]};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[e]), "v"(b[(e + i) & 7]));
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(vacc[(i * V + v) & 15]) : "v"(va[(e + v) & 3]), "v"(vb[(i + v) & 3]));
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(a[e]), "+v"(b[e]));
+    }
+    float s_ = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_ += acc[i][r];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s_ += vacc[j].x + vacc[j].y;
+    if (s_ == 123.456f) out[0] = s_;   // keeps the accumulators alive
+}
+
 // time stamps of a launch WITHOUT the epilogue's stores: what is left of the slot turnaround when there is nothing to drain
 struct TimelineSinkPolicy : TimelinePolicy {
     static constexpr bool kSinkEpilogue = true;
@@ -550,6 +602,24 @@ MOFA_MEASURE_API int mofa_measure_set_timeline(unsigned long long* buf) {
 }
 
 /* `blocks` workgroups of 4 waves running iters x 64 fp32 MFMAs each (tools/microbench_layer.py --peak) */
+MOFA_MEASURE_API int mofa_measure_mfma_valu_probe(float* out, int32_t blocks, int32_t iters, int32_t valu_per_mfma, void* stream) {
+    const dim3 g((unsigned)blocks), b(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (valu_per_mfma) {
+        case 0: hipLaunchKernelGGL(k_mfma_valu_probe<0>, g, b, 0, st, out, iters); break;
+        case 1: hipLaunchKernelGGL(k_mfma_valu_probe<1>, g, b, 0, st, out, iters); break;
+        case 2: hipLaunchKernelGGL(k_mfma_valu_probe<2>, g, b, 0, st, out, iters); break;
+        case 4: hipLaunchKernelGGL(k_mfma_valu_probe<4>, g, b, 0, st, out, iters); break;
+        case 6: hipLaunchKernelGGL(k_mfma_valu_probe<6>, g, b, 0, st, out, iters); break;
+        case 8: hipLaunchKernelGGL(k_mfma_valu_probe<8>, g, b, 0, st, out, iters); break;
+        case 12: hipLaunchKernelGGL(k_mfma_valu_probe<12>, g, b, 0, st, out, iters); break;
+        case 15: hipLaunchKernelGGL(k_mfma_valu_probe<15>, g, b, 0, st, out, iters); break;
+        case 16: hipLaunchKernelGGL(k_mfma_valu_probe<16>, g, b, 0, st, out, iters); break;
+        default: set_error("mfma_valu_probe: valu_per_mfma must be one of 0 1 2 4 6 8 12 15 16"); return MOFA_EINVAL;
+    }
+    return check_launch("k_mfma_valu_probe");
+}
+
 MOFA_MEASURE_API int mofa_measure_mfma_peak_probe(float* out, int32_t blocks, int32_t iters, int32_t random_operands, void* stream) {
     hipLaunchKernelGGL(k_mfma_peak_probe, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, iters, random_operands);
     return check_launch("k_mfma_peak_probe");

@@ -38,7 +38,7 @@ def test_library_exports_nothing_but_the_declared_abi():
     for f in os.listdir(csrc):
         if f.endswith((".hip", ".h")):
             src = open(os.path.join(csrc, f)).read()
-            for arm in ("MOFA_TIMELINE", "MOFA_ABLATE", "MOFA_SPLIT_FAKE", "MOFA_SETPRIO", "k_layer_persist", "k_layer_ring3", "k_mfma_peak_probe", "k_layer_split", "MOFA_GEMM"):
+            for arm in ("MOFA_TIMELINE", "MOFA_ABLATE", "MOFA_SPLIT_FAKE", "MOFA_SETPRIO", "k_layer_persist", "k_layer_ring3", "k_mfma_peak_probe", "k_mfma_valu_probe", "k_layer_split", "MOFA_GEMM"):
                 assert arm not in src, (f, arm)
 
 
