@@ -377,7 +377,10 @@ __global__ __launch_bounds__(256, 2) void k_mfma_peak_probe(float* __restrict__ 
 // vector fp32 peak is the same 157.3 TFLOP/s on a different pipe.  A v_mfma_f32_32x32x2_f32 occupies the matrix core for 16 passes of 4
 // cycles; this probe issues V independent v_pk_fma_f32 (64 lanes x 2 FMAs = 256 FLOP each) behind every MFMA of the peak probe's stream
 // and reports both rates — the bound of a layer kernel whose workgroups compute a strip of their output tile on the vector pipe.
-template <int V>
+// KIND: which instruction rides behind the MFMAs — 0 v_pk_fma_f32, 1 v_fma_f32, 2 v_add_u32, 3 v_mov_b32, 4 v_lshl_add_u32 (address
+// arithmetic), 5 ds_read_b128 (LDS, waited for once per 64 MFMAs), 6 s_add_u32 (scalar pipe), 7 v_pk_fma_f32 issued as ONE cluster of 8 V
+// instructions behind every 8th MFMA instead of V behind each (same count: does grouping save the switches?)
+template <int V, int KIND = 0>
 __global__ __launch_bounds__(256, 2) void k_mfma_valu_probe(float* __restrict__ out, int iters) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x16 acc[8];
@@ -386,8 +389,17 @@ __global__ __launch_bounds__(256, 2) void k_mfma_valu_probe(float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     f32x2 vacc[16];
+    unsigned iacc[16];
+    f32x4 lacc[4];
+    __shared__ f32x4 lds_src[256];
+    lds_src[threadIdx.x] = f32x4{1.f, 2.f, 3.f, 4.f};
+    __syncthreads();
+    const unsigned laddr = (unsigned)(threadIdx.x * 16);
+    unsigned sacc = blockIdx.x;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) vacc[j] = f32x2{0.f, 0.f};
+    for (int j = 0; j < 16; ++j) vacc[j] = f32x2{0.f, 0.f}, iacc[j] = (unsigned)j;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned h = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u + 12345u);
     float a[8], b[8];
     f32x2 va[4], vb[4];
@@ -406,11 +418,28 @@ __global__ __launch_bounds__(256, 2) void k_mfma_valu_probe(float* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[e]), "v"(b[(e + i) & 7]));
+                if constexpr (KIND == 7) {
+                    if (i == 7) {
 #pragma unroll
-                for (int v = 0; v < V; ++v)
-                    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(vacc[(i * V + v) & 15]) : "v"(va[(e + v) & 3]), "v"(vb[(i + v) & 3]));
+                        for (int v = 0; v < 8 * V; ++v)
+                            asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(vacc[v & 15]) : "v"(va[(e + v) & 3]), "v"(vb[v & 3]));
+                    }
+                } else {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        const int j = (i * V + v) & 15;
+                        if constexpr (KIND == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(vacc[j]) : "v"(va[(e + v) & 3]), "v"(vb[(i + v) & 3]));
+                        if constexpr (KIND == 1) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(vacc[j].x) : "v"(a[(e + v) & 7]), "v"(b[(i + v) & 7]));
+                        if constexpr (KIND == 2) asm volatile("v_add_u32 %0, %1, %0" : "+v"(iacc[j]) : "v"(h));
+                        if constexpr (KIND == 3) asm volatile("v_mov_b32 %0, %1" : "=v"(iacc[j]) : "v"(h));
+                        if constexpr (KIND == 4) asm volatile("v_lshl_add_u32 %0, %1, 2, %0" : "+v"(iacc[j]) : "v"(h));
+                        if constexpr (KIND == 5) asm volatile("ds_read_b128 %0, %1" : "=v"(lacc[j & 3]) : "v"(laddr));
+                        if constexpr (KIND == 6) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sacc));
+                    }
+                }
             }
         }
+        if constexpr (KIND == 5) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(a[e]), "+v"(b[e]));
     }
@@ -420,7 +449,10 @@ __global__ __launch_bounds__(256, 2) void k_mfma_valu_probe(float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) s_ += acc[i][r];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) s_ += vacc[j].x + vacc[j].y;
+    for (int j = 0; j < 16; ++j) s_ += vacc[j].x + vacc[j].y + (float)iacc[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s_ += lacc[j].x + lacc[j].w;
+    s_ += (float)sacc;
     if (s_ == 123.456f) out[0] = s_;   // keeps the accumulators alive
 }
 
@@ -602,6 +634,32 @@ MOFA_MEASURE_API int mofa_measure_set_timeline(unsigned long long* buf) {
 }
 
 /* `blocks` workgroups of 4 waves running iters x 64 fp32 MFMAs each (tools/microbench_layer.py --peak) */
+template <int KIND>
+static int launch_kind_probe(float* out, int32_t blocks, int32_t iters, int32_t v, hipStream_t st) {
+    const dim3 g((unsigned)blocks), b(256);
+    switch (v) {
+        case 1: hipLaunchKernelGGL((k_mfma_valu_probe<1, KIND>), g, b, 0, st, out, iters); break;
+        case 2: hipLaunchKernelGGL((k_mfma_valu_probe<2, KIND>), g, b, 0, st, out, iters); break;
+        case 4: hipLaunchKernelGGL((k_mfma_valu_probe<4, KIND>), g, b, 0, st, out, iters); break;
+        default: set_error("mfma_kind_probe: per_mfma must be 1, 2 or 4"); return MOFA_EINVAL;
+    }
+    return check_launch("k_mfma_valu_probe<kind>");
+}
+MOFA_MEASURE_API int mofa_measure_mfma_kind_probe(float* out, int32_t blocks, int32_t iters, int32_t per_mfma, int32_t kind, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    switch (kind) {
+        case 0: return launch_kind_probe<0>(out, blocks, iters, per_mfma, st);
+        case 1: return launch_kind_probe<1>(out, blocks, iters, per_mfma, st);
+        case 2: return launch_kind_probe<2>(out, blocks, iters, per_mfma, st);
+        case 3: return launch_kind_probe<3>(out, blocks, iters, per_mfma, st);
+        case 4: return launch_kind_probe<4>(out, blocks, iters, per_mfma, st);
+        case 5: return launch_kind_probe<5>(out, blocks, iters, per_mfma, st);
+        case 6: return launch_kind_probe<6>(out, blocks, iters, per_mfma, st);
+        case 7: return launch_kind_probe<7>(out, blocks, iters, per_mfma, st);
+        default: set_error("mfma_kind_probe: kind must be 0..7"); return MOFA_EINVAL;
+    }
+}
+
 MOFA_MEASURE_API int mofa_measure_mfma_valu_probe(float* out, int32_t blocks, int32_t iters, int32_t valu_per_mfma, void* stream) {
     const dim3 g((unsigned)blocks), b(256);
     hipStream_t st = (hipStream_t)stream;

@@ -218,7 +218,7 @@ __device__ __forceinline__ void mma_panel(const float* __restrict__ Xt, const fl
 // xb / x2b / wb: the tile's first panel in the two activation sources (x2b is only dereferenced when KT > k1p) and in the
 // weight pack; xstep / wstep: floats between consecutive panels; xrow0 / wrow0: this wave's first row in the staged X / W
 // tile; `wave`: index of the wave's 1 KiB slot inside each 4 KiB staging round.
-template <int NI, int NJ, int BM, int BN, class P = ShippedPolicy, int XAUX = 0>
+template <int NI, int NJ, int BM, int BN, class P = ShippedPolicy, int XAUX = 0, bool SCALAR_BASE = true>
 __device__ __forceinline__ void kloop_pipelined(const float* xb, const float* x2b, const float* wb, long long xstep, long long wstep,
                                                 int k1p, int KT, float* smem, int tid, int wave, int lane, int xrow0, int wrow0,
                                                 f32x16 (&acc)[NI][NJ], typename P::Probe& probe) {
@@ -227,6 +227,21 @@ __device__ __forceinline__ void kloop_pipelined(const float* xb, const float* x2
     int pq = 0;                                  // panel xb / wb point at
     const unsigned toff = (unsigned)tid * 4u;
     float* const lds_wave = smem + wave * 256;   // this wave's 1 KiB slot inside each 4 KiB round
+    // Byte offset of this lane's 16 B inside round r of an ACTIVATION panel: loop-invariant, ONE VGPR each, opaque to the optimiser, so that
+    // every activation request is `global_load_lds_dwordx4 v_off, s[base]` (scalar panel base + 32-bit lane offset).  Left to itself hipcc
+    // rebuilds the per-round addresses with 64-bit vector adds (`v_lshl_add_u64`: 8-12 per 128 MFMAs) inside the MFMA stream — and on this part
+    // a vector instruction in the shadow of an MFMA is NOT free: it takes 6-12 cycles of the matrix pipe (profiles/r06_probe_dual_issue.md).
+    // Measured (profiles/r06_ab_kloop_addr.md): the chained kernel 0.950 -> 0.960 of the peak, the per-layer kernels +1.3 ... +2.7 %.  The
+    // WEIGHT requests stay as hipcc forms them: forcing them too is slower in the per-layer kernels (-3 %; same file).  SCALAR_BASE = false
+    // (the generic persistent kernel, which has no register to spare for the offsets): hipcc's own addressing.
+    unsigned xoff[XR];
+    if constexpr (SCALAR_BASE) {
+#pragma unroll
+        for (int r = 0; r < XR; ++r) {
+            xoff[r] = ((unsigned)r * 1024u + (unsigned)tid * 4u) * 4u;
+            asm volatile("" : "+v"(xoff[r]));
+        }
+    }
 
     struct Frag {
         f32x4 a[NI], b[NJ];
@@ -234,8 +249,16 @@ __device__ __forceinline__ void kloop_pipelined(const float* xb, const float* x2
     auto request = [&](int stage) {              // LDS-DMA of panel pq into `stage`, then step to panel pq + 1
         float* xs = lds_wave + stage * STAGE;
         float* ws = xs + BM * 16;
+        if constexpr (SCALAR_BASE) {
 #pragma unroll
-        for (int r = 0; r < XR; ++r) glds16_policy<XAUX>(xb + (r * 1024u + toff), xs + r * 1024);
+            for (int r = 0; r < XR; ++r) asm volatile("" : "+v"(xoff[r]));   // (re-opaqued per request: a zero-extension hoisted out of the loop
+                                                                              //  would hide the 32-bit offset from the instruction selector)
+#pragma unroll
+            for (int r = 0; r < XR; ++r) glds16_policy<XAUX>((const float*)((const char*)xb + xoff[r]), xs + r * 1024);
+        } else {
+#pragma unroll
+            for (int r = 0; r < XR; ++r) glds16_policy<XAUX>(xb + (r * 1024u + toff), xs + r * 1024);
+        }
 #pragma unroll
         for (int r = 0; r < WR; ++r) glds16(wb + (r * 1024u + toff), ws + r * 1024);
         ++pq;

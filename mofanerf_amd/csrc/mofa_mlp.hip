@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused_generic(const FusedArgs a)
 
             if (a.pipe && !l0 && np - nbase >= BNMAX && KT >= 4 && !(KT & 1)) {
                 // full 256-feature block of an ordinary layer: the software-pipelined K loop of k_layer (bit-identical)
-                kloop_pipelined<NI, NJ, TM, BNMAX>(a.arena + l.x1_off + m0 * 16, l.k2p ? a.arena + l.x2_off + m0 * 16 : nullptr, wbase + (long long)nbase * 16,
+                kloop_pipelined<NI, NJ, TM, BNMAX, ShippedPolicy, 0, false>(a.arena + l.x1_off + m0 * 16, l.k2p ? a.arena + l.x2_off + m0 * 16 : nullptr, wbase + (long long)nbase * 16,
                                                    a.m_padded * 16, (long long)np * 16, l.k1p, KT, smem, tid, wn, lane, 0, wn * 64, acc, probe);
                 __syncthreads();    // every wave is done reading the stages before the next block / layer requests into them
             } else {
@@ -392,15 +392,30 @@ __device__ __forceinline__ void kloop_fused(const float* xb, const float* x2b, c
     struct Frag {
         f32x4 a[NI], b[NJ];
     };
+    // Byte offsets of this lane's 16 B inside round r of a panel, ONE VGPR each and opaque to the optimiser, and the weight-panel pointer kept
+    // in SGPRs across its per-panel step: every LDS-DMA request of the loop is then `global_load_lds_dwordx4 v_off, s[base]`.  Left to itself
+    // hipcc forms the addresses with 64-bit vector adds inside the MFMA stream (16 `v_lshl_add_u64` per 128 MFMAs here), and a vector
+    // instruction in the shadow of an MFMA takes 6-12 cycles of the matrix pipe on this part (profiles/r06_probe_dual_issue.md): this kernel
+    // 0.894 -> 0.922 of the peak (profiles/r06_ab_kloop_addr.md).
+    unsigned foff[WR > XR ? WR : XR];
+#pragma unroll
+    for (int r = 0; r < (WR > XR ? WR : XR); ++r) {
+        foff[r] = ((unsigned)r * 1024u + (unsigned)tid * 4u) * 4u;
+        asm volatile("" : "+v"(foff[r]));
+    }
     auto request = [&](int stage) {
         float* xs = lds_wave + stage * STAGE;
         float* ws = xs + BM * 16;
 #pragma unroll
-        for (int r = 0; r < XR; ++r) glds16(xb + (r * 1024u + toff), xs + r * 1024);
+        for (int r = 0; r < (WR > XR ? WR : XR); ++r) asm volatile("" : "+v"(foff[r]));   // (per request: a zero-extension hoisted out of the
+                                                                                           //  loop would hide the 32-bit offset from isel)
 #pragma unroll
-        for (int r = 0; r < WR; ++r) glds16(wb + (r * 1024u + toff), ws + r * 1024);
+        for (int r = 0; r < XR; ++r) glds16((const float*)((const char*)xb + foff[r]), xs + r * 1024);
+#pragma unroll
+        for (int r = 0; r < WR; ++r) glds16((const float*)((const char*)wb + foff[r]), ws + r * 1024);
         ++pq;
         wb += wstep;
+        asm volatile("" : "+s"(wb));              // (a scalar add per panel instead of base + step + offset on the vector pipe per request)
         xb = pq == k1p ? x2b : xb + xstep;
     };
     auto request_next = [&]() {                  // the next layer's panel 0 into stage 0

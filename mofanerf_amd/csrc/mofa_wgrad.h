@@ -203,20 +203,28 @@ __device__ __forceinline__ void wgrad_unit(const float* __restrict__ g, const fl
                 sq[q] = (pc < GP ? g + (long long)(n0 / 16 + pc) * m_padded * 16 : x + (long long)(k0 / 16 + pc - GP) * m_padded * 16) +
                         c_begin * (long long)(MC * 16);
             }
-            const unsigned loff = (unsigned)lane * 4u;
+            // (the lane's BYTE offset, opaque and re-opaqued per request: a zero-extension hipcc hoists out of the loop hides the 32-bit offset
+            //  from the instruction selector, which then forms base + offset with 64-bit VECTOR adds in the MFMA stream — 18 per 128 MFMAs here
+            //  — and a vector instruction in the shadow of an MFMA takes matrix-pipe time on this part: profiles/r06_probe_dual_issue.md;
+            //  the bases are pinned in SGPRs across their per-chunk step for the same reason)
+            unsigned loff = (unsigned)lane * 16u;
+            asm volatile("" : "+v"(loff));
             auto request = [&](int st) {
                 float* base = smem + st * STAGE;
+                asm volatile("" : "+v"(loff));
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
+                    const float* src = (const float*)((const char*)sq[q] + loff);
                     // (128 x 256 tile: pieces 0..7 are the G panels, i.e. q = 0, 1 for every wave — a compile-time choice)
                     if constexpr (GAUX != 0) {
                         static_assert(GP % 4 == 0 && PPP == 1, "G pieces must fill whole rounds of the four waves");
-                        if (q < GP / 4) glds16b_policy<GAUX>(sq[q] + loff, base + dstq[q]);
-                        else glds16b(sq[q] + loff, base + dstq[q]);
+                        if (q < GP / 4) glds16b_policy<GAUX>(src, base + dstq[q]);
+                        else glds16b(src, base + dstq[q]);
                     } else {
-                        glds16b(sq[q] + loff, base + dstq[q]);
+                        glds16b(src, base + dstq[q]);
                     }
                     sq[q] += MC * 16;
+                    asm volatile("" : "+s"(sq[q]));
                 }
             };
             auto bias_add = [&](const WFrag& f) {     // one column of waves owns the bias sums: a REAL wave-uniform branch
@@ -275,7 +283,8 @@ __device__ __forceinline__ void wgrad_unit(const float* __restrict__ g, const fl
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
             __builtin_amdgcn_s_barrier();
             readh(0, 0, fa);
-            for (long long c = 0; c + 2 < nch; c += 2) {
+            const int nch_u = __builtin_amdgcn_readfirstlane((int)nch);     // (workgroup-uniform: a scalar loop counter, not a vector compare per chunk pair)
+            for (int c = 0; c + 2 < nch_u; c += 2) {
                 half_a(0, fa, fb);
                 sync_point();
                 half_b(0, true, true, fb, fa);

@@ -44,6 +44,8 @@ def load():
     L.mofa_measure_last_error.restype = C.c_char_p
     L.mofa_measure_layer_forward.restype, L.mofa_measure_layer_forward.argtypes = C.c_int, LAYER_ARGS
     L.mofa_measure_set_timeline.restype, L.mofa_measure_set_timeline.argtypes = C.c_int, [_f]
+    L.mofa_measure_mfma_kind_probe.restype = C.c_int
+    L.mofa_measure_mfma_kind_probe.argtypes = [_f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]
     L.mofa_measure_mfma_valu_probe.restype = C.c_int
     L.mofa_measure_mfma_valu_probe.argtypes = [_f, C.c_int32, C.c_int32, C.c_int32, _f]
     L.mofa_measure_mfma_peak_probe.restype = C.c_int

@@ -49,6 +49,36 @@ if len(sys.argv) > 1 and sys.argv[1] == "hold":
           f"({(mfma + valu) / PEAK * 100:.1f} % of the fp32 matrix peak)", flush=True)
     sys.exit(0)
 
+if len(sys.argv) > 1 and sys.argv[1] == "kinds":
+    # what ONE instruction of each kind costs the matrix pipe when it rides behind every MFMA: cycles added per MFMA (64 = one MFMA)
+    g = Lm.mofa_measure_mfma_kind_probe
+    KINDS = ["v_pk_fma_f32", "v_fma_f32", "v_add_u32", "v_mov_b32", "v_lshl_add_u32", "ds_read_b128", "s_add_u32", "v_pk_fma_f32, 8 V clustered behind every 8th MFMA"]
+
+    def timed_kind(blocks, iters, V, kind, reps=5):
+        for _ in range(2):
+            build_measure.check(Lm, g(lib.ptr(out), blocks, iters, V, kind, lib.stream()), "probe")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            build_measure.check(Lm, g(lib.ptr(out), blocks, iters, V, kind, lib.stream()), "probe")
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    for blocks, wps in ((512, 2), (256, 1)):
+        base, _, _ = timed(blocks, 2048, 0)
+        per_mfma0 = base * 1e-3 / (2048 * 64 * (2 if wps == 2 else 1)) * 2.39e9     # cycles per MFMA per SIMD stream (two waves share a SIMD)
+        print(f"\n{wps} wave(s) per SIMD; pure MFMA stream: {base:.3f} ms = {per_mfma0:.1f} cycles per MFMA at 2.39 GHz\n")
+        print("| instruction behind every MFMA | 1 per MFMA: cycles added per MFMA | 2 per MFMA | 4 per MFMA |\n|---|---|---|---|")
+        for kind, name in enumerate(KINDS):
+            cells = []
+            for V in (1, 2, 4):
+                ms = timed_kind(blocks, 2048, V, kind)
+                cells.append(f"{(ms / base - 1.0) * per_mfma0:+.1f}")
+            print(f"| `{name}` | " + " | ".join(cells) + " |", flush=True)
+    sys.exit(0)
+
 print("| V (v_pk_fma_f32 per MFMA) | waves / SIMD | ms | MFMA TFLOP/s | vector TFLOP/s | sum | sum / 157.3 |\n|---|---|---|---|---|---|---|")
 for blocks, wps in ((512, 2), (256, 1)):
     for V in (0, 1, 2, 4, 6, 8, 12, 15, 16):
