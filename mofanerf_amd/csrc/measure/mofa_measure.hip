@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_valu_probe(float* __restrict__ 
                         if constexpr (KIND == 3) asm volatile("v_mov_b32 %0, %1" : "=v"(iacc[j]) : "v"(h));
                         if constexpr (KIND == 4) asm volatile("v_lshl_add_u32 %0, %1, 2, %0" : "+v"(iacc[j]) : "v"(h));
                         if constexpr (KIND == 5) asm volatile("ds_read_b128 %0, %1" : "=v"(lacc[j & 3]) : "v"(laddr));
-                        if constexpr (KIND == 6) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sacc));
+                        if constexpr (KIND == 6) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sacc) : : "scc");
                     }
                 }
             }
