@@ -453,61 +453,74 @@ __device__ __forceinline__ void store_tile_staged(const f32x16 (&acc)[NI][NJ], c
 // first turns the accumulator fragments into 1 KiB contiguous wave rows, so the optional reads of dX_old and of the saved
 // activation are fully coalesced 1 KiB loads (all four of a slice in flight together) instead of 16 B per lane at a 64-byte
 // stride, and ACC / MASK are compile-time: no wait sits between a load and the next one.  Same arithmetic as the strided form.
-// MASK: 0 none, 1 the saved fp32 activation, 2 the mask-only tape's bits (one 32-byte wave-uniform load per KiB instead of a KiB).
+// MASK: 0 none, 1 the saved fp32 activation, 2 the mask-only tape's bits.
+// The mask of slice s + 1 is requested BEFORE slice s goes through the window (two register sets, the slice loop fully unrolled): a
+// wave then waits for ONE global round trip per tile instead of one per slice (eight per tile: the form before measured 2 % under the
+// forward tile, whose epilogue loads nothing but its bias row).  MASK = 2: a lane needs bit `lane` of the slice's 16 words, i.e. bit
+// lane & 31 of ONE dword of each (the half lane >> 5 selects) — 16 dword loads at immediate offsets into 16 registers (before: the
+// whole 128 bytes in every lane, 32 registers), and the flag is applied as `value & sign-extended bit` (v_bfe_i32 + v_and: two vector
+// instructions per value instead of two 64-bit ands, a 64-bit compare and a select; 0 -> +0.0f, 1 -> the value's own bits: identical).
 template <int NI, int NJ, bool ACC, int MASK>
 __device__ __forceinline__ void store_tile_staged_bwd(const f32x16 (&acc)[NI][NJ], float* __restrict__ y, const float* __restrict__ mask,
                                                       long long m_padded, long long m_first, int n_first, int lane, float* win,
                                                       const unsigned long long* __restrict__ mask_bits = nullptr) {
     static_assert(NJ % 2 == 0, "row halves of 64 points");
+    constexpr int NH = NJ / 2, NS = NI * 2 * NH;                    // slices of 64 points x 16 features (4 KiB) per wave tile
     const int lr = lane & 31, g = lane >> 5, msw = (lr >> 2) & 3;
+    f32x4 act[2][4];
+    unsigned mw[2][16];
+    auto slice_off = [&](int s) -> long long {                      // float offset of slice s = (i, qh, jh) in the panels
+        const int i = s / (2 * NH), qh = (s / NH) & 1, jh = s % NH;
+        return ((long long)((n_first >> 4) + 2 * i + qh) * m_padded + m_first) * 16 + jh * 1024;
+    };
+    auto request_mask = [&](int s, int b) {
+        const long long po = slice_off(s);
+        if constexpr (MASK == 1) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int qh = 0; qh < 2; ++qh) {
-            const long long poff = ((long long)((n_first >> 4) + 2 * i + qh) * m_padded + m_first) * 16;
-#pragma unroll
-            for (int jh = 0; jh < NJ / 2; ++jh) {
-                const long long off = poff + jh * 1024 + lane * 4;
-                f32x4 old[4], act[4];
-                unsigned long long mb[4][4];
-                if constexpr (ACC) {
-#pragma unroll
-                    for (int it = 0; it < 4; ++it) old[it] = *(const f32x4*)(y + off + it * 256);
-                }
-                if constexpr (MASK == 1) {
-#pragma unroll
-                    for (int it = 0; it < 4; ++it) act[it] = *(const f32x4*)(mask + off + it * 256);
-                }
-                if constexpr (MASK == 2) {
-                    const unsigned long long* w = mask_bits + ((poff + jh * 1024) >> 8) * 4;      // wave-uniform: 4 blocks x 4 words
-#pragma unroll
-                    for (int it = 0; it < 4; ++it)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) mb[it][c] = w[it * 4 + c];
-                }
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int qq = 0; qq < 2; ++qq) {
-                        const int j = 2 * jh + jj, q = 2 * qh + qq;
-                        f32x4 v;
-                        v.x = acc[i][j][4 * q + 0], v.y = acc[i][j][4 * q + 1], v.z = acc[i][j][4 * q + 2], v.w = acc[i][j][4 * q + 3];
-                        *(f32x4*)(win + (32 * jj + lr) * 16 + (((2 * qq + g) ^ msw) << 2)) = v;
-                    }
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    f32x4 v = *(const f32x4*)(win + it * 256 + lane * 4);
-                    if constexpr (ACC) v.x += old[it].x, v.y += old[it].y, v.z += old[it].z, v.w += old[it].w;
-                    if constexpr (MASK == 1)
-                        v.x = act[it].x > 0.f ? v.x : 0.f, v.y = act[it].y > 0.f ? v.y : 0.f, v.z = act[it].z > 0.f ? v.z : 0.f,
-                        v.w = act[it].w > 0.f ? v.w : 0.f;
-                    if constexpr (MASK == 2)
-                        v.x = ((mb[it][0] >> lane) & 1ull) ? v.x : 0.f, v.y = ((mb[it][1] >> lane) & 1ull) ? v.y : 0.f,
-                        v.z = ((mb[it][2] >> lane) & 1ull) ? v.z : 0.f, v.w = ((mb[it][3] >> lane) & 1ull) ? v.w : 0.f;
-                    *(f32x4*)(y + off + it * 256) = v;
-                }
-            }
+            for (int it = 0; it < 4; ++it) act[b][it] = *(const f32x4*)(mask + po + lane * 4 + it * 256);
         }
+        if constexpr (MASK == 2) {
+            const unsigned* w = (const unsigned*)(mask_bits + (po >> 8) * 4) + g;      // 4 blocks x 4 words; this lane's half of each
+#pragma unroll
+            for (int k = 0; k < 16; ++k) mw[b][k] = w[2 * k];
+        }
+    };
+    request_mask(0, 0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i = s / (2 * NH), qh = (s / NH) & 1, jh = s % NH, b = s & 1;
+        const long long off = slice_off(s) + lane * 4;
+        f32x4 old[4];
+        if constexpr (ACC) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) old[it] = *(const f32x4*)(y + off + it * 256);
+        }
+        if (s + 1 < NS) request_mask(s + 1, b ^ 1);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int j = 2 * jh + jj, q = 2 * qh + qq;
+                f32x4 v;
+                v.x = acc[i][j][4 * q + 0], v.y = acc[i][j][4 * q + 1], v.z = acc[i][j][4 * q + 2], v.w = acc[i][j][4 * q + 3];
+                *(f32x4*)(win + (32 * jj + lr) * 16 + (((2 * qq + g) ^ msw) << 2)) = v;
+            }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            f32x4 v = *(const f32x4*)(win + it * 256 + lane * 4);
+            if constexpr (ACC) v.x += old[it].x, v.y += old[it].y, v.z += old[it].z, v.w += old[it].w;
+            if constexpr (MASK == 1)
+                v.x = act[b][it].x > 0.f ? v.x : 0.f, v.y = act[b][it].y > 0.f ? v.y : 0.f, v.z = act[b][it].z > 0.f ? v.z : 0.f,
+                v.w = act[b][it].w > 0.f ? v.w : 0.f;
+            if constexpr (MASK == 2) {
+                v.x = __int_as_float(__float_as_int(v.x) & __builtin_amdgcn_sbfe((int)mw[b][it * 4 + 0], lr, 1));
+                v.y = __int_as_float(__float_as_int(v.y) & __builtin_amdgcn_sbfe((int)mw[b][it * 4 + 1], lr, 1));
+                v.z = __int_as_float(__float_as_int(v.z) & __builtin_amdgcn_sbfe((int)mw[b][it * 4 + 2], lr, 1));
+                v.w = __int_as_float(__float_as_int(v.w) & __builtin_amdgcn_sbfe((int)mw[b][it * 4 + 3], lr, 1));
+            }
+            *(f32x4*)(y + off + it * 256) = v;
+        }
+    }
 }
 
 // BN: feature-tile height; L0: X tile is generated (positional encoding) instead of loaded; operands are staged by LDS-DMA.
