@@ -40,13 +40,45 @@ def active(group=None) -> bool:
     return dist.get_world_size(group) > 1 or force_collectives()
 
 
+def ranks_share_a_device(local_world: int, n_devices: int) -> bool:
+    """True when the ranks of this node outnumber its GPUs, i.e. at least two processes drive one device (the single-GPU functional
+    form of an N-rank job; never the deployment: one process per GPU)."""
+    return n_devices > 0 and local_world > n_devices
+
+
+def per_layer_launches_when_sharing(local_world: int, n_devices: int) -> bool:
+    """The chained launch (csrc/mofa_mlp.hip ``k_net_chain``) is a persistent kernel whose workgroups WAIT for one another.  That is
+    safe while one process owns the device: a ticket drawn earlier is always held by a resident or finished workgroup.  When several
+    processes share a device the hardware scheduler time-slices their queues (compute-wave save / restore) and restores a queue's
+    waves piecemeal into whatever slots other processes' persistent workgroups leave free — waiting workgroups can then hold the chip
+    while the workgroups they wait for sit saved in memory.  Observed with eight ranks at the full benchmark size on one MI355X
+    (`profiles/r06_shared_device_chain.md`): a dependency wait ran out of its budget (seconds; eight times the budget changed
+    nothing), the launch ended incomplete and the library — as designed — poisoned its outputs and raised ``MofaError``.  Loud, never
+    wrong, but not a frame.  So ranks that share a device take the per-layer launches (bit-identical results, about 1 % slower,
+    no inter-workgroup waits), and say so once.  An explicit ``MOFA_CHAIN`` of the caller wins.  Returns True when it switched."""
+    if not ranks_share_a_device(local_world, n_devices) or os.environ.get("MOFA_CHAIN") is not None:
+        return False
+    os.environ["MOFA_CHAIN"] = "0"
+    from . import lib
+    if lib._lib is not None:            # the knobs are read once at load: a library that is already loaded re-reads them
+        lib.reload_env()
+    import warnings
+    warnings.warn(f"{local_world} ranks share {n_devices} device(s): taking the per-layer launches (MOFA_CHAIN=0; bit-identical, about 1 % "
+                  "slower) — the chained launch's workgroups wait for one another and can starve when the hardware scheduler time-slices "
+                  "several processes on one device", lib.MofaWarning, stacklevel=3)
+    return True
+
+
 def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     """Initialise the default process group from torchrun's env; returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 or force_collectives():
+        _rccl_env()                      # (before anything below can initialise the HIP runtime)
+    if world > 1 and torch.cuda.is_available():
+        per_layer_launches_when_sharing(int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), torch.cuda.device_count())
     if (world > 1 or force_collectives()) and not dist.is_initialized():
-        _rccl_env()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:      # MOFA_DIST_BACKEND=gloo lets several ranks share one GPU (functional test of the N>1 path)

@@ -153,8 +153,9 @@ class HipNet:
         raise lib.MofaError(f"a chained launch (k_net_chain) of {self.shape} did not complete: "
                             f"{'a dependency wait timed out; ' if w[0] & 1 else ''}{'tiles missing; ' if w[0] & 2 else ''}"
                             f"last launch finished {w[3]} of {w[4]} tiles, {w[5]} bad of {w[1]} chained launches — its outputs were "
-                            "overwritten with NaN.  (A CU-masked stream or a changed compute partition leaves XCD queues unworked; "
-                            "MOFA_CHAIN=0 selects the per-layer launches.)")
+                            "overwritten with NaN.  (A CU-masked stream or a changed compute partition leaves XCD queues unworked; several "
+                            "PROCESSES sharing this device can starve a dependency wait — the chained launch assumes one process per GPU; "
+                            "MOFA_CHAIN=0 selects the per-layer launches: the same bits, about 1 % slower.)")
 
     def check_verdict(self, block: bool = False) -> None:
         """Raise ``MofaError`` if a chained launch of this network ended incomplete (its outputs were overwritten with NaN by the

@@ -104,3 +104,24 @@ def test_all_gather_tiles_gloo_world8_benchmark_frame_shape():
     """The shape the 8-GPU run takes: a 512 x 512 frame split into eight 64-row blocks, ONE all-gather written straight into the
     frame (equal blocks: no padding path), max-over-ranks timing — on gloo / CPU."""
     mp.spawn(_worker, args=(8, _free_port(), 512 * 512, 512), nprocs=8, join=True)
+
+
+def test_ranks_sharing_a_device_take_the_per_layer_launches(monkeypatch):
+    """Round 6: eight processes on ONE MI355X at the full benchmark size ended a chained launch on a dependency-wait time-out (the
+    hardware scheduler time-slices the processes; waiting workgroups held the chip while the workgroups they waited for sat saved in
+    memory) — loud (NaN + MofaError), never wrong, but not a frame.  Ranks that share a device therefore select MOFA_CHAIN=0 (the
+    per-layer launches: same bits) with a MofaWarning; one rank per device — the deployment — and an explicit setting are left alone."""
+    import warnings
+    from mofanerf_amd import lib
+    assert mdist.ranks_share_a_device(8, 1) and mdist.ranks_share_a_device(2, 1) and mdist.ranks_share_a_device(9, 8)
+    assert not mdist.ranks_share_a_device(8, 8) and not mdist.ranks_share_a_device(1, 1) and not mdist.ranks_share_a_device(4, 8)
+    assert not mdist.ranks_share_a_device(2, 0)                       # no GPU at all (the CPU tests): nothing to decide
+    monkeypatch.setattr(lib, "_lib", None)                            # (no library in a CPU run: nothing to re-read)
+    monkeypatch.delenv("MOFA_CHAIN", raising=False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert mdist.per_layer_launches_when_sharing(8, 8) is False and "MOFA_CHAIN" not in os.environ and not w
+        assert mdist.per_layer_launches_when_sharing(8, 1) is True and os.environ["MOFA_CHAIN"] == "0"
+        assert len(w) == 1 and issubclass(w[0].category, lib.MofaWarning) and "per-layer" in str(w[0].message)
+    monkeypatch.setenv("MOFA_CHAIN", "1")                             # the caller's explicit choice wins
+    assert mdist.per_layer_launches_when_sharing(8, 1) is False and os.environ["MOFA_CHAIN"] == "1"

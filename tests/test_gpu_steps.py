@@ -128,8 +128,8 @@ def test_bench_self_spawns_two_ranks_and_emits_one_contract_json_line():
 
 def test_bench_eight_ranks_validate_themselves_and_reproduce_the_one_rank_frame(tmp_path):
     """VERDICT r4 missing 2: an N > 1 line must carry its own evidence before an 8-GPU node ever runs it.  `bench.py --gpus 8`
-    (eight ranks sharing this GPU over gloo — the functional form of the driver's SCALE run; the fine network is wide enough for the
-    chained launch, so eight processes' persistent kernels contend for one chip) against `--gpus 1` on the same views:
+    (eight ranks sharing this GPU over gloo — the functional form of the driver's SCALE run; ranks sharing a device take the per-layer
+    launches, see the last assertion) against `--gpus 1` (the chained launch) on the same views:
     * `frame_sha256` of the GATHERED frame equals the one-rank digest (rows rendered by eight different ranks, exchanged by the
       all-gather: chunk invariance is bit-exact, so any wrong byte anywhere shows);
     * `parity` is present at N = 8: 256 rays drawn over the whole gathered frame, re-rendered on rank 0 (bit-identical to the pixels
@@ -155,7 +155,12 @@ def test_bench_eight_ranks_validate_themselves_and_reproduce_the_one_rank_frame(
         assert max(par["rgb_max_abs"], par["acc_max_abs"], par["coarse_rgb_max_abs"]) <= 1e-4
     c = j8["collective"]
     assert 0 < c["compute_ms_per_step_min_over_ranks"] <= c["compute_ms_per_step_max_over_ranks"] and c["avg_ms_per_step_rank0"] >= 0
-    assert "k_net_chain" in j8["roofline"]["kernel"] + " ".join(o["kernel"] for o in j8["roofline"]["other_mfma_kernels"])
+    # ranks that SHARE a device take the per-layer launches (dist.per_layer_launches_when_sharing: the chained launch's workgroups wait for
+    # one another and can starve under the hardware scheduler's time slicing of several processes — observed at full size, round 6); the
+    # one-rank line takes the chained launch: the two digests above compare the two launch forms as well
+    k8 = j8["roofline"]["kernel"] + " ".join(o["kernel"] for o in j8["roofline"]["other_mfma_kernels"])
+    k1 = j1["roofline"]["kernel"] + " ".join(o["kernel"] for o in j1["roofline"]["other_mfma_kernels"])
+    assert "k_net_chain" not in k8 and "k_layer" in k8 and "k_net_chain" in k1
 
 
 def test_bulk_render_eight_ranks_cover_the_identity_list_exactly_once(tmp_path):
