@@ -55,7 +55,10 @@ def per_layer_launches_when_sharing(local_world: int, n_devices: int) -> bool:
     (`profiles/r06_shared_device_chain.md`): a dependency wait ran out of its budget (seconds; eight times the budget changed
     nothing), the launch ended incomplete and the library — as designed — poisoned its outputs and raised ``MofaError``.  Loud, never
     wrong, but not a frame.  So ranks that share a device take the per-layer launches (bit-identical results, about 1 % slower,
-    no inter-workgroup waits), and say so once.  An explicit ``MOFA_CHAIN`` of the caller wins.  Returns True when it switched."""
+    no inter-workgroup waits), and say so once.  An explicit ``MOFA_CHAIN`` of the caller wins.  Returns True when it switched.
+    (The test is the launcher's view — ranks on this node against VISIBLE devices.  A launcher that narrows each rank's visibility to its
+    own GPU makes every rank see one device and N ranks: the per-layer launches are then taken needlessly — correct, about 1 % slower;
+    export MOFA_CHAIN=1 there.  torch.distributed.run, the driver's launcher, leaves all GPUs visible to every rank.)"""
     if not ranks_share_a_device(local_world, n_devices) or os.environ.get("MOFA_CHAIN") is not None:
         return False
     os.environ["MOFA_CHAIN"] = "0"
