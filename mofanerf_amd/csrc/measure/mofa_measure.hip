@@ -678,6 +678,49 @@ MOFA_MEASURE_API int mofa_measure_mfma_valu_probe(float* out, int32_t blocks, in
     return check_launch("k_mfma_valu_probe");
 }
 
+// Does a RESIDENT workgroup stay where it was dispatched while several PROCESSES share the device?  (round 6: profiles/r06_shared_device_chain.md —
+// k_net_chain keeps producer and consumer of a row tile on one XCD, read once at entry.)  Every workgroup holds a slot like k_net_chain's (two per CU:
+// 64 KiB of LDS) for `ticks` of the 100 MHz real-time counter and polls its XCC_ID / HW_ID registers and the clock; it reports
+// {XCC_ID at entry, XCC_ID changes, HW_ID changes (CU / SE / SIMD ...), longest gap between two polls (= time off the chip), polls, last XCC_ID,
+//  entry time, exit time}.
+__global__ __launch_bounds__(256, 2) void k_xcc_watch(unsigned long long* __restrict__ out, unsigned long long ticks) {
+    extern __shared__ float smem_watch[];
+    if (threadIdx.x == 255) smem_watch[16 * 1024 - 1] = 0.f;      // (the allocation is what matters)
+    unsigned x0, h0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x0));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(h0));
+    x0 &= 7u;
+    unsigned xl = x0, hl = h0, xch = 0, hch = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long prev = t0, gap = 0, polls = 0, t = t0;
+    while (t - t0 < ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        t = __builtin_amdgcn_s_memrealtime();
+        if (t - prev > gap) gap = t - prev;
+        prev = t;
+        unsigned x, h;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(h));
+        x &= 7u;
+        if (x != xl) ++xch, xl = x;
+        if (h != hl) ++hch, hl = h;
+        ++polls;
+    }
+    if (threadIdx.x == 0) {
+        unsigned long long* o = out + (size_t)blockIdx.x * 8;
+        o[0] = x0, o[1] = xch, o[2] = hch, o[3] = gap, o[4] = polls, o[5] = xl, o[6] = t0, o[7] = t;
+    }
+}
+MOFA_MEASURE_API int mofa_measure_xcc_watch(unsigned long long* out, int32_t blocks, unsigned long long ticks, void* stream) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)k_xcc_watch, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return check_launch("hipFuncSetAttribute(k_xcc_watch)");
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_xcc_watch, dim3((unsigned)blocks), dim3(256), 64 * 1024, (hipStream_t)stream, out, ticks);
+    return check_launch("k_xcc_watch");
+}
+
 MOFA_MEASURE_API int mofa_measure_mfma_peak_probe(float* out, int32_t blocks, int32_t iters, int32_t random_operands, void* stream) {
     hipLaunchKernelGGL(k_mfma_peak_probe, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, iters, random_operands);
     return check_launch("k_mfma_peak_probe");

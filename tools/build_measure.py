@@ -48,6 +48,8 @@ def load():
     L.mofa_measure_mfma_kind_probe.argtypes = [_f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f]
     L.mofa_measure_mfma_valu_probe.restype = C.c_int
     L.mofa_measure_mfma_valu_probe.argtypes = [_f, C.c_int32, C.c_int32, C.c_int32, _f]
+    L.mofa_measure_xcc_watch.restype = C.c_int
+    L.mofa_measure_xcc_watch.argtypes = [_f, C.c_int32, C.c_uint64, _f]
     L.mofa_measure_mfma_peak_probe.restype = C.c_int
     L.mofa_measure_mfma_peak_probe.argtypes = [_f, C.c_int32, C.c_int32, C.c_int32, _f]
     return L
