@@ -314,3 +314,24 @@ def test_the_hot_k_loops_carry_no_vector_address_arithmetic():
     main = max(c["mofa::k_wgrad<128, 256>"], key=lambda l: l["mfma"])
     assert main["mfma"] == 128 and not any(op.startswith(("v_lshl_add_u64", "v_cmp")) for op in main["vector_ops"]), main
     assert set(main["vector_ops"]) <= {"v_pk_add_f32", "v_add_u32_e32"}, main      # the bias sums (one wave in eight, behind a scalar branch) + 4 LDS address adds
+
+
+def test_the_backward_epilogue_requests_its_mask_one_slice_ahead():
+    """ISA-level regression guard for round 6's last kernel change (profiles/r06_ab_bwd_epilogue.md; no GPU needed).  The backward-data epilogue
+    walks a wave's tile in eight 4 KiB slices; it used to request each slice's ReLU mask at the top of the slice and wait for it with
+    `s_waitcnt vmcnt(0)` — eight exposed global round trips per tile — and to apply a mask bit with two 64-bit ands, a 64-bit compare and a select.
+    Now the next slice's mask is in flight while the current slice goes through the LDS window, the bits arrive as ONE dword per lane and word and
+    are applied as `value & v_bfe_i32(word, lane & 31, 1)`.  In the shipped code object of the chained backward-data kernel that reads: 128 sign-extending
+    bit-field extracts per epilogue form (the plain and the accumulating form keep the old one: it runs on two of 26 products), no 64-bit compare in the
+    plain form's share, and waits that leave more than a slice's requests in flight."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kloop_census
+    kernels = {name: ins for name, ins, _ in kloop_census.disassemble(build.build())}
+    ins = kernels["mofa::k_net_chain<2>"]
+    ops = [op for op, _ in ins]
+    assert ops.count("v_bfe_i32") == 128, ops.count("v_bfe_i32")                      # 8 slices x 16 values of the mask-bit form
+    assert ops.count("v_cmp_ne_u64_e32") <= 128                                       # only chain_store_bwd_acc's (the accumulating form) are left
+    waits = [int(m.group(1)) for op, args in ins if op == "s_waitcnt" for m in [re.search(r"vmcnt\((\d+)\)", args)] if m]
+    assert sum(1 for w in waits if w >= 16) >= 16, sorted(set(waits))                # waits with a whole slice's 16 dword requests still in flight
