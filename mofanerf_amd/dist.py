@@ -46,6 +46,12 @@ def ranks_share_a_device(local_world: int, n_devices: int) -> bool:
     return n_devices > 0 and local_world > n_devices
 
 
+def default_backend(cuda: bool, sharing: bool) -> str:
+    """``nccl`` (= RCCL over xGMI) with one rank per GPU; ``gloo`` on the CPU and when ranks SHARE a device — RCCL refuses two ranks on one
+    GPU, so the single-GPU functional form of an N-rank job (tensors staged through the host, see ``all_gather_tiles``) needs no flag."""
+    return "nccl" if cuda and not sharing else "gloo"
+
+
 def per_layer_launches_when_sharing(local_world: int, n_devices: int) -> bool:
     """The chained launch (csrc/mofa_mlp.hip ``k_net_chain``) is a persistent kernel whose workgroups WAIT for one another.  That is
     safe while one process owns the device: a ticket drawn earlier is always held by a resident or finished workgroup.  When several
@@ -79,13 +85,16 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 or force_collectives():
         _rccl_env()                      # (before anything below can initialise the HIP runtime)
+    sharing = False
     if world > 1 and torch.cuda.is_available():
-        per_layer_launches_when_sharing(int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), torch.cuda.device_count())
+        local_world, n_dev = int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), torch.cuda.device_count()
+        sharing = ranks_share_a_device(local_world, n_dev)
+        per_layer_launches_when_sharing(local_world, n_dev)
     if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:      # MOFA_DIST_BACKEND=gloo lets several ranks share one GPU (functional test of the N>1 path)
-            backend = os.environ.get("MOFA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            backend = os.environ.get("MOFA_DIST_BACKEND") or default_backend(torch.cuda.is_available(), sharing)
         if torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

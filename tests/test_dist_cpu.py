@@ -116,6 +116,7 @@ def test_ranks_sharing_a_device_take_the_per_layer_launches(monkeypatch):
     assert mdist.ranks_share_a_device(8, 1) and mdist.ranks_share_a_device(2, 1) and mdist.ranks_share_a_device(9, 8)
     assert not mdist.ranks_share_a_device(8, 8) and not mdist.ranks_share_a_device(1, 1) and not mdist.ranks_share_a_device(4, 8)
     assert not mdist.ranks_share_a_device(2, 0)                       # no GPU at all (the CPU tests): nothing to decide
+    assert mdist.default_backend(True, False) == "nccl" and mdist.default_backend(True, True) == "gloo" and mdist.default_backend(False, False) == "gloo"
     monkeypatch.setattr(lib, "_lib", None)                            # (no library in a CPU run: nothing to re-read)
     monkeypatch.delenv("MOFA_CHAIN", raising=False)
     with warnings.catch_warnings(record=True) as w:
