@@ -674,6 +674,9 @@ def main():
         if mdist.active():
             out["rccl_ranks"] = world
             out["backend"] = torch.distributed.get_backend()
+            if mdist.shared_device:       # the single-GPU functional form of an N-rank job: the line validates the N > 1 code path, it is NOT a scaling point
+                out["functional_only"] = (f"{mdist.shared_device[0]} ranks share {mdist.shared_device[1]} device(s): per-layer launches, gloo staging through the host; "
+                                          "the aggregate rate is one device's — not a scaling measurement")
             out["collective"] = {"what": {"render": "all_gather_into_tensor of the [rays/N,5] fp32 tiles, written straight into the frame",
                                           "fit": "none (replicas)", "train": "all_reduce of the flat fp32 gradient bucket"}[a.mode],
                                  "avg_ms_per_step_rank0": round(comm, 4)}

@@ -46,6 +46,9 @@ def ranks_share_a_device(local_world: int, n_devices: int) -> bool:
     return n_devices > 0 and local_world > n_devices
 
 
+shared_device = None     # (ranks on this node, visible GPUs) when init_from_env found ranks sharing a device, else None
+
+
 def default_backend(cuda: bool, sharing: bool) -> str:
     """``nccl`` (= RCCL over xGMI) with one rank per GPU; ``gloo`` on the CPU and when ranks SHARE a device — RCCL refuses two ranks on one
     GPU, so the single-GPU functional form of an N-rank job (tensors staged through the host, see ``all_gather_tiles``) needs no flag."""
@@ -85,10 +88,12 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 or force_collectives():
         _rccl_env()                      # (before anything below can initialise the HIP runtime)
+    global shared_device
     sharing = False
     if world > 1 and torch.cuda.is_available():
         local_world, n_dev = int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), torch.cuda.device_count()
         sharing = ranks_share_a_device(local_world, n_dev)
+        shared_device = (local_world, n_dev) if sharing else None
         per_layer_launches_when_sharing(local_world, n_dev)
     if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
